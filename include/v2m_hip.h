@@ -1,0 +1,212 @@
+/*
+ * v2m_hip.h -- C ABI of the MI355X (gfx950) haplotype-splice path for vcf2multialign.
+ *
+ * Drop-in boundary for ONE hot path of tsnorri/vcf2multialign: the per-row
+ * reference+ALT splice (output_sequence) batched over the rows of one A2M file, and the
+ * bit-packed path-matrix transpose.  The C++ host keeps parsing the VCF, building the
+ * variant_graph and writing the A2M file; everything between "graph built" and "row
+ * bytes ready" happens on the GPU behind these entry points.
+ *
+ * Reference interfaces replaced (paths relative to the reference tree):
+ *   v2m_transpose_bits[_device]   transpose_matrix()            include/vcf2multialign/transpose_matrix.hh:14
+ *                                                                libvcf2multialign/transpose_matrix.cc:41-109
+ *                                                                (call site libvcf2multialign/variant_graph.cc:453)
+ *   v2m_upload_graph              the read-only view of          include/vcf2multialign/variant_graph.hh:57-66
+ *                                 variant_graph + ref_seq that
+ *                                 output_sequence() walks
+ *   v2m_splice_rows[_device]      output_sequence() called once  include/vcf2multialign/sequence_writer.hh:49-56
+ *                                 per row by                     libvcf2multialign/sequence_writer.cc:22-85
+ *                                 haplotype_output::output_a2m   libvcf2multialign/haplotype_output.cc:38-82
+ *                                 and founder_sequence_greedy_   libvcf2multialign/founder_sequence_greedy_output.cc:515-550
+ *                                 output::output_a2m
+ *   v2m_row_batch                 sequence_writing_delegate      include/vcf2multialign/sequence_writer.hh:16-36
+ *                                 (chromosome_copy_index, and    libvcf2multialign/haplotype_output.cc:22-32
+ *                                 the founder delegate's copy    libvcf2multialign/founder_sequence_greedy_output.cc:78-115
+ *                                 switch at cut nodes)
+ *
+ * Conventions
+ *   - Plain C: pointers + sizes, no exceptions, no C++/torch types.  Every function that can
+ *     fail returns a V2M_* status; v2m_last_error() gives the message.
+ *   - All graph integers are uint64_t exactly as in the reference (variant_graph.hh:38-40);
+ *     the library narrows to 32 bits on upload and rejects graphs that do not fit
+ *     (V2M_ERR_UNSUPPORTED).
+ *   - Bit matrices: column-major, one column = n_rows/64 consecutive uint64_t words, row r of a
+ *     column in word r/64 at bit r%64 (LSB first).  Dimensions are multiples of 64.
+ *   - One ctx per GPU, driven by one host thread.  The graph is uploaded once and reused.
+ *   - There is NO CPU fallback: without a usable HIP device v2m_ctx_create() fails.
+ */
+#ifndef V2M_HIP_H
+#define V2M_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define V2M_ABI_VERSION 1
+
+enum {
+	V2M_OK = 0,
+	V2M_ERR_INVALID_ARGUMENT = 1, /* null pointer, zero-sized where not allowed, bad flag */
+	V2M_ERR_PRECONDITION = 2,     /* what the reference asserts: dims % 64, graph invariants, cut nodes */
+	V2M_ERR_UNSUPPORTED = 3,      /* valid input outside what this build handles (e.g. > 32-bit positions) */
+	V2M_ERR_NO_DEVICE = 4,        /* no HIP device / wrong architecture */
+	V2M_ERR_HIP = 5,              /* a HIP runtime call failed */
+	V2M_ERR_OUT_OF_MEMORY = 6,
+	V2M_ERR_SINK = 7,             /* the sink callback returned non-zero */
+	V2M_ERR_STATE = 8             /* call order: no graph uploaded, no path matrix set, ... */
+};
+
+/* sequence_writing_delegate::PLOIDY_MAX (sequence_writer.hh:23-25): "follow REF edges only". */
+#define V2M_PLOIDY_MAX UINT32_MAX
+
+/* flags of v2m_splice_rows* */
+#define V2M_SPLICE_UNALIGNED 0x1u /* should_output_unaligned (sequence_writer.cc:80): no '-' padding */
+
+typedef struct v2m_ctx v2m_ctx;
+
+/* ---- context ---------------------------------------------------------------------------- */
+
+/* Binds to HIP device `device_id`, creates the library's stream.  Fails with V2M_ERR_NO_DEVICE
+ * when there is no usable gfx950 device. */
+int v2m_ctx_create(int device_id, v2m_ctx **ctx_out);
+void v2m_ctx_destroy(v2m_ctx *ctx);
+
+/* Message of the last failure on this ctx (or, with ctx == NULL, of the last failed
+ * v2m_ctx_create on this thread).  Never NULL. */
+const char *v2m_last_error(const v2m_ctx *ctx);
+
+/* Blocks until everything queued on the ctx's stream has finished. */
+int v2m_ctx_synchronize(v2m_ctx *ctx);
+
+/* The hipStream_t all kernels of this ctx are launched on (for event timing by the caller). */
+void *v2m_ctx_stream(v2m_ctx *ctx);
+
+uint32_t v2m_abi_version(void);
+
+/* ---- transpose_matrix ------------------------------------------------------------------- */
+
+/* dst(c, r) = src(r, c).  src has n_rows x n_cols bits, dst n_cols x n_rows; both column-major
+ * uint64 words as above; dst holds n_rows*n_cols/64 words and is fully overwritten.
+ * n_cols == 0 is a no-op returning V2M_OK (transpose_matrix.cc:48-49); dimensions that are
+ * not multiples of 64 return V2M_ERR_PRECONDITION (asserted at transpose_matrix.cc:53-54).
+ * Host-pointer form: copies in, transposes on the GPU, copies out, synchronous. */
+int v2m_transpose_bits(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_rows, uint64_t n_cols, uint64_t *dst_words);
+
+/* Device-pointer form: both buffers already in HBM (8-byte aligned, non-overlapping);
+ * asynchronous on the ctx's stream. */
+int v2m_transpose_bits_device(v2m_ctx *ctx, const void *d_src_words, uint64_t n_rows, uint64_t n_cols, void *d_dst_words);
+
+/* ---- variant_graph view ----------------------------------------------------------------- */
+
+/* Raw view of the variant_graph fields output_sequence() reads (variant_graph.hh:57-63),
+ * with alt_edge_labels flattened to CSR.  All pointers are host pointers owned by the caller
+ * and only read during v2m_upload_graph(). */
+typedef struct v2m_graph_view {
+	uint64_t node_count;                 /* reference_positions.size() (>= 1; last node = sink) */
+	uint64_t edge_count;                 /* alt_edge_targets.size() */
+	const uint64_t *reference_positions; /* [node_count]  strictly increasing                   */
+	const uint64_t *aligned_positions;   /* [node_count]  MSA co-ordinates                      */
+	const uint64_t *alt_edge_targets;    /* [edge_count]  node ids                              */
+	const uint64_t *alt_edge_count_csum; /* [node_count + 1]; edges of node n = [csum[n], csum[n+1]) */
+	const uint64_t *alt_edge_label_offsets; /* [edge_count + 1] offsets into alt_edge_label_bytes */
+	const char *alt_edge_label_bytes;
+	/* paths_by_chrom_copy_and_edge: rows = edges (padded to path_rows), cols = chromosome copies
+	 * (padded to path_cols).  May be NULL when the matrix is supplied later with
+	 * v2m_set_paths_device(). */
+	const uint64_t *paths_by_chrom_copy_and_edge;
+	uint64_t path_rows; /* >= edge_count, multiple of 64 (0 allowed when edge_count == 0) */
+	uint64_t path_cols; /* multiple of 64 */
+} v2m_graph_view;
+
+/* Validates the invariants output_sequence() relies on (V2M_ERR_PRECONDITION otherwise),
+ * narrows to 32 bits, uploads graph + reference, and precomputes the device-side tables
+ * (edge source nodes, per-edge aligned spans, the gap-aligned REF row, per-tile edge ranges).
+ * Replaces any previously uploaded graph.  Synchronous. */
+int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *graph, const char *ref_seq, uint64_t ref_len);
+
+/* Uses a path matrix that already lives in HBM (e.g. the output of v2m_transpose_bits_device)
+ * as paths_by_chrom_copy_and_edge of the uploaded graph.  The buffer is BORROWED: it must stay
+ * valid and unchanged until the next upload/set or ctx destruction. */
+int v2m_set_paths_device(v2m_ctx *ctx, const void *d_words, uint64_t path_rows, uint64_t path_cols);
+
+/* aligned_positions.back(): the length of every aligned row. 0 before an upload. */
+uint64_t v2m_aligned_length(const v2m_ctx *ctx);
+/* Smallest row pitch v2m_splice_rows_device accepts in aligned mode (aligned length rounded up to 256). */
+uint64_t v2m_min_row_pitch(const v2m_ctx *ctx);
+
+/* ---- rows -------------------------------------------------------------------------------- */
+
+/* A batch of output rows, i.e. one sequence_writing_delegate per row:
+ *   - row i with no cuts follows chromosome copy copy_index[i] for the whole walk
+ *     (haplotype_output.cc:22-32); V2M_PLOIDY_MAX = the REF row (haplotype_output.cc:55).
+ *   - row i with cuts [cut_offsets[i], cut_offsets[i+1]) starts as V2M_PLOIDY_MAX and switches to
+ *     cut_copies[k] when the walk visits node cut_nodes[k] (founder_sequence_greedy_output.cc:106-114).
+ *     Cut nodes must be strictly increasing and must not lie strictly inside any ALT edge's
+ *     (source, target) node span -- the reference asserts this at :108; violating batches are
+ *     rejected with V2M_ERR_PRECONDITION.  cut_copies may be V2M_PLOIDY_MAX.
+ * cut_offsets == NULL means no row has cuts.  Copy indices must be < path_cols. */
+typedef struct v2m_row_batch {
+	uint64_t n_rows;
+	const uint32_t *copy_index;  /* [n_rows] */
+	const uint64_t *cut_offsets; /* [n_rows + 1] or NULL */
+	const uint64_t *cut_nodes;   /* [cut_offsets[n_rows]] */
+	const uint32_t *cut_copies;  /* [cut_offsets[n_rows]] */
+} v2m_row_batch;
+
+/* Receives one finished row body: exactly the bytes output_sequence() would have streamed
+ * after the optional '>'id'\n' header and before the caller's '\n' (haplotype_output.cc:57,76).
+ * `bytes` is library-owned pinned memory, valid only during the call.  Rows arrive in batch
+ * order, one call per row, on the calling thread.  Return non-zero to abort (V2M_ERR_SINK). */
+typedef int (*v2m_sink_fn)(void *user, uint64_t row_index, const char *bytes, uint64_t length);
+
+/* Splices every row of the batch on the GPU and hands the bodies to `sink` in order.
+ * Works through the batch in device-sized slices, overlapping the D2H copy of one slice with
+ * the kernels of the next.  Synchronous. */
+int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m_sink_fn sink, void *user);
+
+/* Device-resident form: row i is written to d_out + i * row_pitch and stays in HBM.
+ * Aligned mode: every row has v2m_aligned_length() bytes; row_pitch >= v2m_min_row_pitch()
+ * and a multiple of 16; d_out 16-byte aligned; the bytes between the row's end and the next
+ * multiple of 16 are clobbered.  Unaligned mode: row_pitch must be >= the longest row
+ * (reference length + total label bytes is always enough; see v2m_max_unaligned_length()).
+ * row_lengths_out (host, optional, [n_rows]) receives each row's length.
+ * Asynchronous on the ctx's stream unless row_lengths_out is non-NULL in unaligned mode. */
+int v2m_splice_rows_device(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, void *d_out, uint64_t row_pitch, uint64_t *row_lengths_out);
+
+/* Upper bound of any unaligned row's length for the uploaded graph. */
+uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx);
+
+/* ---- verification helper ------------------------------------------------------------------ */
+
+/* 64-bit position-sensitive checksum of each of n_rows device rows (row i = d_rows + i*row_pitch,
+ * lengths[i] bytes, or `length` for all rows when lengths == NULL):
+ *   sum over byte positions p of  mix64((p + 1) * 0x9E3779B97F4A7C15 ^ byte[p])  (mod 2^64),
+ *   mix64 = the splitmix64 finaliser.
+ * Used to check full-size outputs against the CPU without moving them.  Synchronous. */
+int v2m_checksum_rows_device(v2m_ctx *ctx, const void *d_rows, uint64_t row_pitch, uint64_t n_rows, uint64_t length, const uint64_t *lengths, uint64_t *checksums_out);
+
+/* ---- kernel timing ------------------------------------------------------------------------ */
+
+enum {
+	V2M_KERNEL_TRANSPOSE = 0,       /* transpose_bits_kernel */
+	V2M_KERNEL_RESOLVE = 1,         /* resolve_effective_edges_kernel (per-row skip-rule scan) */
+	V2M_KERNEL_SPLICE_ALIGNED = 2,  /* splice_aligned_kernel (dominant) */
+	V2M_KERNEL_SPLICE_UNALIGNED = 3,
+	V2M_KERNEL_TEMPLATE = 4,        /* expand_reference_row_kernel (once per upload) */
+	V2M_KERNEL_COUNT = 5
+};
+
+/* When enabled, every launch of the kernels above is bracketed by HIP events on the ctx's
+ * stream.  v2m_profile_get() synchronises and returns launch count and summed device time. */
+int v2m_profile_enable(v2m_ctx *ctx, int enabled);
+int v2m_profile_reset(v2m_ctx *ctx);
+int v2m_profile_get(v2m_ctx *ctx, int kernel, uint64_t *launches_out, double *total_ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* V2M_HIP_H */

@@ -1,0 +1,247 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle and the goldens.
+Bit-exact everywhere (byte / bit / index work)."""
+
+import io
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _goldens(name):
+	with open(os.path.join(HERE, "golden", "reference_goldens.json")) as f:
+		return json.load(f)[name]
+
+
+def _case_id(c):
+	return c["vcf"] + "+" + c["fasta"]
+
+
+@pytest.fixture(scope="module")
+def v2m():
+	import vcf2multialign_amd as v
+	return v
+
+
+@pytest.fixture(scope="module")
+def ctx(v2m):
+	c = v2m.Context(0)
+	yield c
+	c.close()
+
+
+def _upload(v2m, ctx, g):
+	vg = v2m.VariantGraph.from_object(g)
+	ctx.upload_graph(vg, g.ref)
+	return vg
+
+
+def _oracle_rows(g, rows, unaligned=False):
+	out = []
+	for r in rows:
+		if isinstance(r, (int, np.integer)):
+			out.append(g.output_sequence(g.ref, copy_index=int(r), unaligned=unaligned))
+		else:
+			out.append(g.output_sequence(g.ref, cuts=list(r), unaligned=unaligned))
+	return out
+
+
+# ---- transpose_matrix ----------------------------------------------------------------------
+
+def _set_bit(words, nrows, r, c):
+	idx = c * nrows + r
+	words[idx >> 6] |= np.uint64(1) << np.uint64(idx & 63)
+
+
+@pytest.mark.parametrize("case", _goldens("transpose_matrix"), ids=lambda c: "%dx%d" % (c["rows"], c["cols"]))
+def test_transpose_fixed(ctx, case):   # tests/transpose_matrix.cc:188-251
+	src = np.zeros(case["rows"] * case["cols"] // 64, dtype=np.uint64)
+	exp = np.zeros_like(src)
+	_set_bit(src, case["rows"], *case["set_bit"])
+	_set_bit(exp, case["expected_rows"], *case["expected_bit"])
+	assert np.array_equal(ctx.transpose_matrix(src, case["rows"], case["cols"]), exp)
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 2), (2, 1), (3, 5), (8, 8), (9, 7), (16, 17), (79, 33), (5, 130), (64, 64)])
+def test_transpose_random(ctx, h, w):  # tests/transpose_matrix.cc:254-279 (1/3 of the bits set), plus ragged panels
+	rng = np.random.default_rng(1000 * h + w)
+	rows, cols = 64 * h, 64 * w
+	src = rng.integers(0, 2 ** 63, size=rows * cols // 64, dtype=np.uint64) & rng.integers(0, 2 ** 63, size=rows * cols // 64, dtype=np.uint64)
+	src |= rng.integers(0, 2, size=src.size, dtype=np.uint64) << np.uint64(63)
+	got = ctx.transpose_matrix(src, rows, cols)
+	assert np.array_equal(got, oracle.transpose_matrix(src, rows, cols, naive=True))
+	assert np.array_equal(ctx.transpose_matrix(got, cols, rows), src)   # involution
+
+
+def test_transpose_edge_cases(ctx, v2m):
+	assert ctx.transpose_matrix(np.zeros(0, np.uint64), 64, 0).size == 0           # transpose_matrix.cc:48-49
+	with pytest.raises(v2m.V2MError) as e:
+		ctx.transpose_matrix(np.zeros(2, np.uint64), 64, 2)                         # asserted at transpose_matrix.cc:53-54
+	assert e.value.code == 2
+
+
+# ---- reference goldens through the GPU -----------------------------------------------------
+
+@pytest.mark.parametrize("case", _goldens("founder_sequences"), ids=_case_id)
+def test_founder_a2m_goldens(v2m, ctx, case):   # tests/founder_sequences.cc:118-188
+	d = os.path.join(HERE, "golden", "reference-fixtures", "founder-sequences")
+	g = oracle.build_variant_graph(os.path.join(d, case["fasta"]), os.path.join(d, case["vcf"]), case["chromosome"])
+	vg = _upload(v2m, ctx, g)
+	out = io.BytesIO()
+	v2m.FounderSequenceGreedyOutput(ctx).output_a2m(vg, case["cut_positions"], case["assigned_samples_column_major"], out)
+	assert out.getvalue().decode() == case["expected_a2m"]
+
+
+@pytest.mark.parametrize("stem,fasta", [("test-1a", "test-1.fa"), ("test-1b", "test-1.fa"), ("test-2", "test-2.fa"), ("test-3", "test-3.fa"), ("test-4", "test-4.fa")])
+def test_haplotype_a2m_fixtures(v2m, ctx, stem, fasta):   # haplotype_output.cc:38-82 on the variant-graph fixtures
+	d = os.path.join(HERE, "golden", "reference-fixtures", "variant-graph")
+	g = oracle.build_variant_graph(os.path.join(d, fasta), os.path.join(d, stem + ".vcf"), "1")
+	vg = _upload(v2m, ctx, g)
+	out = io.BytesIO()
+	n = v2m.HaplotypeOutput(ctx).output_a2m(vg, out)
+	assert n == 1 + g.total_chromosome_copies
+	with open(os.path.join(HERE, "golden", "derived", stem + ".haplotypes.a2m"), "rb") as f:
+		assert out.getvalue() == f.read()
+	out = io.BytesIO()
+	v2m.HaplotypeOutput(ctx, chromosome_id="chrT", should_output_reference=False).output_a2m(vg, out)
+	with open(os.path.join(HERE, "golden", "derived", stem + ".haplotypes.chr.noref.a2m"), "rb") as f:
+		assert out.getvalue() == f.read()
+
+
+# ---- synthetic graphs ----------------------------------------------------------------------
+
+SYNTH = [
+	# seed, ref_len, variants, samples, kwargs
+	(1, 3000, 60, 4, {}),
+	(2, 50000, 800, 8, {"mix": (1.0, 0.0, 0.0)}),                       # SNV only (config 2 shape)
+	(3, 200000, 3000, 12, {}),                                          # config 3 mix, several tiles
+	(4, 120000, 1500, 6, {"long_every": 40}),                           # long deletions / insertions crossing tiles
+	(5, 40000, 4000, 5, {"multi_allelic": 0.3, "density": 0.3}),        # dense, multi-allelic, many overlaps
+	(6, 70000, 900, 3, {"ploidy": 1}),
+]
+
+
+@pytest.mark.parametrize("seed,ref_len,n_var,n_samples,kw", SYNTH, ids=lambda x: str(x) if isinstance(x, int) else None)
+def test_synthetic_haplotypes(v2m, ctx, tmp_path, seed, ref_len, n_var, n_samples, kw):
+	g = synth.build_case(tmp_path, seed, ref_len, n_var, n_samples, **kw)
+	_upload(v2m, ctx, g)
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies))
+	got = ctx.splice_rows(rows)
+	exp = _oracle_rows(g, rows)
+	assert len(got) == len(exp)
+	for i, (a, b) in enumerate(zip(got, exp)):
+		assert len(a) == g.aligned_length
+		assert a == b, "row %d differs" % i
+
+
+@pytest.mark.parametrize("density", [0.02, 0.3, 0.9])
+def test_random_path_bits_skip_rule(v2m, ctx, tmp_path, density):
+	"""iid random path bits: most set edges overlap an earlier one, so nearly every chunk of the
+	resolve scan takes the serial path (sequence_writer.cc:51-67 skip semantics)."""
+	g0 = synth.build_case(tmp_path, 11, 60000, 5000, 4, multi_allelic=0.2, long_every=97)
+	g = synth.with_random_paths(g0, 5, density)
+	_upload(v2m, ctx, g)
+	rows = list(range(min(8, g.path_cols)))
+	got = ctx.splice_rows(rows)
+	for i, (a, b) in enumerate(zip(got, _oracle_rows(g, rows))):
+		assert a == b, "row %d differs" % i
+
+
+def test_founder_rows_synthetic(v2m, ctx, tmp_path):
+	"""Copy switching at cut nodes that no edge spans (founder_sequence_greedy_output.cc:106-114)."""
+	g = synth.build_case(tmp_path, 21, 80000, 1200, 10)
+	_upload(v2m, ctx, g)
+	# bridge nodes: nodes that no edge jumps over
+	reach = 0
+	bridges = []
+	for n in range(g.node_count - 1):
+		if n >= reach and n > 0:
+			bridges.append(n)
+		for e in range(int(g.alt_edge_count_csum[n]), int(g.alt_edge_count_csum[n + 1])):
+			reach = max(reach, int(g.alt_edge_targets[e]))
+	rng = np.random.default_rng(3)
+	H = g.total_chromosome_copies
+	rows = []
+	for _ in range(6):
+		cuts = [0] + sorted(int(x) for x in rng.choice(bridges, size=min(25, len(bridges)), replace=False))
+		copies = [int(x) for x in rng.integers(0, H, size=len(cuts))]
+		copies[2] = v2m.PLOIDY_MAX                                  # unassigned slot (founder_sequence_greedy_output.cc:172)
+		rows.append(list(zip(cuts, copies)))
+	rows.append([(bridges[3], 1)])                                  # first cut not at node 0: REF until then
+	got = ctx.splice_rows(rows)
+	for i, (a, b) in enumerate(zip(got, _oracle_rows(g, rows))):
+		assert a == b, "row %d differs" % i
+
+
+def test_device_rows_checksums(v2m, ctx, tmp_path):
+	"""Device-resident output + on-device checksums == host checksums of the oracle rows; and the
+	sink path cut into several ring slices gives the same bytes."""
+	import torch
+	g = synth.build_case(tmp_path, 31, 150000, 2500, 16)
+	_upload(v2m, ctx, g)
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies))
+	exp = _oracle_rows(g, rows)
+	pitch = ctx.min_row_pitch
+	assert pitch % 256 == 0 and pitch >= g.aligned_length
+	buf = torch.zeros(len(rows) * pitch, dtype=torch.uint8, device="cuda")
+	torch.cuda.synchronize()
+	ctx.splice_rows_device(rows, buf.data_ptr(), pitch)
+	sums = ctx.checksum_rows_device(buf.data_ptr(), pitch, len(rows), length=g.aligned_length)
+	ctx.synchronize()
+	assert np.array_equal(sums, v2m.checksum_rows_host(exp))
+	host = buf.cpu().numpy().reshape(len(rows), pitch)
+	for i, b in enumerate(exp):
+		assert host[i, :len(b)].tobytes() == b
+
+
+def test_sink_slices(v2m, ctx, tmp_path, monkeypatch):
+	g = synth.build_case(tmp_path, 32, 90000, 1500, 8)
+	monkeypatch.setenv("V2M_RING_SLOT_BYTES", "300000")   # ~3 rows per slice: several slices, both ring halves reused
+	_upload(v2m, ctx, g)
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies))
+	got = ctx.splice_rows(rows)
+	for i, (a, b) in enumerate(zip(got, _oracle_rows(g, rows))):
+		assert a == b, "row %d differs" % i
+
+
+# ---- edge cases and error behaviour --------------------------------------------------------
+
+def test_no_variants_and_empty_batches(v2m, ctx, tmp_path):
+	ref = b"ACGTACGTAC"
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, [], 2)
+	g = oracle.build_variant_graph(fa, vcf, "1")
+	assert g.edge_count == 0 and g.node_count == 2
+	_upload(v2m, ctx, g)
+	assert ctx.splice_rows([v2m.PLOIDY_MAX]) == [ref]
+	assert ctx.splice_rows([]) == []
+
+
+def test_precondition_errors(v2m, ctx, tmp_path):
+	g = synth.build_case(tmp_path, 41, 5000, 100, 3)
+	vg = _upload(v2m, ctx, g)
+	with pytest.raises(v2m.V2MError) as e:                       # copy outside the matrix
+		ctx.splice_rows([g.path_cols])
+	assert e.value.code == 1
+	# a cut node inside an edge span is what the reference asserts against (founder_sequence_greedy_output.cc:108)
+	e0 = next(e for e in range(g.edge_count) if int(g.alt_edge_targets[e]) - int(np.searchsorted(g.alt_edge_count_csum, e, side="right") - 1) >= 2)
+	src = int(np.searchsorted(g.alt_edge_count_csum, e0, side="right") - 1)
+	with pytest.raises(v2m.V2MError) as e:
+		ctx.splice_rows([[(0, 0), (src + 1, 1)]])
+	assert e.value.code == 2
+	# graph invariants: label longer than its aligned span (libbio_assert_lte at sequence_writer.cc:61)
+	bad = v2m.VariantGraph.from_object(g)
+	bad.aligned_positions = bad.aligned_positions.copy()
+	bad.aligned_positions[1:] -= np.uint64(1)
+	with pytest.raises(v2m.V2MError) as e:
+		ctx.upload_graph(bad, g.ref)
+	assert e.value.code == 2
+	ctx.upload_graph(vg, g.ref)   # the context stays usable
+	assert ctx.splice_rows([0]) == _oracle_rows(g, [0])

@@ -1,0 +1,495 @@
+// kernels.hpp -- hand-written gfx950 (CDNA4, wave64) kernels of the vcf2multialign splice path.
+//
+// Integer copy/index work, HBM-bound: no MFMA anywhere.  The rules that matter here are
+// coalesced 16-B/lane global accesses, LDS staging of byte-granular patches, keeping the
+// shared inputs (REF row, edge tables) L2/Infinity-Cache resident across the rows that
+// reuse them, and launching far more workgroups than the 256 CUs.
+//
+// Reference semantics (paths relative to the reference tree):
+//   transpose_bits_kernel           libvcf2multialign/transpose_matrix.cc:41-109
+//   expand_reference_row_kernel     libvcf2multialign/sequence_writer.cc:22-85 with copy = PLOIDY_MAX
+//   resolve_effective_edges_kernel  the order-dependent part of sequence_writer.cc:51-67
+//   splice_aligned_kernel           the byte-producing part of sequence_writer.cc:57-83
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace v2m {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int kWave = 64;
+typedef u32 vec4u __attribute__((ext_vector_type(4)));   // native 16-B vector (nontemporal builtins need it)
+
+// ---------------------------------------------------------------------------------------------
+// Geometry of the aligned splice.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTileBytes = 16384;                    // aligned positions per tile
+constexpr int kSpliceThreads = 256;
+constexpr int kTileChunks = kTileBytes / 16;          // 16-B chunks per tile (1024)
+constexpr int kChunksPerThread = kTileChunks / kSpliceThreads;   // 4
+constexpr int kLongPatch = 96;                        // patches longer than this are filled by a whole wave
+constexpr int kLongQueue = 64;
+
+// Per-edge patch descriptor: where the edge's label + padding lands in aligned co-ordinates.
+struct __attribute__((aligned(16))) edge_patch {
+	u32 aln_begin;    // aligned_positions[source node]
+	u32 aln_end;      // aligned_positions[target node]
+	u32 label_begin;  // offset into the label byte pool
+	u32 label_len;
+};
+
+// Source and target node of an edge, packed for one 8-B load in the resolve scan.
+struct __attribute__((aligned(8))) edge_span {
+	u32 src;
+	u32 tgt;
+};
+
+
+// ---------------------------------------------------------------------------------------------
+// Bit-matrix transpose.  src: n_rows x n_cols bits, column-major, SW = n_rows/64 words per column.
+// dst: n_cols x n_rows bits, DW = n_cols/64 words per column.
+//
+// One workgroup moves a 512 x 512-bit panel (8 row-words x 8 column groups = 32 KiB) through
+// LDS: every source column contributes 64 contiguous bytes and every destination column
+// receives 64 contiguous bytes, so both HBM sides move whole 64-B segments instead of the
+// 8-B strided words a tile-per-wave scheme would touch.  Each wave transposes 64 x 64-bit
+// tiles in registers with the six-stage butterfly (lane = source column, bit = source row).
+// ---------------------------------------------------------------------------------------------
+constexpr int kTrPanel = 8;         // row-words and column groups per workgroup panel
+constexpr int kTrThreads = 256;
+
+__device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask)
+{
+	u32 lo = __shfl_xor((u32) v, mask, kWave);
+	u32 hi = __shfl_xor((u32) (v >> 32), mask, kWave);
+	return ((u64) hi << 32) | lo;
+}
+
+// 64 x 64 bit transpose across the wave: on return lane j bit i == (on entry) lane i bit j.
+__device__ __forceinline__ u64 wave_transpose_64x64(u64 x, int lane)
+{
+#define V2M_TR_STAGE(D, LOWMASK)                                                   \
+	{                                                                              \
+		u64 const y = shfl_xor_u64(x, D);                                          \
+		u64 const low = LOWMASK;                                                   \
+		x = (lane & D) ? ((x & ~low) | ((y & ~low) >> D)) : ((x & low) | ((y & low) << D)); \
+	}
+	V2M_TR_STAGE(32, 0x00000000FFFFFFFFULL)
+	V2M_TR_STAGE(16, 0x0000FFFF0000FFFFULL)
+	V2M_TR_STAGE(8, 0x00FF00FF00FF00FFULL)
+	V2M_TR_STAGE(4, 0x0F0F0F0F0F0F0F0FULL)
+	V2M_TR_STAGE(2, 0x3333333333333333ULL)
+	V2M_TR_STAGE(1, 0x5555555555555555ULL)
+#undef V2M_TR_STAGE
+	return x;
+}
+
+__global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW)
+{
+	// [source column within panel][row-word], padded to 9 words: the per-lane stride of the
+	// transposing read is 72 B, conflict-free for ds_read_b64 ((18*lane) mod 64 distinct over 32 lanes).
+	__shared__ u64 panel[64 * kTrPanel][kTrPanel + 1];
+
+	int const t = threadIdx.x;
+	int const lane = t & 63;
+	int const wave = t >> 6;
+	u64 const rw0 = (u64) blockIdx.x * kTrPanel;    // first source row-word
+	u64 const cg0 = (u64) blockIdx.y * kTrPanel;    // first source column group
+	u64 const n_cols = DW * 64;
+
+	// load: 8 consecutive lanes fetch one column's 64 contiguous bytes
+	for (int k = 0; k < (64 * kTrPanel * kTrPanel) / kTrThreads; ++k) {
+		int const idx = t + kTrThreads * k;
+		int const col = idx >> 3, w = idx & 7;
+		u64 const gcol = cg0 * 64 + col;
+		u64 v = 0;
+		if (gcol < n_cols && rw0 + w < SW)
+			v = src[gcol * SW + rw0 + w];
+		panel[col][w] = v;
+	}
+	__syncthreads();
+
+	// each wave owns two row-words; pull their 2 x 8 tiles into registers
+	u64 x[2][kTrPanel];
+#pragma unroll
+	for (int a = 0; a < 2; ++a)
+#pragma unroll
+		for (int cg = 0; cg < kTrPanel; ++cg)
+			x[a][cg] = panel[64 * cg + lane][2 * wave + a];
+	__syncthreads();
+
+#pragma unroll
+	for (int a = 0; a < 2; ++a)
+#pragma unroll
+		for (int cg = 0; cg < kTrPanel; ++cg)
+			panel[64 * (2 * wave + a) + lane][cg] = wave_transpose_64x64(x[a][cg], lane);   // now [dst column within panel][column group]
+	__syncthreads();
+
+	// store: 8 consecutive lanes write one destination column's 64 contiguous bytes
+	for (int k = 0; k < (64 * kTrPanel * kTrPanel) / kTrThreads; ++k) {
+		int const idx = t + kTrThreads * k;
+		int const dcol = idx >> 3, cw = idx & 7;
+		u64 const grow = rw0 * 64 + dcol;          // destination column = source row
+		if (grow < SW * 64 && cg0 + cw < DW)
+			dst[grow * DW + cg0 + cw] = panel[dcol][cw];
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// The gap-aligned REF row ("template"): what output_sequence() emits for
+// chromosome_copy_index == PLOIDY_MAX (sequence_writer.cc:49,70-81): for every node its reference
+// segment followed by '-' up to the next node's aligned position.  Built once per uploaded
+// graph; every aligned output row equals it outside the spans of its effective ALT edges.
+// One thread per 16 output bytes; bytes past L are zero.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_reference_row_kernel(
+	char const *__restrict__ ref, u32 const *__restrict__ ref_pos, u32 const *__restrict__ aln_pos,
+	u32 n_nodes, u32 L, u64 n_chunks, uint4 *__restrict__ out, char gap)
+{
+	u64 const c = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+	if (c >= n_chunks) return;
+	u64 const p0 = c * 16;
+	unsigned char bytes[16];
+	if (p0 >= L) {
+		out[c] = make_uint4(0, 0, 0, 0);
+		return;
+	}
+	// node containing p0: last n with aln_pos[n] <= p0
+	u32 lo = 0, hi = n_nodes;   // invariant: aln_pos[lo] <= p0 < aln_pos[hi] (hi == n_nodes means +inf)
+	while (hi - lo > 1) {
+		u32 const mid = lo + (hi - lo) / 2;
+		if (aln_pos[mid] <= p0) lo = mid; else hi = mid;
+	}
+	u32 n = lo;
+	u32 a0 = aln_pos[n], r0 = ref_pos[n];
+	u32 a1 = (n + 1 < n_nodes) ? aln_pos[n + 1] : 0xFFFFFFFFu;
+	u32 r1 = (n + 1 < n_nodes) ? ref_pos[n + 1] : r0;
+#pragma unroll
+	for (int b = 0; b < 16; ++b) {
+		u64 const p = p0 + b;
+		unsigned char v = 0;
+		if (p < L) {
+			while (p >= a1) {
+				++n;
+				a0 = a1; r0 = r1;
+				a1 = (n + 1 < n_nodes) ? aln_pos[n + 1] : 0xFFFFFFFFu;
+				r1 = (n + 1 < n_nodes) ? ref_pos[n + 1] : r0;
+			}
+			u32 const off = (u32) p - a0;
+			v = (off < r1 - r0) ? (unsigned char) ref[r0 + off] : (unsigned char) gap;
+		}
+		bytes[b] = v;
+	}
+	uint4 o;
+	o.x = bytes[0] | (bytes[1] << 8) | (bytes[2] << 16) | ((u32) bytes[3] << 24);
+	o.y = bytes[4] | (bytes[5] << 8) | (bytes[6] << 16) | ((u32) bytes[7] << 24);
+	o.z = bytes[8] | (bytes[9] << 8) | (bytes[10] << 16) | ((u32) bytes[11] << 24);
+	o.w = bytes[12] | (bytes[13] << 8) | (bytes[14] << 16) | ((u32) bytes[15] << 24);
+	out[c] = o;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Effective-edge resolution: the order-dependent part of the walk.
+//
+// output_sequence() only honours a set path bit if the walk actually visits the edge's
+// source node: following an ALT edge jumps to its target and silently skips the set bits of
+// every node in between, and among several set edges of one node the lowest index wins
+// (sequence_writer.cc:51-67).  Scanning the row's set bits in edge order with the current
+// node `cur` (initially 0): edge e is effective iff src[e] >= cur, and then cur = tgt[e]
+// (hard part 2).
+//
+// One wave per output row.  The wave streams the row's path-bit column 64 words (4096 edges)
+// at a time.  Fast path: with P = running maximum of cur and the targets of all earlier set
+// edges, src[e] >= P for every set edge proves that every set edge is effective (targets then
+// increase monotonically, so P is exactly cur).  Only chunks that fail the test fall back to a
+// lane-serial replay.  Founder rows assemble their bit column from several chromosome copies,
+// one per cut segment (founder_sequence_greedy_output.cc:106-114).
+// ---------------------------------------------------------------------------------------------
+struct row_segments {
+	// segment k of a row covers edges [edge_begin[k], edge_begin[k+1]) and reads copy[k];
+	// the last segment extends to the end.  Rows without cuts have exactly one segment.
+	u32 const *seg_offsets;     // [n_rows + 1]
+	u32 const *seg_edge_begin;  // [total segments]
+	u32 const *seg_copy;        // [total segments]  (0xFFFFFFFF = follow REF)
+};
+
+__device__ __forceinline__ u64 load_row_word(
+	u64 const *__restrict__ paths, u64 words_per_copy, row_segments const &rs, u32 s_begin, u32 s_end, u32 wi)
+{
+	u32 const e0 = wi * 64u;
+	if (s_end - s_begin == 1) {
+		u32 const copy = rs.seg_copy[s_begin];
+		return (copy == 0xFFFFFFFFu) ? 0 : paths[(u64) copy * words_per_copy + wi];
+	}
+	// last segment whose first edge is <= e0
+	u32 lo = s_begin, hi = s_end;
+	while (hi - lo > 1) {
+		u32 const mid = lo + (hi - lo) / 2;
+		if (rs.seg_edge_begin[mid] <= e0) lo = mid; else hi = mid;
+	}
+	u64 w = 0;
+	for (u32 s = lo; s < s_end; ++s) {
+		u32 const b = rs.seg_edge_begin[s];
+		if (b >= e0 + 64) break;
+		u32 const e = (s + 1 < s_end) ? rs.seg_edge_begin[s + 1] : 0xFFFFFFFFu;
+		if (e <= e0) continue;
+		u32 const copy = rs.seg_copy[s];
+		if (copy == 0xFFFFFFFFu) continue;
+		u32 const from = (b > e0) ? b - e0 : 0;             // first bit of this word in the segment
+		u32 const to = (e < e0 + 64) ? e - e0 : 64;         // one past the last
+		u64 mask = (to >= 64 ? ~0ULL : ((1ULL << to) - 1)) & ~((1ULL << from) - 1);
+		w |= paths[(u64) copy * words_per_copy + wi] & mask;
+	}
+	return w;
+}
+
+__global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
+	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
+	row_segments rs, edge_span const *__restrict__ spans,
+	u64 *__restrict__ eff, u64 eff_words_per_row, u32 n_rows)
+{
+	int const lane = threadIdx.x & 63;
+	u32 const row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	if (row >= n_rows) return;   // whole wave exits together
+
+	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
+	u32 const n_words = (n_edges + 63) / 64;
+	u64 *const eff_row = eff + (u64) row * eff_words_per_row;
+	u32 cur = 0;   // current node of the walk at the start of this chunk (wave-uniform)
+
+	for (u32 base = 0; base < n_words; base += 64) {
+		u32 const wi = base + lane;
+		u64 w = 0;
+		if (wi < n_words) {
+			w = load_row_word(paths, words_per_copy, rs, s_begin, s_end, wi);
+			if (wi == n_words - 1 && (n_edges & 63))
+				w &= (1ULL << (n_edges & 63)) - 1;       // padding bits are zero by contract; do not trust them
+		}
+
+		// pass 1: maximum target among this lane's set edges
+		u32 lane_max = 0;
+		for (u64 m = w; m; m &= m - 1) {
+			u32 const e = wi * 64u + __builtin_ctzll(m);
+			u32 const tgt = spans[e].tgt;
+			lane_max = tgt > lane_max ? tgt : lane_max;
+		}
+		// exclusive prefix maximum over lanes
+		u32 incl = lane_max;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			u32 const o = __shfl_up(incl, d, kWave);
+			if (lane >= d) incl = o > incl ? o : incl;
+		}
+		u32 excl = __shfl_up(incl, 1, kWave);
+		if (lane == 0) excl = 0;
+		u32 const chunk_max = __shfl(incl, 63, kWave);
+
+		// pass 2: every set edge must start at or after everything that precedes it
+		u32 run = excl > cur ? excl : cur;
+		bool uncertain = false;
+		for (u64 m = w; m; m &= m - 1) {
+			u32 const e = wi * 64u + __builtin_ctzll(m);
+			edge_span const sp = spans[e];
+			uncertain |= sp.src < run;
+			run = sp.tgt > run ? sp.tgt : run;
+		}
+
+		u64 out = w;
+		if (__any(uncertain)) {
+			// replay the chunk serially, lane by lane, carrying the true current node
+			out = 0;
+			u32 c = cur;
+			u64 busy = __ballot(w != 0);
+			while (busy) {
+				int const j = __builtin_ctzll(busy);
+				busy &= busy - 1;
+				if (lane == j) {
+					for (u64 m = w; m; m &= m - 1) {
+						int const b = __builtin_ctzll(m);
+						edge_span const sp = spans[wi * 64u + b];
+						if (sp.src >= c) {
+							out |= 1ULL << b;
+							c = sp.tgt;
+						}
+					}
+				}
+				c = __shfl(c, j, kWave);
+			}
+			cur = c;
+		} else {
+			cur = chunk_max > cur ? chunk_max : cur;
+		}
+		if (wi < eff_words_per_row)
+			eff_row[wi] = out;
+	}
+	// words between n_words and eff_words_per_row (when the scratch row is wider) stay untouched:
+	// the splice kernel never reads bits >= n_edges.
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Aligned splice: out[row] = template, patched over the aligned span of every effective edge
+// with the edge's label followed by '-' (sequence_writer.cc:57-65,80-83).
+//
+// Workgroup = one 16-KiB tile of aligned positions x a group of rows.  The tile of the
+// template is fetched once into registers (4 x 16 B per thread) and reused for every row of
+// the group; per row it is dropped into LDS, the few effective edges that touch the tile
+// overwrite their spans byte-wise, and the tile streams out with 16-B/lane coalesced stores.
+// Two LDS buffers alternate so that one barrier pair per row suffices.
+//
+// Which edges can touch tile t: those whose span begins inside it -- a contiguous index range,
+// because edges are ordered by source node (variant_graph.cc:81,101) -- plus the edges that
+// begin earlier and reach into it (an explicit per-tile list; at most one of them can be
+// effective for any given row).
+// ---------------------------------------------------------------------------------------------
+struct tile_tables {
+	u32 const *edge_begin;     // [n_tiles + 1] first edge with aln_begin >= t * kTileBytes
+	u32 const *cross_offsets;  // [n_tiles + 1] CSR into cross_edges
+	u32 const *cross_edges;    // edges with aln_begin < t*kTileBytes < aln_end, ascending
+};
+
+__device__ __forceinline__ void fill_patch_bytes(
+	unsigned char *tile, u32 tile_base, edge_patch const p, char const *__restrict__ labels,
+	u32 from, u32 to, u32 start, u32 step, char gap)
+{
+	for (u32 pos = from + start; pos < to; pos += step) {
+		u32 const off = pos - p.aln_begin;
+		tile[pos - tile_base] = (off < p.label_len) ? (unsigned char) labels[p.label_begin + off] : (unsigned char) gap;
+	}
+}
+
+template <bool kNonTemporal>
+__global__ __launch_bounds__(kSpliceThreads) void splice_aligned_kernel(
+	vec4u const *__restrict__ tmpl, u64 const *__restrict__ eff, u64 eff_words_per_row,
+	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
+	char *__restrict__ out, u64 row_pitch, u32 n_rows, u32 rows_per_group, u32 n_groups,
+	u64 store_limit /* aligned length rounded up to 16 */, char gap)
+{
+	__shared__ vec4u lds[2][kTileChunks];
+	__shared__ u32 long_queue[kLongQueue];
+	__shared__ u32 long_count;
+
+	int const t = threadIdx.x;
+	// consecutive workgroups = same tile, next row group: the tile of the template (and the
+	// edge tables behind it) is hot in every XCD's L2 while the groups sweep the rows.
+	u32 const tile = blockIdx.x / n_groups;
+	u32 const group = blockIdx.x % n_groups;
+	u32 const row_begin = group * rows_per_group;
+	u32 const row_end = (row_begin + rows_per_group < n_rows) ? row_begin + rows_per_group : n_rows;
+	u32 const tile_base = tile * (u32) kTileBytes;
+
+	vec4u pristine[kChunksPerThread];
+#pragma unroll
+	for (int k = 0; k < kChunksPerThread; ++k)
+		pristine[k] = tmpl[(u64) tile * kTileChunks + t + kSpliceThreads * k];
+
+	u32 const cross_begin = tt.cross_offsets[tile], n_cross = tt.cross_offsets[tile + 1] - cross_begin;
+	u32 const range_begin = tt.edge_begin[tile], n_range = tt.edge_begin[tile + 1] - range_begin;
+	u32 const n_cand = n_cross + n_range;
+	if (t == 0) long_count = 0;
+
+	for (u32 row = row_begin; row < row_end; ++row) {
+		vec4u *const buf = lds[(row - row_begin) & 1];
+#pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k)
+			buf[t + kSpliceThreads * k] = pristine[k];
+		__syncthreads();
+
+		u64 const *const eff_row = eff + (u64) row * eff_words_per_row;
+		for (u32 i = t; i < n_cand; i += kSpliceThreads) {
+			u32 const e = (i < n_cross) ? tt.cross_edges[cross_begin + i] : range_begin + (i - n_cross);
+			if ((eff_row[e >> 6] >> (e & 63)) & 1) {
+				edge_patch const p = patches[e];
+				u32 const from = p.aln_begin > tile_base ? p.aln_begin : tile_base;
+				u32 const to = p.aln_end < tile_base + kTileBytes ? p.aln_end : tile_base + kTileBytes;
+				if (to - from > kLongPatch) {
+					u32 const slot = atomicAdd(&long_count, 1u);
+					if (slot < kLongQueue) long_queue[slot] = e;
+					else fill_patch_bytes((unsigned char *) buf, tile_base, p, labels, from, to, 0, 1, gap);
+				} else {
+					fill_patch_bytes((unsigned char *) buf, tile_base, p, labels, from, to, 0, 1, gap);
+				}
+			}
+		}
+		__syncthreads();
+
+		u32 const n_long = long_count < kLongQueue ? long_count : kLongQueue;   // block-uniform
+		if (n_long) {
+			// long spans (big deletions, long insertions): one wave per span, 64 bytes per step
+			for (u32 q = t >> 6; q < n_long; q += kSpliceThreads >> 6) {
+				edge_patch const p = patches[long_queue[q]];
+				u32 const from = p.aln_begin > tile_base ? p.aln_begin : tile_base;
+				u32 const to = p.aln_end < tile_base + kTileBytes ? p.aln_end : tile_base + kTileBytes;
+				fill_patch_bytes((unsigned char *) buf, tile_base, p, labels, from, to, t & 63, 64, gap);
+			}
+			__syncthreads();
+			if (t == 0) long_count = 0;   // next read is after the next row's first barrier
+		}
+
+		char *const dst = out + (u64) row * row_pitch + (u64) tile * kTileBytes;
+#pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k) {
+			int const c = t + kSpliceThreads * k;
+			if ((u64) tile_base + (u64) c * 16 < store_limit) {
+				vec4u const nv = buf[c];
+				if (kNonTemporal)
+					__builtin_nontemporal_store(nv, (vec4u *) (dst + c * 16));
+				else
+					*(vec4u *) (dst + c * 16) = nv;
+			}
+		}
+	}
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Row checksums (verification helper): sum over 8-byte little-endian words w (zero padded past
+// the row's length) of mix64((w_index + 1) * GOLDEN ^ word), plus mix64(length).
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ u64 mix64(u64 z)
+{
+	z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+	z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+	z ^= z >> 31;
+	return z;
+}
+
+constexpr u64 kGolden = 0x9E3779B97F4A7C15ULL;
+
+__global__ __launch_bounds__(256) void checksum_rows_kernel(
+	char const *__restrict__ rows, u64 row_pitch, u64 const *__restrict__ lengths, u64 fixed_length,
+	u64 words_per_block, unsigned long long *__restrict__ sums)
+{
+	u32 const row = blockIdx.y;
+	u64 const len = lengths ? lengths[row] : fixed_length;
+	u64 const n_words = (len + 7) / 8;
+	u64 const w_begin = (u64) blockIdx.x * words_per_block;
+	u64 w_end = w_begin + words_per_block;
+	if (w_end > n_words) w_end = n_words;
+	u64 const *const base = (u64 const *) (rows + (u64) row * row_pitch);
+	u64 acc = 0;
+	for (u64 w = w_begin + threadIdx.x; w < w_end; w += blockDim.x) {
+		u64 v = base[w];
+		if (w == n_words - 1 && (len & 7))
+			v &= (1ULL << (8 * (len & 7))) - 1;
+		acc += mix64((w + 1) * kGolden ^ v);
+	}
+	if (blockIdx.x == 0 && threadIdx.x == 0) acc += mix64(len);
+	// wave reduce, then one atomic per wave
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) {
+		u32 lo = __shfl_down((u32) acc, d, kWave);
+		u32 hi = __shfl_down((u32) (acc >> 32), d, kWave);
+		acc += ((u64) hi << 32) | lo;
+	}
+	if ((threadIdx.x & 63) == 0 && acc)
+		atomicAdd(&sums[row], (unsigned long long) acc);
+}
+
+} // namespace v2m

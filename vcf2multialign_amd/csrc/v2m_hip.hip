@@ -1,0 +1,726 @@
+// v2m_hip.hip -- implementation of the C ABI in include/v2m_hip.h for MI355X (gfx950).
+//
+// Host side of the device path: validates and narrows the variant graph, derives the device
+// tables, owns all HBM allocations and the two HIP streams (compute + D2H), and launches the
+// kernels in kernels.hpp.  There is no CPU fallback anywhere in this file: every entry point
+// either runs on the GPU or returns an error.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/v2m_hip.h"
+#include "kernels.hpp"
+
+using v2m::u32;
+using v2m::u64;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct dev_buf {
+	void *p{};
+	size_t bytes{};
+	dev_buf() = default;
+	dev_buf(dev_buf const &) = delete;
+	dev_buf &operator=(dev_buf const &) = delete;
+	~dev_buf() { reset(); }
+	void reset() { if (p) (void) hipFree(p); p = nullptr; bytes = 0; }
+	hipError_t ensure(size_t n)
+	{
+		if (n <= bytes) return hipSuccess;
+		reset();
+		if (0 == n) return hipSuccess;
+		hipError_t const st(hipMalloc(&p, n));
+		if (hipSuccess == st) bytes = n; else p = nullptr;
+		return st;
+	}
+	template <typename T> T *as() const { return static_cast<T *>(p); }
+};
+
+struct pinned_buf {
+	void *p{};
+	size_t bytes{};
+	~pinned_buf() { reset(); }
+	void reset() { if (p) (void) hipHostFree(p); p = nullptr; bytes = 0; }
+	hipError_t ensure(size_t n)
+	{
+		if (n <= bytes) return hipSuccess;
+		reset();
+		if (0 == n) return hipSuccess;
+		hipError_t const st(hipHostMalloc(&p, n, hipHostMallocDefault));
+		if (hipSuccess == st) bytes = n; else p = nullptr;
+		return st;
+	}
+};
+
+struct event_pair { hipEvent_t begin{}, end{}; };
+
+} // namespace
+
+
+struct v2m_ctx {
+	int device{};
+	hipStream_t stream{};
+	hipStream_t copy_stream{};
+	std::string err;
+
+	// profiling
+	bool profiling{};
+	std::vector<event_pair> events[V2M_KERNEL_COUNT];
+	std::vector<event_pair> free_events;
+
+	// graph
+	bool has_graph{};
+	u64 n_nodes{}, n_edges{}, ref_len{}, aligned_len{}, label_bytes{};
+	u32 n_tiles{};
+	std::vector<u32> h_csum;            // alt_edge_count_csum narrowed, [N + 1]
+	std::vector<u32> h_tgt_prefix_max;  // [E + 1]: max target over edges < e (cut validation)
+	dev_buf d_ref, d_ref_pos, d_aln_pos, d_spans, d_patches, d_labels, d_template;
+	dev_buf d_tile_edge_begin, d_cross_offsets, d_cross_edges;
+
+	// paths_by_chrom_copy_and_edge
+	u64 const *d_paths{};
+	dev_buf owned_paths;
+	u64 path_rows{}, path_cols{};
+
+	// per-call scratch
+	dev_buf d_eff, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths;
+	dev_buf ring[2];
+	pinned_buf host_ring[2];
+	hipEvent_t ev_compute[2]{}, ev_copy[2]{};
+};
+
+
+namespace {
+
+int fail(v2m_ctx *ctx, int code, char const *fmt, ...)
+{
+	char buf[512];
+	va_list ap;
+	va_start(ap, fmt);
+	std::vsnprintf(buf, sizeof(buf), fmt, ap);
+	va_end(ap);
+	if (ctx) ctx->err = buf; else g_create_error = buf;
+	return code;
+}
+
+#define V2M_HIP_TRY(ctx, expr)                                                              \
+	do {                                                                                    \
+		hipError_t const st_ = (expr);                                                      \
+		if (hipSuccess != st_) {                                                            \
+			int const code_ = (hipErrorOutOfMemory == st_) ? V2M_ERR_OUT_OF_MEMORY : V2M_ERR_HIP; \
+			return fail(ctx, code_, "%s failed: %s", #expr, hipGetErrorString(st_));       \
+		}                                                                                   \
+	} while (0)
+
+
+// Brackets a launch with events when profiling is on.
+struct timed_launch {
+	v2m_ctx *ctx;
+	int kernel;
+	event_pair ev{};
+	bool active{};
+
+	timed_launch(v2m_ctx *c, int k) : ctx(c), kernel(k)
+	{
+		if (!ctx->profiling) return;
+		if (!ctx->free_events.empty()) { ev = ctx->free_events.back(); ctx->free_events.pop_back(); }
+		else if (hipSuccess != hipEventCreate(&ev.begin) || hipSuccess != hipEventCreate(&ev.end)) return;
+		active = (hipSuccess == hipEventRecord(ev.begin, ctx->stream));
+	}
+	~timed_launch()
+	{
+		if (!active) return;
+		(void) hipEventRecord(ev.end, ctx->stream);
+		ctx->events[kernel].push_back(ev);
+	}
+};
+
+
+template <typename T>
+int upload_vec(v2m_ctx *ctx, dev_buf &dst, std::vector<T> const &src, size_t min_bytes = 16)
+{
+	size_t const bytes(std::max(src.size() * sizeof(T), min_bytes));
+	V2M_HIP_TRY(ctx, dst.ensure(bytes));
+	if (!src.empty())
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(dst.p, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+	return V2M_OK;
+}
+
+
+int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst)
+{
+	u64 const SW(n_rows / 64), DW(n_cols / 64);
+	u64 const gx((SW + v2m::kTrPanel - 1) / v2m::kTrPanel), gy((DW + v2m::kTrPanel - 1) / v2m::kTrPanel);
+	if (gy > 65535 || gx > 0x7FFFFFFFu)
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch (%llu x %llu bits)", (unsigned long long) n_rows, (unsigned long long) n_cols);
+	{
+		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
+		hipLaunchKernelGGL(v2m::transpose_bits_kernel, dim3((unsigned) gx, (unsigned) gy), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW);
+	}
+	V2M_HIP_TRY(ctx, hipGetLastError());
+	return V2M_OK;
+}
+
+
+// Host-side preparation of a row batch: validates it against the uploaded graph and flattens
+// every row into (edge_begin, copy) segments.
+struct prepared_rows {
+	std::vector<u32> seg_offsets, seg_edge_begin, seg_copy;
+};
+
+int prepare_rows(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row_end, prepared_rows &out)
+{
+	out.seg_offsets.assign(1, 0);
+	out.seg_edge_begin.clear();
+	out.seg_copy.clear();
+	for (u64 r(row_begin); r < row_end; ++r) {
+		u64 const c_begin(rows->cut_offsets ? rows->cut_offsets[r] : 0), c_end(rows->cut_offsets ? rows->cut_offsets[r + 1] : 0);
+		if (c_end < c_begin) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut_offsets decrease at row %llu", (unsigned long long) r);
+		if (c_begin == c_end) {
+			if (!rows->copy_index) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row %llu has no cuts and rows->copy_index is NULL", (unsigned long long) r);
+			u32 const copy(rows->copy_index[r]);
+			if (copy != V2M_PLOIDY_MAX && (!ctx->d_paths || copy >= ctx->path_cols))
+				return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row %llu: chromosome copy %u is outside the path matrix (%llu columns)", (unsigned long long) r, copy, (unsigned long long) ctx->path_cols);
+			out.seg_edge_begin.push_back(0);
+			out.seg_copy.push_back(copy);
+		} else {
+			u64 prev(0);
+			for (u64 k(c_begin); k < c_end; ++k) {
+				u64 const node(rows->cut_nodes[k]);
+				u32 const copy(rows->cut_copies[k]);
+				if (node >= ctx->n_nodes) return fail(ctx, V2M_ERR_PRECONDITION, "row %llu: cut node %llu does not exist", (unsigned long long) r, (unsigned long long) node);
+				if (k > c_begin && node <= prev) return fail(ctx, V2M_ERR_PRECONDITION, "row %llu: cut nodes must be strictly increasing", (unsigned long long) r);
+				if (copy != V2M_PLOIDY_MAX && (!ctx->d_paths || copy >= ctx->path_cols))
+					return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row %llu: chromosome copy %u is outside the path matrix", (unsigned long long) r, copy);
+				u32 const first_edge(ctx->h_csum[node]);
+				// founder_sequence_greedy_output.cc:108 asserts the walk never jumps over a cut node
+				if (node > 0 && ctx->h_tgt_prefix_max[first_edge] > node)
+					return fail(ctx, V2M_ERR_PRECONDITION, "row %llu: cut node %llu lies inside the span of an ALT edge", (unsigned long long) r, (unsigned long long) node);
+				if (k == c_begin && node != 0) {   // copy index is PLOIDY_MAX until the first cut is visited
+					out.seg_edge_begin.push_back(0);
+					out.seg_copy.push_back(V2M_PLOIDY_MAX);
+				}
+				out.seg_edge_begin.push_back(first_edge);
+				out.seg_copy.push_back(copy);
+				prev = node;
+			}
+		}
+		out.seg_offsets.push_back(u32(out.seg_copy.size()));
+	}
+	return V2M_OK;
+}
+
+
+bool nontemporal_stores()
+{
+	static int const v = [] {
+		char const *e = std::getenv("V2M_NT_STORES");
+		return (e && *e) ? std::atoi(e) : 0;
+	}();
+	return v != 0;
+}
+
+u32 rows_per_group_for(u64 n_rows)
+{
+	static int const v = [] {
+		char const *e = std::getenv("V2M_ROWS_PER_GROUP");
+		return (e && *e) ? std::atoi(e) : 0;
+	}();
+	if (v > 0) return u32(v);
+	return u32(std::min<u64>(16, std::max<u64>(1, n_rows)));
+}
+
+
+// Resolve + aligned splice of rows [row_begin, row_end) of the batch into d_out.
+int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row_end, char *d_out, u64 row_pitch)
+{
+	u64 const n_rows(row_end - row_begin);
+	if (0 == n_rows || 0 == ctx->aligned_len) return V2M_OK;
+
+	u64 const eff_words((ctx->n_edges + 63) / 64);
+	if (ctx->n_edges) {
+		prepared_rows pr;
+		if (int const rc = prepare_rows(ctx, rows, row_begin, row_end, pr)) return rc;
+		if (int const rc = upload_vec(ctx, ctx->d_seg_offsets, pr.seg_offsets)) return rc;
+		if (int const rc = upload_vec(ctx, ctx->d_seg_edge_begin, pr.seg_edge_begin)) return rc;
+		if (int const rc = upload_vec(ctx, ctx->d_seg_copy, pr.seg_copy)) return rc;
+		// the vectors die at the end of this scope; pageable-memory async copies have been staged by then
+		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		V2M_HIP_TRY(ctx, ctx->d_eff.ensure(n_rows * eff_words * sizeof(u64)));
+
+		v2m::row_segments rs{ctx->d_seg_offsets.as<u32>(), ctx->d_seg_edge_begin.as<u32>(), ctx->d_seg_copy.as<u32>()};
+		{
+			timed_launch tl(ctx, V2M_KERNEL_RESOLVE);
+			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
+				ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(),
+				ctx->d_eff.as<u64>(), eff_words, u32(n_rows));
+		}
+		V2M_HIP_TRY(ctx, hipGetLastError());
+	}
+
+	u32 const rpg(rows_per_group_for(n_rows));
+	u32 const n_groups(u32((n_rows + rpg - 1) / rpg));
+	u64 const n_blocks(u64(ctx->n_tiles) * n_groups);
+	if (n_blocks > 0x7FFFFFFFull)
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "splice grid too large (%llu workgroups); use smaller batches", (unsigned long long) n_blocks);
+	v2m::tile_tables tt{ctx->d_tile_edge_begin.as<u32>(), ctx->d_cross_offsets.as<u32>(), ctx->d_cross_edges.as<u32>()};
+	u64 const store_limit((ctx->aligned_len + 15) & ~u64(15));
+	{
+		timed_launch tl(ctx, V2M_KERNEL_SPLICE_ALIGNED);
+		if (nontemporal_stores())
+			hipLaunchKernelGGL(v2m::splice_aligned_kernel<true>, dim3(unsigned(n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
+				ctx->d_template.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
+				d_out, row_pitch, u32(n_rows), rpg, n_groups, store_limit, '-');
+		else
+			hipLaunchKernelGGL(v2m::splice_aligned_kernel<false>, dim3(unsigned(n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
+				ctx->d_template.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
+				d_out, row_pitch, u32(n_rows), rpg, n_groups, store_limit, '-');
+	}
+	V2M_HIP_TRY(ctx, hipGetLastError());
+	return V2M_OK;
+}
+
+
+int check_batch(v2m_ctx *ctx, v2m_row_batch const *rows, u32 flags)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (!rows) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "rows is NULL");
+	if (flags & ~V2M_SPLICE_UNALIGNED) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "unknown flags 0x%x", flags);
+	if (!ctx->has_graph) return fail(ctx, V2M_ERR_STATE, "no graph uploaded");
+	if (rows->n_rows && !rows->copy_index && !rows->cut_offsets) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "rows->copy_index is NULL");
+	if (rows->cut_offsets && rows->cut_offsets[rows->n_rows] && (!rows->cut_nodes || !rows->cut_copies))
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut arrays are NULL");
+	if (rows->n_rows >= 0xFFFFFFFFull) return fail(ctx, V2M_ERR_UNSUPPORTED, "too many rows in one batch");
+	if (flags & V2M_SPLICE_UNALIGNED) return fail(ctx, V2M_ERR_UNSUPPORTED, "unaligned output is not implemented in this build yet");
+	return V2M_OK;
+}
+
+} // namespace
+
+
+// =============================================================================================
+extern "C" {
+
+uint32_t v2m_abi_version(void) { return V2M_ABI_VERSION; }
+
+int v2m_ctx_create(int device_id, v2m_ctx **ctx_out)
+{
+	if (!ctx_out) return fail(nullptr, V2M_ERR_INVALID_ARGUMENT, "ctx_out is NULL");
+	*ctx_out = nullptr;
+	int count(0);
+	hipError_t st(hipGetDeviceCount(&count));
+	if (hipSuccess != st || 0 == count)
+		return fail(nullptr, V2M_ERR_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback", hipSuccess != st ? hipGetErrorString(st) : "device count is 0");
+	if (device_id < 0 || device_id >= count)
+		return fail(nullptr, V2M_ERR_INVALID_ARGUMENT, "device %d out of range (%d devices)", device_id, count);
+	hipDeviceProp_t prop;
+	st = hipGetDeviceProperties(&prop, device_id);
+	if (hipSuccess != st) return fail(nullptr, V2M_ERR_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(st));
+	if (0 != std::strncmp(prop.gcnArchName, "gfx950", 6))
+		return fail(nullptr, V2M_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 (MI355X) only", device_id, prop.gcnArchName);
+	st = hipSetDevice(device_id);
+	if (hipSuccess != st) return fail(nullptr, V2M_ERR_HIP, "hipSetDevice: %s", hipGetErrorString(st));
+
+	auto *ctx(new v2m_ctx);
+	ctx->device = device_id;
+	if (hipSuccess != (st = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking))
+		|| hipSuccess != (st = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking))) {
+		delete ctx;
+		return fail(nullptr, V2M_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(st));
+	}
+	for (int i(0); i < 2; ++i) {
+		(void) hipEventCreateWithFlags(&ctx->ev_compute[i], hipEventDisableTiming);
+		(void) hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
+	}
+	*ctx_out = ctx;
+	return V2M_OK;
+}
+
+void v2m_ctx_destroy(v2m_ctx *ctx)
+{
+	if (!ctx) return;
+	(void) hipSetDevice(ctx->device);
+	(void) hipStreamSynchronize(ctx->stream);
+	(void) hipStreamSynchronize(ctx->copy_stream);
+	for (auto &v : ctx->events) for (auto &e : v) { (void) hipEventDestroy(e.begin); (void) hipEventDestroy(e.end); }
+	for (auto &e : ctx->free_events) { (void) hipEventDestroy(e.begin); (void) hipEventDestroy(e.end); }
+	for (int i(0); i < 2; ++i) {
+		if (ctx->ev_compute[i]) (void) hipEventDestroy(ctx->ev_compute[i]);
+		if (ctx->ev_copy[i]) (void) hipEventDestroy(ctx->ev_copy[i]);
+	}
+	(void) hipStreamDestroy(ctx->stream);
+	(void) hipStreamDestroy(ctx->copy_stream);
+	delete ctx;
+}
+
+const char *v2m_last_error(const v2m_ctx *ctx)
+{
+	return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int v2m_ctx_synchronize(v2m_ctx *ctx)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->copy_stream));
+	return V2M_OK;
+}
+
+void *v2m_ctx_stream(v2m_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+
+// ---- transpose ------------------------------------------------------------------------------
+
+int v2m_transpose_bits_device(v2m_ctx *ctx, const void *d_src_words, uint64_t n_rows, uint64_t n_cols, void *d_dst_words)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (0 == n_cols) return V2M_OK;                          // transpose_matrix.cc:48-49
+	if (n_rows % 64 || n_cols % 64)                          // transpose_matrix.cc:53-54
+		return fail(ctx, V2M_ERR_PRECONDITION, "matrix dimensions must be multiples of 64 (got %llu x %llu)", (unsigned long long) n_rows, (unsigned long long) n_cols);
+	if (0 == n_rows) return V2M_OK;
+	if (!d_src_words || !d_dst_words) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL matrix pointer");
+	if (((uintptr_t) d_src_words | (uintptr_t) d_dst_words) & 7) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "matrix pointers must be 8-byte aligned");
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	return launch_transpose(ctx, static_cast<u64 const *>(d_src_words), n_rows, n_cols, static_cast<u64 *>(d_dst_words));
+}
+
+int v2m_transpose_bits(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_rows, uint64_t n_cols, uint64_t *dst_words)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (0 == n_cols) return V2M_OK;
+	if (n_rows % 64 || n_cols % 64)
+		return fail(ctx, V2M_ERR_PRECONDITION, "matrix dimensions must be multiples of 64 (got %llu x %llu)", (unsigned long long) n_rows, (unsigned long long) n_cols);
+	if (0 == n_rows) return V2M_OK;
+	if (!src_words || !dst_words) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL matrix pointer");
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	size_t const bytes(n_rows / 64 * n_cols * sizeof(u64));
+	dev_buf src, dst;
+	V2M_HIP_TRY(ctx, src.ensure(bytes));
+	V2M_HIP_TRY(ctx, dst.ensure(bytes));
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(src.p, src_words, bytes, hipMemcpyHostToDevice, ctx->stream));
+	if (int const rc = launch_transpose(ctx, src.as<u64>(), n_rows, n_cols, dst.as<u64>())) return rc;
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(dst_words, dst.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return V2M_OK;
+}
+
+
+// ---- graph ----------------------------------------------------------------------------------
+
+int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq, uint64_t ref_len)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (!g) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "graph is NULL");
+	u64 const N(g->node_count), E(g->edge_count);
+	if (0 == N) return fail(ctx, V2M_ERR_PRECONDITION, "a variant graph has at least the source node");
+	if (!g->reference_positions || !g->aligned_positions || !g->alt_edge_count_csum) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL node array");
+	if (E && (!g->alt_edge_targets || !g->alt_edge_label_offsets)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL edge array");
+	if (ref_len && !ref_seq) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "ref_seq is NULL");
+	if (g->paths_by_chrom_copy_and_edge && (g->path_rows % 64 || g->path_cols % 64 || g->path_rows < E))
+		return fail(ctx, V2M_ERR_PRECONDITION, "path matrix must be (>= edge_count) x copies with both dimensions multiples of 64");
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+	u64 const limit32(0xFFFFFFFFull - 2 * v2m::kTileBytes);
+	u64 const L(g->aligned_positions[N - 1]);
+	if (N >= limit32 || E >= limit32 || L >= limit32 || ref_len >= limit32)
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "graph does not fit 32-bit device indices (nodes %llu, edges %llu, aligned length %llu)", (unsigned long long) N, (unsigned long long) E, (unsigned long long) L);
+
+	// --- validate what output_sequence() silently relies on, narrow to 32 bits -------------
+	std::vector<u32> ref_pos(N), aln_pos(N), csum(N + 1);
+	if (0 != g->reference_positions[0] || 0 != g->aligned_positions[0])
+		return fail(ctx, V2M_ERR_PRECONDITION, "node 0 must be at reference and aligned position 0");
+	for (u64 n(0); n < N; ++n) {
+		u64 const r(g->reference_positions[n]), a(g->aligned_positions[n]);
+		if (r > ref_len) return fail(ctx, V2M_ERR_PRECONDITION, "node %llu: reference position %llu is past the reference (%llu)", (unsigned long long) n, (unsigned long long) r, (unsigned long long) ref_len);
+		if (n) {
+			u64 const pr(g->reference_positions[n - 1]), pa(g->aligned_positions[n - 1]);
+			if (r <= pr) return fail(ctx, V2M_ERR_PRECONDITION, "reference positions must increase strictly (node %llu)", (unsigned long long) n);
+			if (a < pa || a - pa < r - pr)   // the '-' count at sequence_writer.cc:81 would underflow
+				return fail(ctx, V2M_ERR_PRECONDITION, "node %llu: aligned distance is shorter than the reference distance", (unsigned long long) n);
+		}
+		ref_pos[n] = u32(r);
+		aln_pos[n] = u32(a);
+	}
+	if (0 != g->alt_edge_count_csum[0] || E != g->alt_edge_count_csum[N])
+		return fail(ctx, V2M_ERR_PRECONDITION, "alt_edge_count_csum must run from 0 to edge_count");
+	for (u64 n(0); n <= N; ++n) {
+		if (n && g->alt_edge_count_csum[n] < g->alt_edge_count_csum[n - 1]) return fail(ctx, V2M_ERR_PRECONDITION, "alt_edge_count_csum decreases at node %llu", (unsigned long long) n);
+		csum[n] = u32(g->alt_edge_count_csum[n]);
+	}
+	if (N >= 1 && csum[N] != csum[N - 1])
+		return fail(ctx, V2M_ERR_PRECONDITION, "the sink node cannot have ALT edges");
+
+	std::vector<v2m::edge_span> spans(E);
+	std::vector<v2m::edge_patch> patches(E);
+	std::vector<u32> tgt_prefix_max(E + 1, 0);
+	u64 label_total(0);
+	if (E) {
+		label_total = g->alt_edge_label_offsets[E];
+		if (label_total >= limit32) return fail(ctx, V2M_ERR_UNSUPPORTED, "label pool too large");
+		if (label_total && !g->alt_edge_label_bytes) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "alt_edge_label_bytes is NULL");
+		if (0 != g->alt_edge_label_offsets[0]) return fail(ctx, V2M_ERR_PRECONDITION, "alt_edge_label_offsets must start at 0");
+	}
+	for (u64 n(0); n < N; ++n) {
+		for (u32 e(csum[n]); e < csum[n + 1]; ++e) {
+			u64 const tgt(g->alt_edge_targets[e]);
+			if (tgt <= n || tgt >= N) return fail(ctx, V2M_ERR_PRECONDITION, "edge %u: target %llu must lie after its source node %llu", e, (unsigned long long) tgt, (unsigned long long) n);
+			u64 const lo(g->alt_edge_label_offsets[e]), hi(g->alt_edge_label_offsets[e + 1]);
+			if (hi < lo || hi > label_total) return fail(ctx, V2M_ERR_PRECONDITION, "edge %u: bad label offsets", e);
+			if (hi - lo > u64(aln_pos[tgt]) - aln_pos[n])   // libbio_assert_lte at sequence_writer.cc:61
+				return fail(ctx, V2M_ERR_PRECONDITION, "edge %u: label (%llu) is longer than the aligned span (%u)", e, (unsigned long long) (hi - lo), aln_pos[tgt] - aln_pos[n]);
+			spans[e] = {u32(n), u32(tgt)};
+			patches[e] = {aln_pos[n], aln_pos[tgt], u32(lo), u32(hi - lo)};
+			tgt_prefix_max[e + 1] = std::max(tgt_prefix_max[e], u32(tgt));
+		}
+	}
+
+	// --- per-tile edge tables ----------------------------------------------------------------
+	u32 const n_tiles(u32(std::max<u64>(1, (L + v2m::kTileBytes - 1) / v2m::kTileBytes)));
+	std::vector<u32> tile_edge_begin(n_tiles + 1), cross_offsets(n_tiles + 1, 0), cross_edges;
+	{
+		u32 e(0);
+		for (u32 t(0); t <= n_tiles; ++t) {
+			u64 const base(u64(t) * v2m::kTileBytes);
+			while (e < E && patches[e].aln_begin < base) ++e;
+			tile_edge_begin[t] = e;
+		}
+		tile_edge_begin[n_tiles] = u32(E);
+		// an edge crosses into tile t when aln_begin < t*T < aln_end
+		std::vector<u32> counts(n_tiles + 1, 0);
+		auto for_each_crossing = [&](auto &&fn) {
+			for (u32 e2(0); e2 < E; ++e2) {
+				u64 const first(u64(patches[e2].aln_begin) / v2m::kTileBytes + 1);
+				if (0 == patches[e2].aln_end) continue;
+				u64 const last((u64(patches[e2].aln_end) - 1) / v2m::kTileBytes);
+				for (u64 t(first); t <= last && t < n_tiles; ++t) fn(u32(t), e2);
+			}
+		};
+		for_each_crossing([&](u32 t, u32) { ++counts[t]; });
+		for (u32 t(0); t < n_tiles; ++t) cross_offsets[t + 1] = cross_offsets[t] + counts[t];
+		cross_edges.resize(cross_offsets[n_tiles]);
+		std::vector<u32> cursor(cross_offsets.begin(), cross_offsets.end() - 1);
+		for_each_crossing([&](u32 t, u32 e2) { cross_edges[cursor[t]++] = e2; });
+	}
+
+	// --- upload ------------------------------------------------------------------------------
+	ctx->has_graph = false;
+	V2M_HIP_TRY(ctx, ctx->d_ref.ensure(std::max<u64>(ref_len, 16)));
+	if (ref_len) V2M_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ref.p, ref_seq, ref_len, hipMemcpyHostToDevice, ctx->stream));
+	V2M_HIP_TRY(ctx, ctx->d_labels.ensure(std::max<u64>(label_total, 16)));
+	if (label_total) V2M_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_labels.p, g->alt_edge_label_bytes, label_total, hipMemcpyHostToDevice, ctx->stream));
+	if (int const rc = upload_vec(ctx, ctx->d_ref_pos, ref_pos)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_aln_pos, aln_pos)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_spans, spans)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_patches, patches)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_tile_edge_begin, tile_edge_begin)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_cross_offsets, cross_offsets)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_cross_edges, cross_edges)) return rc;
+
+	u64 const n_chunks(u64(n_tiles) * v2m::kTileChunks);
+	V2M_HIP_TRY(ctx, ctx->d_template.ensure(n_chunks * 16));
+	{
+		timed_launch tl(ctx, V2M_KERNEL_TEMPLATE);
+		hipLaunchKernelGGL(v2m::expand_reference_row_kernel, dim3(unsigned((n_chunks + 255) / 256)), dim3(256), 0, ctx->stream,
+			ctx->d_ref.as<char>(), ctx->d_ref_pos.as<u32>(), ctx->d_aln_pos.as<u32>(), u32(N), u32(L), n_chunks, ctx->d_template.as<uint4>(), '-');
+	}
+	V2M_HIP_TRY(ctx, hipGetLastError());
+
+	ctx->d_paths = nullptr;
+	ctx->path_rows = ctx->path_cols = 0;
+	if (g->paths_by_chrom_copy_and_edge) {
+		size_t const bytes(g->path_rows / 64 * g->path_cols * sizeof(u64));
+		V2M_HIP_TRY(ctx, ctx->owned_paths.ensure(std::max<size_t>(bytes, 16)));
+		if (bytes) V2M_HIP_TRY(ctx, hipMemcpyAsync(ctx->owned_paths.p, g->paths_by_chrom_copy_and_edge, bytes, hipMemcpyHostToDevice, ctx->stream));
+		ctx->d_paths = ctx->owned_paths.as<u64>();
+		ctx->path_rows = g->path_rows;
+		ctx->path_cols = g->path_cols;
+	}
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+
+	ctx->n_nodes = N; ctx->n_edges = E; ctx->ref_len = ref_len; ctx->aligned_len = L; ctx->label_bytes = label_total;
+	ctx->n_tiles = n_tiles;
+	ctx->h_csum = std::move(csum);
+	ctx->h_tgt_prefix_max = std::move(tgt_prefix_max);
+	ctx->has_graph = true;
+	return V2M_OK;
+}
+
+int v2m_set_paths_device(v2m_ctx *ctx, const void *d_words, uint64_t path_rows, uint64_t path_cols)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (!ctx->has_graph) return fail(ctx, V2M_ERR_STATE, "no graph uploaded");
+	if (path_rows % 64 || path_cols % 64 || path_rows < ctx->n_edges)
+		return fail(ctx, V2M_ERR_PRECONDITION, "path matrix must be (>= edge_count) x copies with both dimensions multiples of 64");
+	if (path_rows && path_cols && (!d_words || ((uintptr_t) d_words & 7))) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "d_words must be a non-NULL 8-byte aligned device pointer");
+	ctx->d_paths = static_cast<u64 const *>(d_words);
+	ctx->path_rows = path_rows;
+	ctx->path_cols = path_cols;
+	return V2M_OK;
+}
+
+uint64_t v2m_aligned_length(const v2m_ctx *ctx) { return (ctx && ctx->has_graph) ? ctx->aligned_len : 0; }
+uint64_t v2m_min_row_pitch(const v2m_ctx *ctx) { return (ctx && ctx->has_graph) ? ((ctx->aligned_len + 255) & ~u64(255)) : 0; }
+uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx) { return (ctx && ctx->has_graph) ? ctx->ref_len + ctx->label_bytes : 0; }
+
+
+// ---- rows -----------------------------------------------------------------------------------
+
+int v2m_splice_rows_device(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, void *d_out, uint64_t row_pitch, uint64_t *row_lengths_out)
+{
+	if (int const rc = check_batch(ctx, rows, flags)) return rc;
+	if (0 == rows->n_rows) return V2M_OK;
+	if (!d_out || ((uintptr_t) d_out & 15)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "d_out must be a 16-byte aligned device pointer");
+	if (row_pitch % 16 || row_pitch < ((ctx->aligned_len + 15) & ~u64(15)))
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row_pitch must be a multiple of 16 and at least the aligned length rounded up to 16");
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (int const rc = splice_aligned_slice(ctx, rows, 0, rows->n_rows, static_cast<char *>(d_out), row_pitch)) return rc;
+	if (row_lengths_out)
+		for (u64 r(0); r < rows->n_rows; ++r) row_lengths_out[r] = ctx->aligned_len;
+	return V2M_OK;
+}
+
+int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m_sink_fn sink, void *user)
+{
+	if (int const rc = check_batch(ctx, rows, flags)) return rc;
+	if (!sink) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "sink is NULL");
+	if (0 == rows->n_rows) return V2M_OK;
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+	u64 const L(ctx->aligned_len);
+	if (0 == L) {
+		for (u64 r(0); r < rows->n_rows; ++r)
+			if (sink(user, r, "", 0)) return fail(ctx, V2M_ERR_SINK, "sink aborted at row %llu", (unsigned long long) r);
+		return V2M_OK;
+	}
+
+	// Slices of the batch alternate between two device buffers and two pinned host buffers:
+	// the D2H copy of slice s runs on copy_stream while the kernels of slice s+1 run on stream.
+	u64 const pitch(v2m_min_row_pitch(ctx));
+	char const *const slot_env(std::getenv("V2M_RING_SLOT_BYTES"));   // test knob: force small slices
+	u64 const slot_target((slot_env && *slot_env) ? std::strtoull(slot_env, nullptr, 10) : (u64(512) << 20));
+	u64 const rows_per_slice(std::max<u64>(1, std::min<u64>(rows->n_rows, slot_target / pitch)));
+	u64 const n_slices((rows->n_rows + rows_per_slice - 1) / rows_per_slice);
+	u64 const slot_bytes(rows_per_slice * pitch);
+	for (int i(0); i < (n_slices > 1 ? 2 : 1); ++i) {
+		V2M_HIP_TRY(ctx, ctx->ring[i].ensure(slot_bytes));
+		V2M_HIP_TRY(ctx, ctx->host_ring[i].ensure(slot_bytes));
+	}
+
+	auto drain = [&](u64 s) -> int {
+		int const b(int(s & 1));
+		V2M_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_copy[b]));
+		u64 const r0(s * rows_per_slice), r1(std::min(rows->n_rows, r0 + rows_per_slice));
+		char const *base(static_cast<char const *>(ctx->host_ring[b].p));
+		for (u64 r(r0); r < r1; ++r)
+			if (sink(user, r, base + (r - r0) * pitch, L)) return fail(ctx, V2M_ERR_SINK, "sink aborted at row %llu", (unsigned long long) r);
+		return V2M_OK;
+	};
+
+	int rc(V2M_OK);
+	u64 launched(0);
+	for (u64 s(0); s < n_slices && V2M_OK == rc; ++s) {
+		int const b(int(s & 1));
+		u64 const r0(s * rows_per_slice), r1(std::min(rows->n_rows, r0 + rows_per_slice));
+		rc = splice_aligned_slice(ctx, rows, r0, r1, ctx->ring[b].as<char>(), pitch);
+		if (V2M_OK != rc) break;
+		hipError_t st(hipEventRecord(ctx->ev_compute[b], ctx->stream));
+		if (hipSuccess == st) st = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compute[b], 0);
+		if (hipSuccess == st) st = hipMemcpyAsync(ctx->host_ring[b].p, ctx->ring[b].p, (r1 - r0) * pitch, hipMemcpyDeviceToHost, ctx->copy_stream);
+		if (hipSuccess == st) st = hipEventRecord(ctx->ev_copy[b], ctx->copy_stream);
+		if (hipSuccess != st) { rc = fail(ctx, V2M_ERR_HIP, "D2H pipeline: %s", hipGetErrorString(st)); break; }
+		launched = s + 1;
+		if (s >= 1) rc = drain(s - 1);
+	}
+	if (V2M_OK == rc && launched) rc = drain(launched - 1);
+	// leave both streams idle whatever happened
+	(void) hipStreamSynchronize(ctx->stream);
+	(void) hipStreamSynchronize(ctx->copy_stream);
+	return rc;
+}
+
+
+// ---- checksums ------------------------------------------------------------------------------
+
+int v2m_checksum_rows_device(v2m_ctx *ctx, const void *d_rows, uint64_t row_pitch, uint64_t n_rows, uint64_t length, const uint64_t *lengths, uint64_t *checksums_out)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (0 == n_rows) return V2M_OK;
+	if (!d_rows || !checksums_out || ((uintptr_t) d_rows & 7) || (row_pitch & 7)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad checksum arguments");
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	V2M_HIP_TRY(ctx, ctx->d_sums.ensure(n_rows * 8));
+	V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_sums.p, 0, n_rows * 8, ctx->stream));
+	u64 max_len(length);
+	u64 const *d_lengths(nullptr);
+	if (lengths) {
+		max_len = *std::max_element(lengths, lengths + n_rows);
+		V2M_HIP_TRY(ctx, ctx->d_lengths.ensure(n_rows * 8));
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_lengths.p, lengths, n_rows * 8, hipMemcpyHostToDevice, ctx->stream));
+		d_lengths = ctx->d_lengths.as<u64>();
+	}
+	for (u64 r(0); r < n_rows; ++r) {
+		u64 const len(lengths ? lengths[r] : length);
+		if (len > row_pitch) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row %llu is longer than the pitch", (unsigned long long) r);
+	}
+	u64 const words_per_block(256 * 32);
+	u64 const n_words((max_len + 7) / 8);
+	u64 const gx(std::max<u64>(1, (n_words + words_per_block - 1) / words_per_block));
+	for (u64 r0(0); r0 < n_rows; r0 += 32768) {
+		u64 const nr(std::min<u64>(32768, n_rows - r0));
+		hipLaunchKernelGGL(v2m::checksum_rows_kernel, dim3(unsigned(gx), unsigned(nr)), dim3(256), 0, ctx->stream,
+			static_cast<char const *>(d_rows) + r0 * row_pitch, row_pitch, d_lengths ? d_lengths + r0 : nullptr, length, words_per_block,
+			ctx->d_sums.as<unsigned long long>() + r0);
+		V2M_HIP_TRY(ctx, hipGetLastError());
+	}
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(checksums_out, ctx->d_sums.p, n_rows * 8, hipMemcpyDeviceToHost, ctx->stream));
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return V2M_OK;
+}
+
+
+// ---- profiling ------------------------------------------------------------------------------
+
+int v2m_profile_enable(v2m_ctx *ctx, int enabled)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	ctx->profiling = (0 != enabled);
+	return V2M_OK;
+}
+
+int v2m_profile_reset(v2m_ctx *ctx)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	for (auto &v : ctx->events) {
+		ctx->free_events.insert(ctx->free_events.end(), v.begin(), v.end());
+		v.clear();
+	}
+	return V2M_OK;
+}
+
+int v2m_profile_get(v2m_ctx *ctx, int kernel, uint64_t *launches_out, double *total_ms_out)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (kernel < 0 || kernel >= V2M_KERNEL_COUNT) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	double total(0);
+	for (auto const &e : ctx->events[kernel]) {
+		float ms(0);
+		V2M_HIP_TRY(ctx, hipEventElapsedTime(&ms, e.begin, e.end));
+		total += ms;
+	}
+	if (launches_out) *launches_out = ctx->events[kernel].size();
+	if (total_ms_out) *total_ms_out = total;
+	return V2M_OK;
+}
+
+} // extern "C"
