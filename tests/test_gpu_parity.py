@@ -126,6 +126,7 @@ SYNTH = [
 	(4, 120000, 1500, 6, {"long_every": 40}),                           # long deletions / insertions crossing tiles
 	(5, 40000, 4000, 5, {"multi_allelic": 0.3, "density": 0.3}),        # dense, multi-allelic, many overlaps
 	(6, 70000, 900, 3, {"ploidy": 1}),
+	(7, 30000, 500, 40, {}),                                            # 80 copies: two words per path-matrix column
 ]
 
 
