@@ -1,0 +1,230 @@
+#!/usr/bin/env python3
+"""bench.py -- aligned A2M Gbases/s of the MI355X haplotype-splice path.
+
+A "step" is one pass of the hot path over this rank's share of the synthetic workload:
+transpose the rank's genotype bit matrix (transpose_matrix), then splice every owned row
+(REF on rank 0 + the rank's chromosome copies) into aligned A2M row bodies in HBM, in batches that
+reuse one device output buffer (the rows of config 3 total 501 GB).  All inputs are resident in HBM
+before the timed region starts; nothing is copied to the host inside it.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Haplotypes shard across ranks in blocks of 64 chromosome copies with the reference and graph
+replicated; there is no collective on the data path.  The total work is the
+named config's and is fixed as N grows, hence "scaling": "strong".
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+	if p not in sys.path:
+		sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+
+def log(*a):
+	print(*a, file=sys.stderr, flush=True)
+
+
+def shard_copies(n_copies, world, rank):
+	"""Contiguous blocks of whole 64-copy words (so bit-matrix words split cleanly)."""
+	n_words = (n_copies + 63) // 64
+	base, extra = divmod(n_words, world)
+	w0 = rank * base + min(rank, extra)
+	w1 = w0 + base + (1 if rank < extra else 0)
+	return 64 * w0, min(n_copies, 64 * w1), 64 * (w1 - w0)   # first copy, end copy, padded local copy count
+
+
+def main():
+	ap = argparse.ArgumentParser()
+	ap.add_argument("--gpus", type=int, default=1)
+	ap.add_argument("--steps", type=int, default=3)
+	ap.add_argument("--warmup", type=int, default=1)
+	ap.add_argument("--config", default="config3", help="synthetic workload (vcf2multialign_amd/synth.py CONFIGS)")
+	ap.add_argument("--batch-rows", type=int, default=512, help="rows per splice launch (one device output buffer of this many rows is reused)")
+	ap.add_argument("--cpu-baseline-rows", type=int, default=64, help="haplotypes (plus REF) the CPU oracle is timed on; 0 disables")
+	ap.add_argument("--verify-rows", type=int, default=3, help="rows of the last batch checked against the CPU oracle after timing; 0 disables")
+	args = ap.parse_args()
+
+	rank = int(os.environ.get("RANK", "0"))
+	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+	world = int(os.environ.get("WORLD_SIZE", "1"))
+	if world != args.gpus:
+		if world == 1 and args.gpus > 1:
+			sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+		sys.exit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+
+	import torch
+	import torch.distributed as dist
+
+	import vcf2multialign_amd as v2m
+	from vcf2multialign_amd import _native as N
+	from vcf2multialign_amd import synth
+
+	torch.cuda.set_device(local_rank)
+	dev = torch.device("cuda", local_rank)
+	if world > 1:
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		dist.init_process_group("nccl", device_id=dev)
+
+	# ---- workload: generated on every rank (deterministic), resident in HBM before timing ----------
+	t0 = time.time()
+	ds = synth.dataset(args.config)
+	g = ds.graph
+	L, R, NN, E = g.aligned_length, len(ds.reference), g.node_count, g.edge_count
+	H = ds.n_copies
+	Ep = ds.path_rows
+	if rank == 0:
+		log("[bench] %s: R=%d variants/edges=%d nodes=%d L=%d copies=%d (generated in %.1fs)" % (args.config, R, E, NN, L, H, time.time() - t0))
+
+	ctx = v2m.Context(local_rank)
+	ctx.upload_graph(g, ds.reference)
+	pitch = ctx.min_row_pitch
+
+	c0, c1, hp_local = shard_copies(H, world, rank)
+	n_local_copies = c1 - c0
+	rows = ([v2m.PLOIDY_MAX] if rank == 0 else []) + list(range(n_local_copies))   # local copy indices into this rank's matrix
+	n_rows = len(rows)
+	total_rows = H + 1
+
+	thr = torch.from_numpy(ds.edge_thresholds.astype(np.int64)).to(torch.int32).to(dev) if E else torch.zeros(1, dtype=torch.int32, device=dev)
+	words = Ep // 64 * hp_local
+	paths_src = torch.empty(max(words, 1), dtype=torch.int64, device=dev)   # paths_by_edge_and_chrom_copy (this rank's copies x Ep)
+	paths_dst = torch.empty(max(words, 1), dtype=torch.int64, device=dev)   # paths_by_chrom_copy_and_edge (Ep x this rank's copies)
+	batch_rows = max(1, min(args.batch_rows, n_rows))
+	out = torch.empty(batch_rows * pitch, dtype=torch.uint8, device=dev)
+	torch.cuda.synchronize()
+	if hp_local:
+		ds.fill_paths_device(ctx.stream, paths_src.data_ptr(), thr.data_ptr(), copy_base=c0, n_rows=hp_local)
+	ctx.synchronize()
+
+	batches = [v2m.RowBatch(rows[i:i + batch_rows]) for i in range(0, n_rows, batch_rows)]
+
+	def step():
+		if hp_local:
+			ctx.transpose_bits_device(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())
+			ctx.set_paths_device(paths_dst.data_ptr(), Ep, hp_local)
+		for b in batches:
+			ctx.splice_rows_device(b, out.data_ptr(), pitch)
+
+	def fence():
+		ctx.synchronize()
+		torch.cuda.synchronize()
+		if world > 1:
+			dist.barrier()
+
+	for _ in range(args.warmup):
+		step()
+	fence()
+	ctx.profile_enable(True)
+	ctx.profile_reset()
+	t_begin = time.perf_counter()
+	for _ in range(args.steps):
+		step()
+	ctx.synchronize()
+	torch.cuda.synchronize()
+	elapsed = time.perf_counter() - t_begin
+	if world > 1:
+		dist.barrier()
+		t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+		dist.all_reduce(t, op=dist.ReduceOp.MAX)
+		elapsed = float(t.item())
+	ctx.profile_enable(False)
+
+	# ---- roofline of the dominant kernel, from HIP events on the kernel's own stream ---------------
+	launches, splice_ms = ctx.profile_get(N.KERNEL_SPLICE_ALIGNED)
+	_, resolve_ms = ctx.profile_get(N.KERNEL_RESOLVE)
+	_, transpose_ms = ctx.profile_get(N.KERNEL_TRANSPOSE)
+	label_bytes = len(g.label_bytes)
+	# algorithmic bytes of one launch over Hb rows (SURVEY.md 8d / BASELINE.md):
+	#   Hb*L + Hb*Ep/8 + R + 24*N + 8*E + sum|label|
+	alg_bytes_total = 0
+	for b in batches:
+		alg_bytes_total += b.n_rows * L + b.n_rows * Ep // 8 + R + 24 * NN + 8 * E + label_bytes
+	alg_bytes_per_launch = alg_bytes_total / max(1, len(batches))
+	avg_launch_s = (splice_ms / 1e3) / max(1, launches)
+	achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+
+	value = total_rows * L * args.steps / elapsed / 1e9
+
+	result = {
+		"metric": "aligned A2M Gbases/sec",
+		"value": round(value, 3),
+		"unit": "Gbases/s",
+		"n_gpus": world,
+		"steps": args.steps,
+		"warmup": args.warmup,
+		"ms_per_step": round(1e3 * elapsed / args.steps, 3),
+		"higher_is_better": True,
+		"scaling": "strong",
+		"vs_baseline": None,
+		"dtype": "u8",
+		"data": "synthetic",
+		"config": {
+			"workload": "%s: synthetic %d bp reference, %d variant records (%d ALT edges), %d diploid samples = %d haplotype rows + REF, --haplotypes aligned A2M, L=%d"
+				% (args.config, R, ds.n_variants, E, ds.samples, H, L),
+			"rows_total": total_rows, "aligned_length": L, "batch_rows": batch_rows,
+			"sharding": "chromosome copies in blocks of 64 per rank, graph + reference replicated, no collective",
+		},
+		"roofline": {
+			"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+			"frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+			"kernel": "splice_aligned_kernel", "launches": launches, "avg_launch_ms": round(1e3 * avg_launch_s, 4),
+			"algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
+			"other_kernels_ms_per_step": {"resolve_effective_edges_kernel": round(resolve_ms / args.steps, 3), "transpose_bits_kernel": round(transpose_ms / args.steps, 3)},
+		},
+	}
+
+	# ---- CPU oracle: parity of sampled rows, and the timed single-thread baseline (rank 0, N=1) ----
+	if rank == 0 and (args.verify_rows or (world == 1 and args.cpu_baseline_rows)):
+		import oracle
+		n_cols = max(args.cpu_baseline_rows if world == 1 else 0, 64)
+		n_cols = min(64 * ((n_cols + 63) // 64), 64 * ((H + 63) // 64))
+		cols = np.concatenate([ds.copy_column(c) if c < H else np.zeros(Ep // 64, np.uint64) for c in range(n_cols)]) if Ep else np.zeros(0, np.uint64)
+		og = oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
+			g.label_offsets, g.label_bytes, cols, Ep, n_cols, g.sample_names[:n_cols // ds.ploidy], g.ploidy_csum[:n_cols // ds.ploidy + 1])
+		if args.verify_rows:
+			# re-run the first batch (REF + first copies) and compare device checksums + full bytes of sampled rows
+			k = min(args.verify_rows, batch_rows, n_cols)
+			ctx.splice_rows_device(batches[0], out.data_ptr(), pitch)
+			sums = ctx.checksum_rows_device(out.data_ptr(), pitch, k, length=L)
+			bodies = [og.output_sequence(ds.reference, copy_index=int(r)) for r in rows[:k]]
+			ok = bool(np.array_equal(sums, v2m.checksum_rows_host(bodies)))
+			host_row = out[(k - 1) * pitch:(k - 1) * pitch + L].cpu().numpy().tobytes()
+			ok = ok and host_row == bodies[k - 1]
+			result["parity"] = {"rows_checked": k, "bit_exact": ok, "method": "device row checksums + one full row vs CPU oracle"}
+			if not ok:
+				log("[bench] PARITY FAILURE against the CPU oracle")
+		if world == 1 and args.cpu_baseline_rows:
+			nb = min(args.cpu_baseline_rows, H)
+			nbytes, secs = og.haplotype_output_a2m(ds.reference, None, first_copy=0, n_copies=nb)
+			bases = (nb + 1) * L
+			result["cpu_baseline"] = {
+				"value": round(bases / secs / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
+				"sample": "REF + first %d haplotypes of %s (%.2f Gbases) through the oracle's output_sequence/haplotype_output_a2m into a discarding std::ostream, %.1f s; rows are independent, so the rate carries to the full %d rows; host has %d logical CPUs"
+					% (nb, args.config, bases / 1e9, secs, total_rows, os.cpu_count()),
+			}
+
+	if rank == 0:
+		print(json.dumps(result), flush=True)
+	if world > 1:
+		dist.barrier()
+		dist.destroy_process_group()
+	ctx.close()
+	if rank == 0 and result.get("parity", {}).get("bit_exact") is False:
+		sys.exit(3)
+
+
+if __name__ == "__main__":
+	main()

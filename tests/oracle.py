@@ -98,7 +98,9 @@ class OracleGraph:
 		self.label_bytes = C.string_at(L.v2mo_label_bytes(handle), nbytes) if nbytes else b""
 		blob = C.string_at(L.v2mo_sample_name_blob(handle), L.v2mo_sample_name_blob_size(handle))
 		self.sample_names = [s.decode() for s in blob.split(b"\0")[:-1]] if S else []
-		self.ploidy_csum = _np_from(L.v2mo_ploidy_csum(handle), S + 1, np.uint32) if S else np.zeros(1, np.uint32)
+		# no record on the requested chromosome leaves ploidy_csum empty in the reference too (variant_graph.cc:215-221 never runs)
+		pc = L.v2mo_ploidy_csum(handle)
+		self.ploidy_csum = _np_from(pc, S + 1, np.uint32) if (S and pc) else np.zeros(1, np.uint32)
 		r, c = C.c_uint64(), C.c_uint64()
 		p = L.v2mo_path_words(handle, 0, C.byref(r), C.byref(c))
 		self.path_rows, self.path_cols = r.value, c.value  # rows = edges (Ep), cols = copies (Hp)

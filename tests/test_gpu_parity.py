@@ -217,23 +217,24 @@ def test_sink_slices(v2m, ctx, tmp_path, monkeypatch):
 
 def test_no_variants_and_empty_batches(v2m, ctx, tmp_path):
 	ref = b"ACGTACGTAC"
-	fa, vcf = synth.write_inputs(str(tmp_path), ref, [], 2)
+	# one record whose only ALT is '.', i.e. no edge at all (variant_graph.cc:362-363)
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, [(2, b"G", [b"."], np.zeros((2, 2), dtype=np.int64))], 2)
 	g = oracle.build_variant_graph(fa, vcf, "1")
-	assert g.edge_count == 0 and g.node_count == 2
+	assert g.edge_count == 0 and g.node_count == 3 and g.total_chromosome_copies == 4
 	_upload(v2m, ctx, g)
-	assert ctx.splice_rows([v2m.PLOIDY_MAX]) == [ref]
+	assert ctx.splice_rows([v2m.PLOIDY_MAX, 0, 3]) == [ref, ref, ref]
 	assert ctx.splice_rows([]) == []
 
 
 def test_precondition_errors(v2m, ctx, tmp_path):
-	g = synth.build_case(tmp_path, 41, 5000, 100, 3)
+	g = synth.build_case(tmp_path, 41, 60000, 400, 3, long_every=10)
 	vg = _upload(v2m, ctx, g)
 	with pytest.raises(v2m.V2MError) as e:                       # copy outside the matrix
 		ctx.splice_rows([g.path_cols])
 	assert e.value.code == 1
 	# a cut node inside an edge span is what the reference asserts against (founder_sequence_greedy_output.cc:108)
-	e0 = next(e for e in range(g.edge_count) if int(g.alt_edge_targets[e]) - int(np.searchsorted(g.alt_edge_count_csum, e, side="right") - 1) >= 2)
-	src = int(np.searchsorted(g.alt_edge_count_csum, e0, side="right") - 1)
+	src_of = np.searchsorted(g.alt_edge_count_csum, np.arange(g.edge_count), side="right") - 1
+	src = int(src_of[np.nonzero(g.alt_edge_targets.astype(np.int64) - src_of >= 2)[0][0]])
 	with pytest.raises(v2m.V2MError) as e:
 		ctx.splice_rows([[(0, 0), (src + 1, 1)]])
 	assert e.value.code == 2

@@ -84,6 +84,13 @@ def load():
 		raise ImportError(
 			"%s is missing: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
 			"vcf2multialign_amd has no CPU fallback." % path)
+	# One HIP runtime per process: torch ships its own libamdhip64 (SONAME libamdhip64.so.7, the same as
+	# /opt/rocm's).  Importing torch first makes our NEEDED entry resolve to the copy torch already
+	# loaded; the other order would load two runtimes and the second one finds no GPU.
+	try:
+		import torch  # noqa: F401
+	except ImportError:
+		pass
 	lib = C.CDLL(path)
 	for name, (restype, argtypes) in SIGNATURES.items():
 		fn = getattr(lib, name)   # AttributeError if the library does not export a declared symbol

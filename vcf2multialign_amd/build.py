@@ -18,6 +18,11 @@ HIP_SOURCES = [os.path.join(CSRC, "v2m_hip.hip")]
 HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "kernels.hpp"), os.path.join(ROOT, "include", "v2m_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra"]
 
+# synthetic-input generator (bench + scale tests): host generator + the HIP kernel filling genotype bits
+SYNTH_LIB_PATH = os.path.join(PKG_DIR, "libv2m_synth.so")
+SYNTH_SOURCES = [os.path.join(CSRC, "synth", "synth_capi.hip"), os.path.join(CSRC, "synth", "synth.cc"), os.path.join(CSRC, "host", "graph_builder.cc")]
+SYNTH_DEPS = SYNTH_SOURCES + [os.path.join(CSRC, "synth", "synth.hh"), os.path.join(CSRC, "host", "graph_builder.hh"), os.path.join(CSRC, "host", "variant_graph.hh")]
+
 
 def find_hipcc():
 	for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
@@ -33,15 +38,20 @@ def _stale(target, deps):
 	return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build_native(force=False, verbose=False):
-	"""Compiles libv2m_hip.so for gfx950 if it is missing or older than its sources."""
-	if not force and not _stale(LIB_PATH, HIP_DEPS):
-		return LIB_PATH
+def _build(target, sources, deps, force, verbose):
+	if not force and not _stale(target, deps):
+		return target
 	hipcc = find_hipcc()
 	if hipcc is None:
-		raise RuntimeError("hipcc not found: cannot build " + LIB_PATH)
-	cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + HIP_SOURCES
+		raise RuntimeError("hipcc not found: cannot build " + target)
+	cmd = [hipcc] + HIPCC_FLAGS + ["-o", target] + sources
 	if verbose:
 		print(" ".join(cmd))
 	subprocess.check_call(cmd, cwd=ROOT)
-	return LIB_PATH
+	return target
+
+
+def build_native(force=False, verbose=False):
+	"""Compiles libv2m_hip.so (and the synthetic-input helper) for gfx950 if missing or older than the sources."""
+	_build(SYNTH_LIB_PATH, SYNTH_SOURCES, SYNTH_DEPS, force, verbose)
+	return _build(LIB_PATH, HIP_SOURCES, HIP_DEPS, force, verbose)

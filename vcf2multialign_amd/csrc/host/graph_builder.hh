@@ -1,0 +1,90 @@
+// graph_builder.hh -- streaming construction of the variant graph from variant records.
+//
+// Behaviour follows the reference's build_variant_graph() (libvcf2multialign/variant_graph.cc:108-454,
+// SURVEY.md Appendix B) record for record; the structure does not: the reference is one function
+// around a VCF-reader callback, this is a push-style builder that any record source can drive --
+// the VCF text reader (vcf_reader.cc) and the synthetic generator (synth.cc) both do -- with the
+// pending ALT targets in a binary heap instead of a multimap.
+#pragma once
+
+#include <functional>
+#include <queue>
+#include <string_view>
+#include <vector>
+
+#include "variant_graph.hh"
+
+namespace v2m::host {
+
+enum class alt_kind { sequence, deletion, unhandled };   // vcf::sv_type NONE / DEL / everything else (variant_graph.cc:328-364)
+
+alt_kind classify_alt(std::string_view alt);
+
+struct alt_allele {
+	alt_kind kind{alt_kind::unhandled};
+	std::string_view sequence;   // for alt_kind::sequence
+};
+
+struct overlap_info {
+	u64 ref_pos{};
+	u32 copy_row{};      // chromosome copy (row of paths_by_edge_and_chrom_copy)
+	u32 alt_number{};    // 1-based GT value
+};
+
+class graph_builder {
+public:
+	typedef std::function<void(overlap_info const &)> overlap_callback;
+
+	// track_paths == false builds nodes/edges only (the path matrix is then produced elsewhere,
+	// e.g. directly in HBM by the synthetic generator).
+	graph_builder(variant_graph &graph, bool track_paths = true);
+
+	// Must be called once before the first record, with the ploidy of every (included) sample
+	// (variant_graph.cc:215-288: taken from the first matching record).
+	void begin(std::vector<std::string> sample_names, std::vector<u32> const &ploidies);
+
+	// One record.  Positions must be non-decreasing (variant_graph.cc:292-297; returns false otherwise).
+	// After the call edge_for_alt(i) tells which edge ALT i became (kEdgeMax if it was skipped).
+	bool add_record(u64 ref_pos, u64 ref_allele_length, alt_allele const *alts, std::size_t n_alts);
+	u64 edge_for_alt(std::size_t alt_idx) const { return m_edges_by_alt[alt_idx]; }
+
+	// Genotype of one chromosome copy for the record just added: alt_number is the 1-based GT value
+	// (0 and missing are not passed).  Sets the path bit, reporting an overlap first when the copy is
+	// still inside an earlier ALT (variant_graph.cc:399-424 -- the bit is set even then).
+	void set_genotype(u32 copy_row, u32 alt_number);
+
+	// Sink node and final column count (variant_graph.cc:437-451).  The transpose that follows in the
+	// reference (:453) is NOT done here: it is the GPU's job (gpu_path.hh: transpose_paths()).
+	void finish(u64 ref_length);
+
+	void on_overlap(overlap_callback cb) { m_overlap_cb = std::move(cb); }
+
+private:
+	struct pending_target {
+		u64 ref_pos;
+		u64 seq;          // insertion order, to break ties like std::multimap does
+		u64 edge;
+		u64 aln_pos;
+		bool operator>(pending_target const &o) const { return ref_pos != o.ref_pos ? ref_pos > o.ref_pos : seq > o.seq; }
+	};
+
+	u64 add_node(u64 ref_pos, u64 aln_pos);
+	u64 add_or_update_node(u64 ref_pos, u64 aln_pos);
+	u64 add_edge(std::string_view label);
+	void flush_targets(u64 ref_pos);
+
+	variant_graph &m_graph;
+	bool m_track_paths;
+	std::priority_queue<pending_target, std::vector<pending_target>, std::greater<pending_target>> m_pending;
+	u64 m_seq{};
+	u64 m_aln_pos{};
+	u64 m_prev_ref_pos{};
+	u64 m_cur_ref_pos{};
+	u64 m_min_edge{};
+	std::vector<u64> m_edges_by_alt;
+	std::vector<u64> m_current_edge_targets;
+	std::vector<u64> m_target_ref_pos_by_copy;
+	overlap_callback m_overlap_cb;
+};
+
+} // namespace v2m::host

@@ -1,0 +1,129 @@
+#include "synth.hh"
+
+#include <algorithm>
+#include <cmath>
+
+#include "../host/graph_builder.hh"
+
+namespace v2m::synth {
+
+namespace {
+
+struct xoshiro256ss {
+	u64 s[4];
+	explicit xoshiro256ss(u64 seed)
+	{
+		for (auto &v : s) { seed += 0x9E3779B97F4A7C15ULL; v = mix64(seed); }
+	}
+	static u64 rotl(u64 x, int k) { return (x << k) | (x >> (64 - k)); }
+	u64 next()
+	{
+		u64 const result(rotl(s[1] * 5, 7) * 9);
+		u64 const t(s[1] << 17);
+		s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+		s[2] ^= t;
+		s[3] = rotl(s[3], 45);
+		return result;
+	}
+	double uniform() { return double(next() >> 11) * (1.0 / 9007199254740992.0); }
+	u64 below(u64 n) { return u64((__uint128_t(next()) * n) >> 64); }
+};
+
+constexpr char kBases[4] = {'A', 'C', 'G', 'T'};
+
+char other_base(xoshiro256ss &rng, char ref)
+{
+	char c;
+	do c = kBases[rng.below(4)]; while (c == ref);
+	return c;
+}
+
+u32 geometric_mean3(xoshiro256ss &rng, u32 cap)
+{
+	u32 k(1);
+	while (k < cap && rng.uniform() >= 1.0 / 3.0) ++k;
+	return k;
+}
+
+u32 draw_threshold(xoshiro256ss &rng)
+{
+	double const f(0.5 * std::pow(10.0, -3.0 * rng.uniform()));
+	return u32(f * 4294967296.0);
+}
+
+} // namespace
+
+
+void generate(config const &cfg, dataset &out)
+{
+	xoshiro256ss rng(cfg.seed);
+	u64 const R(cfg.ref_length);
+
+	out.reference.resize(R);
+	for (u64 i(0); i < R; i += 32) {            // 2 bits per base, 32 bases per draw
+		u64 bits(rng.next());
+		for (u64 j(i); j < std::min(R, i + 32); ++j, bits >>= 2)
+			out.reference[j] = kBases[bits & 3];
+	}
+
+	// distinct sorted sites
+	std::vector<u64> sites;
+	u64 const span(R > 64 ? R - 64 : 1);
+	u64 const want(std::min(cfg.n_variants, span));
+	sites.reserve(want + want / 8);
+	while (sites.size() < want) {
+		u64 const missing(want - sites.size());
+		for (u64 i(0); i < missing + missing / 16 + 8; ++i) sites.push_back(rng.below(span));
+		std::sort(sites.begin(), sites.end());
+		sites.erase(std::unique(sites.begin(), sites.end()), sites.end());
+	}
+	if (sites.size() > want) {
+		// drop the surplus at evenly spread ranks so the rest stays uniform
+		std::vector<u64> kept;
+		kept.reserve(want);
+		u64 const n(sites.size());
+		for (u64 i(0); i < want; ++i) kept.push_back(sites[i * n / want]);
+		sites.swap(kept);
+	}
+
+	out.graph = host::variant_graph{};
+	out.edge_thresholds.clear();
+	host::graph_builder builder(out.graph, /* track_paths */ false);
+	std::string alt_a, alt_b;
+	for (u64 const pos : sites) {
+		double const u(rng.uniform());
+		char const ref_base(out.reference[pos]);
+		host::alt_allele alts[2];
+		std::size_t n_alts(1);
+		u64 ref_len(1);
+		alt_a.clear();
+		double edge(cfg.frac_mnp);
+		if (u < edge) {
+			ref_len = 2 + rng.below(3);
+			for (u64 i(0); i < ref_len; ++i) alt_a.push_back(other_base(rng, out.reference[pos + i]));
+		} else if (u < (edge += cfg.frac_insertion)) {
+			u32 const k(geometric_mean3(rng, cfg.max_indel));
+			alt_a.push_back(ref_base);
+			for (u32 i(0); i < k; ++i) alt_a.push_back(kBases[rng.below(4)]);
+		} else if (u < (edge += cfg.frac_deletion)) {
+			ref_len = 1 + geometric_mean3(rng, cfg.max_indel);
+			alt_a.push_back(ref_base);
+		} else if (u < (edge += cfg.frac_multiallelic)) {
+			alt_a.push_back(other_base(rng, ref_base));
+			alt_b.clear();
+			alt_b.push_back(ref_base);
+			u32 const k(geometric_mean3(rng, cfg.max_indel));
+			for (u32 i(0); i < k; ++i) alt_b.push_back(kBases[rng.below(4)]);
+			alts[1] = {host::alt_kind::sequence, alt_b};
+			n_alts = 2;
+		} else {
+			alt_a.push_back(other_base(rng, ref_base));
+		}
+		alts[0] = {host::alt_kind::sequence, alt_a};
+		builder.add_record(pos, ref_len, alts, n_alts);
+		for (std::size_t a(0); a < n_alts; ++a) out.edge_thresholds.push_back(draw_threshold(rng));
+	}
+	builder.finish(R);
+}
+
+} // namespace v2m::synth
