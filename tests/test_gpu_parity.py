@@ -143,10 +143,13 @@ def test_synthetic_haplotypes(v2m, ctx, tmp_path, seed, ref_len, n_var, n_sample
 		assert a == b, "row %d differs" % i
 
 
-@pytest.mark.parametrize("density", [0.02, 0.3, 0.9])
-def test_random_path_bits_skip_rule(v2m, ctx, tmp_path, density):
-	"""iid random path bits: most set edges overlap an earlier one, so nearly every chunk of the
-	resolve scan takes the serial path (sequence_writer.cc:51-67 skip semantics)."""
+@pytest.mark.parametrize("density,max_back", [(0.02, None), (0.3, None), (0.9, None), (0.3, "0"), (0.9, "1")])
+def test_random_path_bits_skip_rule(v2m, ctx, tmp_path, monkeypatch, density, max_back):
+	"""iid random path bits on a graph full of overlapping edges (long deletions, multi-allelic sites):
+	the skip semantics of sequence_writer.cc:51-67 decide most rows.  max_back forces the rows whose
+	restart point lies in an earlier word through the one-wave-per-row serial kernel."""
+	if max_back is not None:
+		monkeypatch.setenv("V2M_MAX_BACK_WORDS", max_back)
 	g0 = synth.build_case(tmp_path, 11, 60000, 5000, 4, multi_allelic=0.2, long_every=97)
 	g = synth.with_random_paths(g0, 5, density)
 	_upload(v2m, ctx, g)

@@ -204,12 +204,24 @@ __global__ __launch_bounds__(256) void expand_reference_row_kernel(
 // node `cur` (initially 0): edge e is effective iff src[e] >= cur, and then cur = tgt[e]
 // (hard part 2).
 //
-// One wave per output row.  The wave streams the row's path-bit column 64 words (4096 edges)
-// at a time.  Fast path: with P = running maximum of cur and the targets of all earlier set
-// edges, src[e] >= P for every set edge proves that every set edge is effective (targets then
-// increase monotonically, so P is exactly cur).  Only chunks that fail the test fall back to a
-// lane-serial replay.  Founder rows assemble their bit column from several chromosome copies,
-// one per cut segment (founder_sequence_greedy_output.cc:106-114).
+// What makes this parallel is a property of the GRAPH, not of the row: an edge whose source
+// node is at or after the target of every lower-numbered edge (src[e] >= max tgt[0..e)) can
+// never be skipped, whatever bits a row has, because cur is always one of those targets.
+// Only the other edges -- the "overlappable" ones, lying inside the span of an earlier edge:
+// variants under a deletion, second and later ALTs of a multi-allelic site -- need the scan,
+// and for them the scan can restart, with cur = 0, at the nearest earlier edge that is NOT
+// overlappable (set or not: every earlier target is <= its source).  Both the mask and hence the
+// restart points are properties of the uploaded graph, computed once.
+//
+// resolve_effective_edges_kernel: one thread per (row, 64-edge word), fully coalesced.  A word
+// with no set overlappable bit is copied through.  Otherwise the thread finds its restart
+// point in the static mask and replays the row's set bits from there to the end of its own
+// word.  A restart point more than kMaxBackWords away
+// (graphs with chromosome-scale deletions) flags the row for resolve_rows_serial_kernel, the
+// one-wave-per-row scan that carries cur across the whole row.
+//
+// Founder rows assemble their bit column from several chromosome copies, one per cut segment
+// (founder_sequence_greedy_output.cc:106-114).
 // ---------------------------------------------------------------------------------------------
 struct row_segments {
 	// segment k of a row covers edges [edge_begin[k], edge_begin[k+1]) and reads copy[k];
@@ -249,14 +261,78 @@ __device__ __forceinline__ u64 load_row_word(
 	return w;
 }
 
+constexpr u32 kMaxBackWords = 2048;   // default max_back_words: restart points > 131072 edges back go to the serial kernel
+
 __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
+	row_segments rs, edge_span const *__restrict__ spans, u64 const *__restrict__ overlappable,
+	u64 *__restrict__ eff, u32 n_words, u32 n_rows, u32 *__restrict__ needs_serial, u32 max_back_words)
+{
+	u64 const idx = (u64) blockIdx.x * blockDim.x + threadIdx.x;
+	if (idx >= (u64) n_rows * n_words) return;
+	u32 const row = (u32) (idx / n_words), wi = (u32) (idx % n_words);
+	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
+	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;   // padding bits are zero by contract; do not trust them
+
+	u64 w = load_row_word(paths, words_per_copy, rs, s_begin, s_end, wi);
+	if (wi == n_words - 1) w &= tail_mask;
+	u64 const ovl_w = overlappable[wi];
+	u64 const ov = w & ovl_w;
+	u64 out = w;
+	if (ov) {
+		// Restart point: the nearest earlier edge that is NOT overlappable, set or not.  When the walk
+		// reaches such an edge every earlier target is <= its source node, so the scan state there is
+		// equivalent to cur = 0.  The search runs over the graph-static mask only.
+		int const b0 = __builtin_ctzll(ov);
+		u32 sw = wi;
+		int sb = 0;
+		bool ok = true;
+		u64 fixed = ~ovl_w & ((1ULL << b0) - 1);
+		if (fixed) {
+			sb = 63 - __builtin_clzll(fixed);
+		} else {
+			u32 steps = 0;
+			for (;;) {
+				if (0 == sw) { sb = 0; break; }              // edge 0 is never overlappable; defensive
+				--sw;
+				if (++steps > max_back_words) { ok = false; break; }
+				fixed = ~overlappable[sw];
+				if (fixed) { sb = 63 - __builtin_clzll(fixed); break; }
+			}
+		}
+		if (!ok) {
+			atomicOr(&needs_serial[row], 1u);
+		} else {
+			out = (sw == wi) ? (w & ((1ULL << sb) - 1)) : 0;   // set bits before the restart point in this word are certain
+			u32 cur = 0;
+			for (u32 ww = sw; ww <= wi; ++ww) {
+				u64 x = (ww == wi) ? w : load_row_word(paths, words_per_copy, rs, s_begin, s_end, ww);
+				if (ww == sw) x &= ~((1ULL << sb) - 1);
+				for (; x; x &= x - 1) {
+					int const b = __builtin_ctzll(x);
+					edge_span const sp = spans[ww * 64u + b];
+					if (sp.src >= cur) {
+						cur = sp.tgt;
+						if (ww == wi) out |= 1ULL << b;
+					}
+				}
+			}
+		}
+	}
+	eff[(u64) row * n_words + wi] = out;
+}
+
+
+// One wave per flagged row: the row-long scan that carries cur across 4096-edge chunks.
+__global__ __launch_bounds__(256) void resolve_rows_serial_kernel(
+	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
 	row_segments rs, edge_span const *__restrict__ spans,
-	u64 *__restrict__ eff, u64 eff_words_per_row, u32 n_rows)
+	u64 *__restrict__ eff, u64 eff_words_per_row, u32 n_rows, u32 const *__restrict__ needs_serial)
 {
 	int const lane = threadIdx.x & 63;
 	u32 const row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
 	if (row >= n_rows) return;   // whole wave exits together
+	if (needs_serial && 0 == needs_serial[row]) return;
 
 	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
 	u32 const n_words = (n_edges + 63) / 64;

@@ -84,7 +84,7 @@ struct v2m_ctx {
 	u32 n_tiles{};
 	std::vector<u32> h_csum;            // alt_edge_count_csum narrowed, [N + 1]
 	std::vector<u32> h_tgt_prefix_max;  // [E + 1]: max target over edges < e (cut validation)
-	dev_buf d_ref, d_ref_pos, d_aln_pos, d_spans, d_patches, d_labels, d_template;
+	dev_buf d_ref, d_ref_pos, d_aln_pos, d_spans, d_patches, d_labels, d_template, d_overlappable;
 	dev_buf d_tile_edge_begin, d_cross_offsets, d_cross_edges;
 
 	// paths_by_chrom_copy_and_edge
@@ -93,7 +93,7 @@ struct v2m_ctx {
 	u64 path_rows{}, path_cols{};
 
 	// per-call scratch
-	dev_buf d_eff, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths;
+	dev_buf d_eff, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial;
 	dev_buf ring[2];
 	pinned_buf host_ring[2];
 	hipEvent_t ev_compute[2]{}, ev_copy[2]{};
@@ -258,12 +258,24 @@ int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin,
 		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		V2M_HIP_TRY(ctx, ctx->d_eff.ensure(n_rows * eff_words * sizeof(u64)));
 
+		V2M_HIP_TRY(ctx, ctx->d_needs_serial.ensure(n_rows * sizeof(u32)));
+		V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_needs_serial.p, 0, n_rows * sizeof(u32), ctx->stream));
+
 		v2m::row_segments rs{ctx->d_seg_offsets.as<u32>(), ctx->d_seg_edge_begin.as<u32>(), ctx->d_seg_copy.as<u32>()};
+		u64 const n_threads(n_rows * eff_words);
+		char const *const back_env(std::getenv("V2M_MAX_BACK_WORDS"));   // test knob: 0 forces the serial kernel for every cross-word restart
+		u32 const max_back_words((back_env && *back_env) ? u32(std::strtoul(back_env, nullptr, 10)) : v2m::kMaxBackWords);
+		if ((n_threads + 255) / 256 > 0x7FFFFFFFull)
+			return fail(ctx, V2M_ERR_UNSUPPORTED, "resolve grid too large; use smaller batches");
 		{
 			timed_launch tl(ctx, V2M_KERNEL_RESOLVE);
-			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
+			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_threads + 255) / 256)), dim3(256), 0, ctx->stream,
+				ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
+				ctx->d_eff.as<u64>(), u32(eff_words), u32(n_rows), ctx->d_needs_serial.as<u32>(), max_back_words);
+			// rows whose restart point is too far back for the per-word kernel (chromosome-scale deletions)
+			hipLaunchKernelGGL(v2m::resolve_rows_serial_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
 				ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(),
-				ctx->d_eff.as<u64>(), eff_words, u32(n_rows));
+				ctx->d_eff.as<u64>(), eff_words, u32(n_rows), ctx->d_needs_serial.as<u32>());
 		}
 		V2M_HIP_TRY(ctx, hipGetLastError());
 	}
@@ -463,6 +475,7 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 	std::vector<v2m::edge_span> spans(E);
 	std::vector<v2m::edge_patch> patches(E);
 	std::vector<u32> tgt_prefix_max(E + 1, 0);
+	std::vector<u64> overlappable((E + 63) / 64, 0);   // edge e can be skipped by some row iff src[e] < max tgt[0..e)
 	u64 label_total(0);
 	if (E) {
 		label_total = g->alt_edge_label_offsets[E];
@@ -481,6 +494,7 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 			spans[e] = {u32(n), u32(tgt)};
 			patches[e] = {aln_pos[n], aln_pos[tgt], u32(lo), u32(hi - lo)};
 			tgt_prefix_max[e + 1] = std::max(tgt_prefix_max[e], u32(tgt));
+			if (n < tgt_prefix_max[e]) overlappable[e >> 6] |= u64(1) << (e & 63);
 		}
 	}
 
@@ -522,6 +536,7 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 	if (int const rc = upload_vec(ctx, ctx->d_aln_pos, aln_pos)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_spans, spans)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_patches, patches)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_overlappable, overlappable)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_tile_edge_begin, tile_edge_begin)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_cross_offsets, cross_offsets)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_cross_edges, cross_edges)) return rc;
