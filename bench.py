@@ -37,15 +37,6 @@ def log(*a):
 	print(*a, file=sys.stderr, flush=True)
 
 
-def shard_copies(n_copies, world, rank):
-	"""Contiguous blocks of whole 64-copy words (so bit-matrix words split cleanly)."""
-	n_words = (n_copies + 63) // 64
-	base, extra = divmod(n_words, world)
-	w0 = rank * base + min(rank, extra)
-	w1 = w0 + base + (1 if rank < extra else 0)
-	return 64 * w0, min(n_copies, 64 * w1), 64 * (w1 - w0)   # first copy, end copy, padded local copy count
-
-
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
@@ -71,6 +62,7 @@ def main():
 	import vcf2multialign_amd as v2m
 	from vcf2multialign_amd import _native as N
 	from vcf2multialign_amd import synth
+	from vcf2multialign_amd.sharding import max_over_ranks, shard_copies
 
 	torch.cuda.set_device(local_rank)
 	dev = torch.device("cuda", local_rank)
@@ -137,9 +129,7 @@ def main():
 	elapsed = time.perf_counter() - t_begin
 	if world > 1:
 		dist.barrier()
-		t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-		dist.all_reduce(t, op=dist.ReduceOp.MAX)
-		elapsed = float(t.item())
+		elapsed = max_over_ranks(elapsed, dist, dev)
 	ctx.profile_enable(False)
 
 	# ---- roofline of the dominant kernel, from HIP events on the kernel's own stream ---------------

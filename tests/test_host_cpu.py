@@ -1,0 +1,147 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/v2m_hip.h declares, fails
+loudly without a device, and the host-side logic (row batches, sharding, checksums) is right."""
+
+import os
+import re
+import socket
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+@pytest.fixture(scope="module")
+def v2m():
+	from vcf2multialign_amd import build
+	build.build_native()
+	import vcf2multialign_amd as v
+	return v
+
+
+def _declared_functions():
+	with open(os.path.join(ROOT, "include", "v2m_hip.h")) as f:
+		text = f.read()
+	text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+	names = set(re.findall(r"\b(v2m_[a-z0-9_]+)\s*\(", text))
+	names -= {"v2m_sink_fn"}
+	return sorted(names)
+
+
+def test_library_exports_every_declared_symbol(v2m):
+	from vcf2multialign_amd import _native
+	lib = v2m.load_library()
+	declared = _declared_functions()
+	assert len(declared) >= 18
+	for name in declared:
+		assert hasattr(lib, name), name + " is declared in include/v2m_hip.h but not exported"
+	assert set(declared) == set(_native.SIGNATURES), "ctypes signatures and header disagree"
+	assert lib.v2m_abi_version() == 1
+
+
+def test_no_device_means_loud_failure(v2m):
+	import torch
+	if torch.cuda.is_available():
+		pytest.skip("a GPU is present")
+	with pytest.raises(v2m.V2MError) as e:
+		v2m.Context(0)
+	assert e.value.code == 4 and "no CPU fallback" in str(e.value)
+
+
+def test_product_never_touches_the_oracle():
+	"""The product tree must not import, link or mention the oracle (it is test infrastructure)."""
+	pkg = os.path.join(ROOT, "vcf2multialign_amd")
+	for dirpath, _, files in os.walk(pkg):
+		for fn in files:
+			if fn.endswith((".py", ".hip", ".cc", ".hh", ".hpp", ".h")):
+				with open(os.path.join(dirpath, fn), errors="replace") as f:
+					text = f.read()
+				assert "v2mo_" not in text and "libv2m_oracle" not in text and "import oracle" not in text, os.path.join(dirpath, fn)
+
+
+def test_row_batch_layout(v2m):
+	rb = v2m.RowBatch([v2m.PLOIDY_MAX, 3, [(0, 5), (7, v2m.PLOIDY_MAX), (9, 2)], 1])
+	assert rb.n_rows == 4
+	assert rb.copy_index.tolist() == [v2m.PLOIDY_MAX, 3, v2m.PLOIDY_MAX, 1]
+	assert rb.cut_offsets.tolist() == [0, 0, 0, 3, 3]
+	assert rb.cut_nodes.tolist() == [0, 7, 9] and rb.cut_copies.tolist() == [5, v2m.PLOIDY_MAX, 2]
+	assert v2m.RowBatch([0, 1]).cut_offsets is None
+	assert v2m.RowBatch.haplotypes(range(3), include_reference=True).copy_index.tolist() == [v2m.PLOIDY_MAX, 0, 1, 2]
+
+
+def test_checksum_reference_values(v2m):
+	# the checksum definition in include/v2m_hip.h, spelled out independently for two tiny rows
+	def mix(z):
+		z &= 2 ** 64 - 1
+		z ^= z >> 30; z = z * 0xBF58476D1CE4E5B9 % 2 ** 64
+		z ^= z >> 27; z = z * 0x94D049BB133111EB % 2 ** 64
+		z ^= z >> 31
+		return z
+	def ref(b):
+		acc = mix(len(b))
+		padded = b + b"\0" * ((-len(b)) % 8)
+		for i in range(0, len(padded), 8):
+			acc += mix(((i // 8 + 1) * 0x9E3779B97F4A7C15) % 2 ** 64 ^ int.from_bytes(padded[i:i + 8], "little"))
+		return acc % 2 ** 64
+	rows = [b"ACGT-ACGTACG", b"", b"A" * 8, b"ACGTACGTT"]
+	assert v2m.checksum_rows_host(rows).tolist() == [ref(r) for r in rows]
+
+
+@pytest.mark.parametrize("n_copies,world", [(5008, 1), (5008, 2), (5008, 4), (5008, 8), (2000, 8), (20000, 8), (100, 8), (64, 3), (1, 2)])
+def test_sharding_covers_all_rows_in_order(n_copies, world):
+	from vcf2multialign_amd.sharding import PLOIDY_MAX, local_rows, shard_copies
+	seen = []
+	for r in range(world):
+		c0, c1, hp = shard_copies(n_copies, world, r)
+		assert c0 % 64 == 0 or c0 == n_copies
+		assert hp % 64 == 0 and c1 - c0 <= hp
+		rows = local_rows(n_copies, world, r)
+		for gi, lc in rows:
+			assert lc == PLOIDY_MAX or 0 <= lc < hp
+		seen.extend(gi for gi, _ in rows)
+	assert seen == list(range(n_copies + 1))
+
+
+def _free_port():
+	s = socket.socket()
+	s.bind(("127.0.0.1", 0))
+	p = s.getsockname()[1]
+	s.close()
+	return p
+
+
+def _gloo_worker(rank, world, port, n_copies, q):
+	import torch.distributed as dist
+	from vcf2multialign_amd.sharding import local_rows, max_over_ranks
+	os.environ["MASTER_ADDR"] = "127.0.0.1"
+	os.environ["MASTER_PORT"] = str(port)
+	dist.init_process_group("gloo", rank=rank, world_size=world)
+	rows = local_rows(n_copies, world, rank)
+	dist.barrier()
+	t = max_over_ranks(1.0 + rank, dist)     # the bench's max-over-ranks timing
+	gathered = [None] * world
+	dist.all_gather_object(gathered, [gi for gi, _ in rows])   # test-only: the data path itself has no collective
+	dist.barrier()
+	dist.destroy_process_group()
+	q.put((rank, t, gathered))
+
+
+def test_two_rank_gloo_partition():
+	"""world_size-2 rehearsal of the N>1 path on CPU: both ranks derive disjoint, ordered shards and agree on the
+	max-over-ranks time."""
+	import torch.multiprocessing as mp
+	ctx = mp.get_context("spawn")
+	q = ctx.Queue()
+	port = _free_port()
+	procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, 300, q)) for r in range(2)]
+	for p in procs:
+		p.start()
+	results = [q.get(timeout=120) for _ in procs]
+	for p in procs:
+		p.join(timeout=60)
+		assert p.exitcode == 0
+	for rank, t, gathered in results:
+		assert t == 2.0
+		assert gathered[0] + gathered[1] == list(range(301))
+		assert gathered[0][-1] == 192 and gathered[1][0] == 193   # rank 0: REF + copies 0..191 (3 words), rank 1: copies 192..299
