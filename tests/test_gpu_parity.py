@@ -114,6 +114,10 @@ def test_haplotype_a2m_fixtures(v2m, ctx, stem, fasta):   # haplotype_output.cc:
 	v2m.HaplotypeOutput(ctx, chromosome_id="chrT", should_output_reference=False).output_a2m(vg, out)
 	with open(os.path.join(HERE, "golden", "derived", stem + ".haplotypes.chr.noref.a2m"), "rb") as f:
 		assert out.getvalue() == f.read()
+	out = io.BytesIO()
+	v2m.HaplotypeOutput(ctx, should_output_unaligned=True).output_a2m(vg, out)   # --unaligned (sequence_writer.cc:80)
+	with open(os.path.join(HERE, "golden", "derived", stem + ".haplotypes.unaligned.fa"), "rb") as f:
+		assert out.getvalue() == f.read()
 
 
 # ---- synthetic graphs ----------------------------------------------------------------------
@@ -141,6 +145,11 @@ def test_synthetic_haplotypes(v2m, ctx, tmp_path, seed, ref_len, n_var, n_sample
 	for i, (a, b) in enumerate(zip(got, exp)):
 		assert len(a) == g.aligned_length
 		assert a == b, "row %d differs" % i
+	got = ctx.splice_rows(rows, unaligned=True)
+	exp = _oracle_rows(g, rows, unaligned=True)
+	assert got[0] == g.ref
+	for i, (a, b) in enumerate(zip(got, exp)):
+		assert a == b, "unaligned row %d differs (lengths %d / %d)" % (i, len(a), len(b))
 
 
 @pytest.mark.parametrize("density,max_back", [(0.02, None), (0.3, None), (0.9, None), (0.3, "0"), (0.9, "1")])
@@ -183,6 +192,9 @@ def test_founder_rows_synthetic(v2m, ctx, tmp_path):
 	got = ctx.splice_rows(rows)
 	for i, (a, b) in enumerate(zip(got, _oracle_rows(g, rows))):
 		assert a == b, "row %d differs" % i
+	got = ctx.splice_rows(rows, unaligned=True)
+	for i, (a, b) in enumerate(zip(got, _oracle_rows(g, rows, unaligned=True))):
+		assert a == b, "unaligned row %d differs" % i
 
 
 def test_device_rows_checksums(v2m, ctx, tmp_path):
@@ -204,6 +216,16 @@ def test_device_rows_checksums(v2m, ctx, tmp_path):
 	host = buf.cpu().numpy().reshape(len(rows), pitch)
 	for i, b in enumerate(exp):
 		assert host[i, :len(b)].tobytes() == b
+	# unaligned, device-resident: ragged row lengths
+	exp = _oracle_rows(g, rows, unaligned=True)
+	upitch = (ctx.max_unaligned_length + 255) // 256 * 256
+	assert upitch >= max(len(b) for b in exp)
+	buf = torch.zeros(len(rows) * upitch, dtype=torch.uint8, device="cuda")
+	torch.cuda.synchronize()
+	lengths = ctx.splice_rows_device(rows, buf.data_ptr(), upitch, unaligned=True, want_lengths=True)
+	assert lengths.tolist() == [len(b) for b in exp]
+	sums = ctx.checksum_rows_device(buf.data_ptr(), upitch, len(rows), lengths=lengths)
+	assert np.array_equal(sums, v2m.checksum_rows_host(exp))
 
 
 def test_sink_slices(v2m, ctx, tmp_path, monkeypatch):
@@ -214,6 +236,22 @@ def test_sink_slices(v2m, ctx, tmp_path, monkeypatch):
 	got = ctx.splice_rows(rows)
 	for i, (a, b) in enumerate(zip(got, _oracle_rows(g, rows))):
 		assert a == b, "row %d differs" % i
+	got = ctx.splice_rows(rows, unaligned=True)
+	for i, (a, b) in enumerate(zip(got, _oracle_rows(g, rows, unaligned=True))):
+		assert a == b, "unaligned row %d differs" % i
+
+
+def test_unaligned_keeps_dashes_and_case_of_the_reference(v2m, ctx, tmp_path):
+	"""Only the padding is dropped in unaligned mode: a '-' or lowercase base that is IN the reference is data."""
+	ref = b"ACG-TNNacgtAC--GTACGTTTGACA"
+	recs = [(4, b"T", [b"TGG"], np.array([[1, 0]])), (8, b"cg", [b"c"], np.array([[0, 1]])), (15, b"G", [b"C", b"GAAAA"], np.array([[2, 1]]))]
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, 1)
+	g = oracle.build_variant_graph(fa, vcf, "1")
+	_upload(v2m, ctx, g)
+	rows = [v2m.PLOIDY_MAX, 0, 1]
+	assert ctx.splice_rows(rows, unaligned=True) == _oracle_rows(g, rows, unaligned=True)
+	assert ctx.splice_rows(rows) == _oracle_rows(g, rows)
+	assert ctx.splice_rows([v2m.PLOIDY_MAX], unaligned=True) == [ref]
 
 
 # ---- edge cases and error behaviour --------------------------------------------------------
@@ -226,6 +264,7 @@ def test_no_variants_and_empty_batches(v2m, ctx, tmp_path):
 	assert g.edge_count == 0 and g.node_count == 3 and g.total_chromosome_copies == 4
 	_upload(v2m, ctx, g)
 	assert ctx.splice_rows([v2m.PLOIDY_MAX, 0, 3]) == [ref, ref, ref]
+	assert ctx.splice_rows([v2m.PLOIDY_MAX, 0, 3], unaligned=True) == [ref, ref, ref]
 	assert ctx.splice_rows([]) == []
 
 

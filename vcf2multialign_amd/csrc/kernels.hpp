@@ -525,6 +525,191 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_aligned_kernel(
 
 
 // ---------------------------------------------------------------------------------------------
+// Unaligned rows (should_output_unaligned, sequence_writer.cc:80: the '-' padding is not written).
+//
+// An unaligned row is the aligned row with the padding removed, so the same tiles are built in LDS
+// -- from a second template whose padding byte is 0 instead of '-' (a byte neither FASTA text nor
+// VCF alleles can contain), patched with 0 as padding -- and then compacted.  Where a tile's bytes
+// land in the row needs the number of non-padding bytes of all tiles before it:
+//   pass 1  splice_unaligned_kernel<true>   counts the non-padding bytes of every (row, tile)
+//           scan_tile_counts_kernel         exclusive prefix sum per row -> tile offsets, row lengths
+//   pass 2  splice_unaligned_kernel<false>  rebuilds each tile, compacts it in LDS at the destination's
+//                                           16-B phase and streams it out (16-B stores inside, byte
+//                                           stores on the ragged first/last chunk, which neighbours share).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 zero_bytes_mask(u32 x)
+{
+	// 0x80 in every byte of x that is zero (exact, no borrow artefacts)
+	return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
+}
+
+template <bool kCountOnly>
+__global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
+	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
+	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
+	u32 *__restrict__ tile_counts /* [n_rows][n_tiles]: counts (pass 1) / exclusive offsets (pass 2) */, u32 n_tiles,
+	char *__restrict__ out, u64 row_pitch, u32 n_rows, u32 rows_per_group, u32 n_groups)
+{
+	__shared__ vec4u lds[kTileChunks];
+	__shared__ vec4u comp[kTileChunks + 1];
+	__shared__ u32 long_queue[kLongQueue];
+	__shared__ u32 long_count;
+	__shared__ u32 wave_sums[kSpliceThreads / 64];
+
+	int const t = threadIdx.x;
+	int const lane = t & 63, wave = t >> 6;
+	u32 const tile = blockIdx.x / n_groups;
+	u32 const group = blockIdx.x % n_groups;
+	u32 const row_begin = group * rows_per_group;
+	u32 const row_end = (row_begin + rows_per_group < n_rows) ? row_begin + rows_per_group : n_rows;
+	u32 const tile_base = tile * (u32) kTileBytes;
+
+	vec4u pristine[kChunksPerThread];
+#pragma unroll
+	for (int k = 0; k < kChunksPerThread; ++k)
+		pristine[k] = tmpl0[(u64) tile * kTileChunks + t + kSpliceThreads * k];
+
+	u32 const cross_begin = tt.cross_offsets[tile], n_cross = tt.cross_offsets[tile + 1] - cross_begin;
+	u32 const range_begin = tt.edge_begin[tile], n_range = tt.edge_begin[tile + 1] - range_begin;
+	u32 const n_cand = n_cross + n_range;
+	if (t == 0) long_count = 0;
+
+	for (u32 row = row_begin; row < row_end; ++row) {
+		__syncthreads();   // the previous row's readers of lds/comp are done
+#pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k)
+			lds[t + kSpliceThreads * k] = pristine[k];
+		__syncthreads();
+
+		u64 const *const eff_row = eff + (u64) row * eff_words_per_row;
+		for (u32 i = t; i < n_cand; i += kSpliceThreads) {
+			u32 const e = (i < n_cross) ? tt.cross_edges[cross_begin + i] : range_begin + (i - n_cross);
+			if ((eff_row[e >> 6] >> (e & 63)) & 1) {
+				edge_patch const p = patches[e];
+				u32 const from = p.aln_begin > tile_base ? p.aln_begin : tile_base;
+				u32 const to = p.aln_end < tile_base + kTileBytes ? p.aln_end : tile_base + kTileBytes;
+				if (to - from > kLongPatch) {
+					u32 const slot = atomicAdd(&long_count, 1u);
+					if (slot < kLongQueue) long_queue[slot] = e;
+					else fill_patch_bytes((unsigned char *) lds, tile_base, p, labels, from, to, 0, 1, 0);
+				} else {
+					fill_patch_bytes((unsigned char *) lds, tile_base, p, labels, from, to, 0, 1, 0);
+				}
+			}
+		}
+		__syncthreads();
+		u32 const n_long = long_count < kLongQueue ? long_count : kLongQueue;
+		if (n_long) {
+			for (u32 q = wave; q < n_long; q += kSpliceThreads >> 6) {
+				edge_patch const p = patches[long_queue[q]];
+				u32 const from = p.aln_begin > tile_base ? p.aln_begin : tile_base;
+				u32 const to = p.aln_end < tile_base + kTileBytes ? p.aln_end : tile_base + kTileBytes;
+				fill_patch_bytes((unsigned char *) lds, tile_base, p, labels, from, to, lane, 64, 0);
+			}
+			__syncthreads();
+			if (t == 0) long_count = 0;
+		}
+
+		// each thread owns 64 contiguous tile bytes: count what survives
+		vec4u v[4];
+		u32 mine = 0;
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			v[k] = lds[4 * t + k];
+#pragma unroll
+			for (int d = 0; d < 4; ++d)
+				mine += 4 - __builtin_popcount(zero_bytes_mask(v[k][d]));
+		}
+		// block-wide exclusive scan of `mine`
+		u32 incl = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			u32 const o = __shfl_up(incl, d, kWave);
+			if (lane >= d) incl += o;
+		}
+		if (lane == 63) wave_sums[wave] = incl;
+		__syncthreads();
+		u32 before = 0, total = 0;
+#pragma unroll
+		for (int wv = 0; wv < kSpliceThreads / 64; ++wv) {
+			u32 const ws = wave_sums[wv];
+			if (wv < wave) before += ws;
+			total += ws;
+		}
+		u32 *const slot = tile_counts + (u64) row * n_tiles + tile;
+		if (kCountOnly) {
+			if (t == 0) *slot = total;
+			continue;
+		}
+
+		u32 const row_off = *slot;             // where this tile's bytes start in the unaligned row
+		u32 const phase = row_off & 15;
+		unsigned char *const c8 = (unsigned char *) comp;
+		u32 pos = phase + before + (incl - mine);
+#pragma unroll
+		for (int k = 0; k < 4; ++k)
+#pragma unroll
+			for (int d = 0; d < 4; ++d) {
+				u32 const x = v[k][d];
+#pragma unroll
+				for (int b = 0; b < 4; ++b) {
+					unsigned char const ch = (unsigned char) (x >> (8 * b));
+					if (ch) c8[pos++] = ch;
+				}
+			}
+		__syncthreads();
+
+		char *const dst = out + (u64) row * row_pitch + (row_off - phase);   // 16-B aligned
+		u32 const end = phase + total;
+		for (u32 c = t; c * 16 < end; c += kSpliceThreads) {
+			u32 const lo = c * 16, hi = lo + 16;
+			if (lo >= phase && hi <= end) {
+				*(vec4u *) (dst + lo) = comp[c];
+			} else {
+				for (u32 p = (lo > phase ? lo : phase); p < (hi < end ? hi : end); ++p)
+					dst[p] = (char) c8[p];
+			}
+		}
+	}
+}
+
+// Exclusive prefix sum of the per-tile byte counts of each row (in place) and the row lengths.
+__global__ __launch_bounds__(256) void scan_tile_counts_kernel(u32 *__restrict__ tile_counts, u32 n_tiles, u64 *__restrict__ row_lengths)
+{
+	__shared__ u32 wave_sums[4];
+	__shared__ u32 carry_s;
+	u32 *const row = tile_counts + (u64) blockIdx.x * n_tiles;
+	int const t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	if (t == 0) carry_s = 0;
+	__syncthreads();
+	for (u32 base = 0; base < n_tiles; base += 256) {
+		u32 const i = base + t;
+		u32 const mine = i < n_tiles ? row[i] : 0;
+		u32 incl = mine;
+#pragma unroll
+		for (int d = 1; d < 64; d <<= 1) {
+			u32 const o = __shfl_up(incl, d, kWave);
+			if (lane >= d) incl += o;
+		}
+		if (lane == 63) wave_sums[wave] = incl;
+		__syncthreads();
+		u32 before = carry_s, total = 0;
+#pragma unroll
+		for (int wv = 0; wv < 4; ++wv) {
+			u32 const ws = wave_sums[wv];
+			if (wv < wave) before += ws;
+			total += ws;
+		}
+		if (i < n_tiles) row[i] = before + incl - mine;
+		__syncthreads();
+		if (t == 0) carry_s += total;
+		__syncthreads();
+	}
+	if (t == 0) row_lengths[blockIdx.x] = carry_s;
+}
+
+
+// ---------------------------------------------------------------------------------------------
 // Row checksums (verification helper): sum over 8-byte little-endian words w (zero padded past
 // the row's length) of mix64((w_index + 1) * GOLDEN ^ word), plus mix64(length).
 // ---------------------------------------------------------------------------------------------

@@ -85,6 +85,8 @@ struct v2m_ctx {
 	std::vector<u32> h_csum;            // alt_edge_count_csum narrowed, [N + 1]
 	std::vector<u32> h_tgt_prefix_max;  // [E + 1]: max target over edges < e (cut validation)
 	dev_buf d_ref, d_ref_pos, d_aln_pos, d_spans, d_patches, d_labels, d_template, d_overlappable;
+	dev_buf d_template0;   // the REF row with 0 as padding byte (unaligned mode), built on first use
+	bool has_template0{};
 	dev_buf d_tile_edge_begin, d_cross_offsets, d_cross_edges;
 
 	// paths_by_chrom_copy_and_edge
@@ -93,7 +95,7 @@ struct v2m_ctx {
 	u64 path_rows{}, path_cols{};
 
 	// per-call scratch
-	dev_buf d_eff, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial;
+	dev_buf d_eff, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial, d_tile_counts, d_row_lengths;
 	dev_buf ring[2];
 	pinned_buf host_ring[2];
 	hipEvent_t ev_compute[2]{}, ev_copy[2]{};
@@ -241,62 +243,128 @@ u32 rows_per_group_for(u64 n_rows)
 }
 
 
+// Effective-edge bits of rows [row_begin, row_end) of the batch into ctx->d_eff.
+int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row_end)
+{
+	u64 const n_rows(row_end - row_begin);
+	u64 const eff_words((ctx->n_edges + 63) / 64);
+	if (0 == ctx->n_edges) return V2M_OK;
+
+	prepared_rows pr;
+	if (int const rc = prepare_rows(ctx, rows, row_begin, row_end, pr)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_seg_offsets, pr.seg_offsets)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_seg_edge_begin, pr.seg_edge_begin)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_seg_copy, pr.seg_copy)) return rc;
+	// the vectors die at the end of this scope; pageable-memory async copies have been staged by then
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	V2M_HIP_TRY(ctx, ctx->d_eff.ensure(n_rows * eff_words * sizeof(u64)));
+	V2M_HIP_TRY(ctx, ctx->d_needs_serial.ensure(n_rows * sizeof(u32)));
+	V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_needs_serial.p, 0, n_rows * sizeof(u32), ctx->stream));
+
+	v2m::row_segments rs{ctx->d_seg_offsets.as<u32>(), ctx->d_seg_edge_begin.as<u32>(), ctx->d_seg_copy.as<u32>()};
+	u64 const n_threads(n_rows * eff_words);
+	char const *const back_env(std::getenv("V2M_MAX_BACK_WORDS"));   // test knob: 0 forces the serial kernel for every cross-word restart
+	u32 const max_back_words((back_env && *back_env) ? u32(std::strtoul(back_env, nullptr, 10)) : v2m::kMaxBackWords);
+	if ((n_threads + 255) / 256 > 0x7FFFFFFFull)
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "resolve grid too large; use smaller batches");
+	{
+		timed_launch tl(ctx, V2M_KERNEL_RESOLVE);
+		hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_threads + 255) / 256)), dim3(256), 0, ctx->stream,
+			ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
+			ctx->d_eff.as<u64>(), u32(eff_words), u32(n_rows), ctx->d_needs_serial.as<u32>(), max_back_words);
+		// rows whose restart point is too far back for the per-word kernel (chromosome-scale deletions)
+		hipLaunchKernelGGL(v2m::resolve_rows_serial_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
+			ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(),
+			ctx->d_eff.as<u64>(), eff_words, u32(n_rows), ctx->d_needs_serial.as<u32>());
+	}
+	V2M_HIP_TRY(ctx, hipGetLastError());
+	return V2M_OK;
+}
+
+
+struct splice_grid {
+	u32 rows_per_group, n_groups;
+	u64 n_blocks;
+};
+
+int make_grid(v2m_ctx *ctx, u64 n_rows, splice_grid &g)
+{
+	g.rows_per_group = rows_per_group_for(n_rows);
+	g.n_groups = u32((n_rows + g.rows_per_group - 1) / g.rows_per_group);
+	g.n_blocks = u64(ctx->n_tiles) * g.n_groups;
+	if (g.n_blocks > 0x7FFFFFFFull)
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "splice grid too large (%llu workgroups); use smaller batches", (unsigned long long) g.n_blocks);
+	return V2M_OK;
+}
+
+
 // Resolve + aligned splice of rows [row_begin, row_end) of the batch into d_out.
 int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row_end, char *d_out, u64 row_pitch)
 {
 	u64 const n_rows(row_end - row_begin);
 	if (0 == n_rows || 0 == ctx->aligned_len) return V2M_OK;
+	if (int const rc = resolve_slice(ctx, rows, row_begin, row_end)) return rc;
 
 	u64 const eff_words((ctx->n_edges + 63) / 64);
-	if (ctx->n_edges) {
-		prepared_rows pr;
-		if (int const rc = prepare_rows(ctx, rows, row_begin, row_end, pr)) return rc;
-		if (int const rc = upload_vec(ctx, ctx->d_seg_offsets, pr.seg_offsets)) return rc;
-		if (int const rc = upload_vec(ctx, ctx->d_seg_edge_begin, pr.seg_edge_begin)) return rc;
-		if (int const rc = upload_vec(ctx, ctx->d_seg_copy, pr.seg_copy)) return rc;
-		// the vectors die at the end of this scope; pageable-memory async copies have been staged by then
-		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		V2M_HIP_TRY(ctx, ctx->d_eff.ensure(n_rows * eff_words * sizeof(u64)));
-
-		V2M_HIP_TRY(ctx, ctx->d_needs_serial.ensure(n_rows * sizeof(u32)));
-		V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_needs_serial.p, 0, n_rows * sizeof(u32), ctx->stream));
-
-		v2m::row_segments rs{ctx->d_seg_offsets.as<u32>(), ctx->d_seg_edge_begin.as<u32>(), ctx->d_seg_copy.as<u32>()};
-		u64 const n_threads(n_rows * eff_words);
-		char const *const back_env(std::getenv("V2M_MAX_BACK_WORDS"));   // test knob: 0 forces the serial kernel for every cross-word restart
-		u32 const max_back_words((back_env && *back_env) ? u32(std::strtoul(back_env, nullptr, 10)) : v2m::kMaxBackWords);
-		if ((n_threads + 255) / 256 > 0x7FFFFFFFull)
-			return fail(ctx, V2M_ERR_UNSUPPORTED, "resolve grid too large; use smaller batches");
-		{
-			timed_launch tl(ctx, V2M_KERNEL_RESOLVE);
-			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_threads + 255) / 256)), dim3(256), 0, ctx->stream,
-				ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
-				ctx->d_eff.as<u64>(), u32(eff_words), u32(n_rows), ctx->d_needs_serial.as<u32>(), max_back_words);
-			// rows whose restart point is too far back for the per-word kernel (chromosome-scale deletions)
-			hipLaunchKernelGGL(v2m::resolve_rows_serial_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
-				ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(),
-				ctx->d_eff.as<u64>(), eff_words, u32(n_rows), ctx->d_needs_serial.as<u32>());
-		}
-		V2M_HIP_TRY(ctx, hipGetLastError());
-	}
-
-	u32 const rpg(rows_per_group_for(n_rows));
-	u32 const n_groups(u32((n_rows + rpg - 1) / rpg));
-	u64 const n_blocks(u64(ctx->n_tiles) * n_groups);
-	if (n_blocks > 0x7FFFFFFFull)
-		return fail(ctx, V2M_ERR_UNSUPPORTED, "splice grid too large (%llu workgroups); use smaller batches", (unsigned long long) n_blocks);
+	splice_grid g;
+	if (int const rc = make_grid(ctx, n_rows, g)) return rc;
 	v2m::tile_tables tt{ctx->d_tile_edge_begin.as<u32>(), ctx->d_cross_offsets.as<u32>(), ctx->d_cross_edges.as<u32>()};
 	u64 const store_limit((ctx->aligned_len + 15) & ~u64(15));
 	{
 		timed_launch tl(ctx, V2M_KERNEL_SPLICE_ALIGNED);
 		if (nontemporal_stores())
-			hipLaunchKernelGGL(v2m::splice_aligned_kernel<true>, dim3(unsigned(n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
+			hipLaunchKernelGGL(v2m::splice_aligned_kernel<true>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 				ctx->d_template.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
-				d_out, row_pitch, u32(n_rows), rpg, n_groups, store_limit, '-');
+				d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, store_limit, '-');
 		else
-			hipLaunchKernelGGL(v2m::splice_aligned_kernel<false>, dim3(unsigned(n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
+			hipLaunchKernelGGL(v2m::splice_aligned_kernel<false>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 				ctx->d_template.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
-				d_out, row_pitch, u32(n_rows), rpg, n_groups, store_limit, '-');
+				d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, store_limit, '-');
+	}
+	V2M_HIP_TRY(ctx, hipGetLastError());
+	return V2M_OK;
+}
+
+
+// Resolve + unaligned splice (count, scan, compact) of rows [row_begin, row_end) into d_out;
+// leaves the row lengths in ctx->d_row_lengths.
+int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row_end, char *d_out, u64 row_pitch)
+{
+	u64 const n_rows(row_end - row_begin);
+	if (0 == n_rows) return V2M_OK;
+	V2M_HIP_TRY(ctx, ctx->d_row_lengths.ensure(n_rows * sizeof(u64)));
+	if (0 == ctx->aligned_len) {
+		V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_row_lengths.p, 0, n_rows * sizeof(u64), ctx->stream));
+		return V2M_OK;
+	}
+	u64 const n_chunks(u64(ctx->n_tiles) * v2m::kTileChunks);
+	if (!ctx->has_template0) {
+		V2M_HIP_TRY(ctx, ctx->d_template0.ensure(n_chunks * 16));
+		{
+			timed_launch tl(ctx, V2M_KERNEL_TEMPLATE);
+			hipLaunchKernelGGL(v2m::expand_reference_row_kernel, dim3(unsigned((n_chunks + 255) / 256)), dim3(256), 0, ctx->stream,
+				ctx->d_ref.as<char>(), ctx->d_ref_pos.as<u32>(), ctx->d_aln_pos.as<u32>(), u32(ctx->n_nodes), u32(ctx->aligned_len), n_chunks, ctx->d_template0.as<uint4>(), char(0));
+		}
+		V2M_HIP_TRY(ctx, hipGetLastError());
+		ctx->has_template0 = true;
+	}
+	if (int const rc = resolve_slice(ctx, rows, row_begin, row_end)) return rc;
+
+	u64 const eff_words((ctx->n_edges + 63) / 64);
+	splice_grid g;
+	if (int const rc = make_grid(ctx, n_rows, g)) return rc;
+	V2M_HIP_TRY(ctx, ctx->d_tile_counts.ensure(n_rows * ctx->n_tiles * sizeof(u32)));
+	v2m::tile_tables tt{ctx->d_tile_edge_begin.as<u32>(), ctx->d_cross_offsets.as<u32>(), ctx->d_cross_edges.as<u32>()};
+	{
+		timed_launch tl(ctx, V2M_KERNEL_SPLICE_UNALIGNED);
+		hipLaunchKernelGGL(v2m::splice_unaligned_kernel<true>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
+			ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
+			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups);
+		hipLaunchKernelGGL(v2m::scan_tile_counts_kernel, dim3(unsigned(n_rows)), dim3(256), 0, ctx->stream,
+			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, ctx->d_row_lengths.as<u64>());
+		hipLaunchKernelGGL(v2m::splice_unaligned_kernel<false>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
+			ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
+			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups);
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
@@ -313,7 +381,6 @@ int check_batch(v2m_ctx *ctx, v2m_row_batch const *rows, u32 flags)
 	if (rows->cut_offsets && rows->cut_offsets[rows->n_rows] && (!rows->cut_nodes || !rows->cut_copies))
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut arrays are NULL");
 	if (rows->n_rows >= 0xFFFFFFFFull) return fail(ctx, V2M_ERR_UNSUPPORTED, "too many rows in one batch");
-	if (flags & V2M_SPLICE_UNALIGNED) return fail(ctx, V2M_ERR_UNSUPPORTED, "unaligned output is not implemented in this build yet");
 	return V2M_OK;
 }
 
@@ -528,6 +595,7 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 
 	// --- upload ------------------------------------------------------------------------------
 	ctx->has_graph = false;
+	ctx->has_template0 = false;
 	V2M_HIP_TRY(ctx, ctx->d_ref.ensure(std::max<u64>(ref_len, 16)));
 	if (ref_len) V2M_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_ref.p, ref_seq, ref_len, hipMemcpyHostToDevice, ctx->stream));
 	V2M_HIP_TRY(ctx, ctx->d_labels.ensure(std::max<u64>(label_total, 16)));
@@ -594,13 +662,23 @@ int v2m_splice_rows_device(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t fla
 {
 	if (int const rc = check_batch(ctx, rows, flags)) return rc;
 	if (0 == rows->n_rows) return V2M_OK;
+	bool const unaligned(flags & V2M_SPLICE_UNALIGNED);
 	if (!d_out || ((uintptr_t) d_out & 15)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "d_out must be a 16-byte aligned device pointer");
-	if (row_pitch % 16 || row_pitch < ((ctx->aligned_len + 15) & ~u64(15)))
-		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row_pitch must be a multiple of 16 and at least the aligned length rounded up to 16");
+	u64 const need(unaligned ? v2m_max_unaligned_length(ctx) : ctx->aligned_len);
+	if (row_pitch % 16 || row_pitch < ((need + 15) & ~u64(15)))
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row_pitch must be a multiple of 16 and at least %llu rounded up to 16", (unsigned long long) need);
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
-	if (int const rc = splice_aligned_slice(ctx, rows, 0, rows->n_rows, static_cast<char *>(d_out), row_pitch)) return rc;
-	if (row_lengths_out)
-		for (u64 r(0); r < rows->n_rows; ++r) row_lengths_out[r] = ctx->aligned_len;
+	if (!unaligned) {
+		if (int const rc = splice_aligned_slice(ctx, rows, 0, rows->n_rows, static_cast<char *>(d_out), row_pitch)) return rc;
+		if (row_lengths_out)
+			for (u64 r(0); r < rows->n_rows; ++r) row_lengths_out[r] = ctx->aligned_len;
+		return V2M_OK;
+	}
+	if (int const rc = splice_unaligned_slice(ctx, rows, 0, rows->n_rows, static_cast<char *>(d_out), row_pitch)) return rc;
+	if (row_lengths_out) {
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(row_lengths_out, ctx->d_row_lengths.p, rows->n_rows * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	}
 	return V2M_OK;
 }
 
@@ -610,6 +688,7 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 	if (!sink) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "sink is NULL");
 	if (0 == rows->n_rows) return V2M_OK;
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	bool const unaligned(flags & V2M_SPLICE_UNALIGNED);
 
 	u64 const L(ctx->aligned_len);
 	if (0 == L) {
@@ -620,15 +699,16 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 
 	// Slices of the batch alternate between two device buffers and two pinned host buffers:
 	// the D2H copy of slice s runs on copy_stream while the kernels of slice s+1 run on stream.
-	u64 const pitch(v2m_min_row_pitch(ctx));
+	u64 const pitch(unaligned ? ((v2m_max_unaligned_length(ctx) + 255) & ~u64(255)) : v2m_min_row_pitch(ctx));
 	char const *const slot_env(std::getenv("V2M_RING_SLOT_BYTES"));   // test knob: force small slices
 	u64 const slot_target((slot_env && *slot_env) ? std::strtoull(slot_env, nullptr, 10) : (u64(512) << 20));
 	u64 const rows_per_slice(std::max<u64>(1, std::min<u64>(rows->n_rows, slot_target / pitch)));
 	u64 const n_slices((rows->n_rows + rows_per_slice - 1) / rows_per_slice);
 	u64 const slot_bytes(rows_per_slice * pitch);
+	u64 const lengths_bytes(rows_per_slice * sizeof(u64));   // unaligned: row lengths ride at the end of the pinned slot
 	for (int i(0); i < (n_slices > 1 ? 2 : 1); ++i) {
 		V2M_HIP_TRY(ctx, ctx->ring[i].ensure(slot_bytes));
-		V2M_HIP_TRY(ctx, ctx->host_ring[i].ensure(slot_bytes));
+		V2M_HIP_TRY(ctx, ctx->host_ring[i].ensure(slot_bytes + lengths_bytes));
 	}
 
 	auto drain = [&](u64 s) -> int {
@@ -636,8 +716,9 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 		V2M_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_copy[b]));
 		u64 const r0(s * rows_per_slice), r1(std::min(rows->n_rows, r0 + rows_per_slice));
 		char const *base(static_cast<char const *>(ctx->host_ring[b].p));
+		u64 const *lengths(reinterpret_cast<u64 const *>(base + slot_bytes));
 		for (u64 r(r0); r < r1; ++r)
-			if (sink(user, r, base + (r - r0) * pitch, L)) return fail(ctx, V2M_ERR_SINK, "sink aborted at row %llu", (unsigned long long) r);
+			if (sink(user, r, base + (r - r0) * pitch, unaligned ? lengths[r - r0] : L)) return fail(ctx, V2M_ERR_SINK, "sink aborted at row %llu", (unsigned long long) r);
 		return V2M_OK;
 	};
 
@@ -646,9 +727,14 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 	for (u64 s(0); s < n_slices && V2M_OK == rc; ++s) {
 		int const b(int(s & 1));
 		u64 const r0(s * rows_per_slice), r1(std::min(rows->n_rows, r0 + rows_per_slice));
-		rc = splice_aligned_slice(ctx, rows, r0, r1, ctx->ring[b].as<char>(), pitch);
+		rc = unaligned
+			? splice_unaligned_slice(ctx, rows, r0, r1, ctx->ring[b].as<char>(), pitch)
+			: splice_aligned_slice(ctx, rows, r0, r1, ctx->ring[b].as<char>(), pitch);
 		if (V2M_OK != rc) break;
-		hipError_t st(hipEventRecord(ctx->ev_compute[b], ctx->stream));
+		hipError_t st(hipSuccess);
+		if (unaligned)   // d_row_lengths is reused by the next slice: take the copy on the compute stream
+			st = hipMemcpyAsync(static_cast<char *>(ctx->host_ring[b].p) + slot_bytes, ctx->d_row_lengths.p, (r1 - r0) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);
+		if (hipSuccess == st) st = hipEventRecord(ctx->ev_compute[b], ctx->stream);
 		if (hipSuccess == st) st = hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compute[b], 0);
 		if (hipSuccess == st) st = hipMemcpyAsync(ctx->host_ring[b].p, ctx->ring[b].p, (r1 - r0) * pitch, hipMemcpyDeviceToHost, ctx->copy_stream);
 		if (hipSuccess == st) st = hipEventRecord(ctx->ev_copy[b], ctx->copy_stream);
