@@ -486,10 +486,16 @@ bool parse_gt(std::string_view field, std::vector<std::uint32_t> &alleles)
 }
 
 
-// variant_graph.cc:108-454.  should_include() is always
-// true here (no sample filter), REF mismatches are fatal.
-bool build_variant_graph(std::string const &ref_seq, char const *vcf_path, char const *chr_id, graph &g, std::string &err)
+// variant_graph.cc:108-454.  REF mismatches are fatal.
+// should_include(sample, copy) (build_graph_delegate, variant_graph.hh:143) is restated as one optional
+// exclusion: every copy of `exclude_sample`, or only copy `exclude_copy` of it when that is >= 0.
+bool build_variant_graph(std::string const &ref_seq, char const *vcf_path, char const *chr_id, graph &g, std::string &err,
+	char const *exclude_sample = nullptr, int exclude_copy = -1)
 {
+	auto should_include([&](std::string const &sample, std::uint32_t copy) {
+		if (!exclude_sample || sample != exclude_sample) return true;
+		return exclude_copy >= 0 && int(copy) != exclude_copy;
+	});
 	std::ifstream is(vcf_path);
 	if (!is) { err = "unable to open VCF"; return false; }
 
@@ -553,16 +559,33 @@ bool build_variant_graph(std::string const &ref_seq, char const *vcf_path, char 
 			is_first = false;
 			g.ploidy_csum.assign(1 + g.sample_names.size(), 0);
 			std::uint32_t out_idx(0);
+			std::vector<std::uint32_t> removed_samples;   // no chromosome copy included
 			for (std::size_t s(0); s < vcf_sample_names.size(); ++s) {
 				if (!sample_gt(s, gt)) { err = "bad GT at line " + std::to_string(lineno); return false; }
 				std::uint32_t included_count(0);
 				for (std::uint32_t c(0); c < gt.size(); ++c) {
-					included_samples.push_back({std::uint32_t(s), out_idx, c, included_count});
-					++included_count;
+					if (should_include(vcf_sample_names[s], c)) {                   // :231
+						included_samples.push_back({std::uint32_t(s), out_idx, c, included_count});
+						++included_count;
+					}
 				}
-				// every copy is included, so no sample is ever removed (:250-273 is dead here)
-				g.ploidy_csum[1 + out_idx] = g.ploidy_csum[out_idx] + included_count;
-				++out_idx;
+				if (included_count) {                                               // :238-247
+					g.ploidy_csum[1 + out_idx] = g.ploidy_csum[out_idx] + included_count;
+					++out_idx;
+				} else {
+					removed_samples.push_back(std::uint32_t(s));
+				}
+			}
+			if (!removed_samples.empty()) {                                         // :250-273
+				g.ploidy_csum.resize(g.ploidy_csum.size() - removed_samples.size());
+				removed_samples.push_back(UINT32_MAX);
+				auto it(removed_samples.begin());
+				std::vector<std::string> kept;
+				for (std::size_t idx(0); idx < g.sample_names.size(); ++idx) {
+					if (idx < *it) kept.push_back(g.sample_names[idx]);
+					else ++it;
+				}
+				g.sample_names.swap(kept);
 			}
 			std::uint64_t const copies(g.ploidy_csum.back());
 			std::uint64_t const rows(64 * ((copies + 63) / 64));                    // :277
@@ -701,8 +724,23 @@ extern "C" {
 
 typedef struct v2mo_graph v2mo_graph;
 
+v2mo_graph *v2mo_build_variant_graph_ex(
+	char const *fasta_path, char const *seq_id, char const *vcf_path, char const *chr_id,
+	char const *exclude_sample, int exclude_copy,
+	char **ref_out, std::uint64_t *ref_len_out, char *err, std::size_t errlen
+);
+
 v2mo_graph *v2mo_build_variant_graph(
 	char const *fasta_path, char const *seq_id, char const *vcf_path, char const *chr_id,
+	char **ref_out, std::uint64_t *ref_len_out, char *err, std::size_t errlen
+)
+{
+	return v2mo_build_variant_graph_ex(fasta_path, seq_id, vcf_path, chr_id, nullptr, -1, ref_out, ref_len_out, err, errlen);
+}
+
+v2mo_graph *v2mo_build_variant_graph_ex(
+	char const *fasta_path, char const *seq_id, char const *vcf_path, char const *chr_id,
+	char const *exclude_sample, int exclude_copy,
 	char **ref_out, std::uint64_t *ref_len_out, char *err, std::size_t errlen
 )
 {
@@ -710,7 +748,7 @@ v2mo_graph *v2mo_build_variant_graph(
 	if (!read_single_fasta_sequence(fasta_path, ref, seq_id)) { set_err(err, errlen, "unable to read the reference sequence"); return nullptr; }
 	auto *g(new graph);
 	std::string msg;
-	if (!build_variant_graph(ref, vcf_path, chr_id, *g, msg)) { set_err(err, errlen, msg); delete g; return nullptr; }
+	if (!build_variant_graph(ref, vcf_path, chr_id, *g, msg, exclude_sample, exclude_copy)) { set_err(err, errlen, msg); delete g; return nullptr; }
 	if (ref_out) {
 		char *buf(static_cast<char *>(std::malloc(ref.size() + 1)));
 		std::memcpy(buf, ref.data(), ref.size());

@@ -37,6 +37,8 @@ def lib():
 	L = C.CDLL(build_oracle())
 	L.v2mo_build_variant_graph.restype = C.c_void_p
 	L.v2mo_build_variant_graph.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p), _u64p, C.c_char_p, C.c_size_t]
+	L.v2mo_build_variant_graph_ex.restype = C.c_void_p
+	L.v2mo_build_variant_graph_ex.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.POINTER(C.c_void_p), _u64p, C.c_char_p, C.c_size_t]
 	L.v2mo_free.argtypes = [C.c_void_p]
 	L.v2mo_graph_from_arrays.restype = C.c_void_p
 	L.v2mo_graph_from_arrays.argtypes = [C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p,
@@ -189,13 +191,14 @@ class OracleGraph:
 		return buf.raw[:n]
 
 
-def build_variant_graph(fasta_path, vcf_path, chr_id, seq_id=None):
-	"""build_variant_graph (variant_graph.cc:108-454) on FASTA + VCF files.  Returns OracleGraph with .ref set."""
+def build_variant_graph(fasta_path, vcf_path, chr_id, seq_id=None, exclude_sample=None, exclude_copy=-1):
+	"""build_variant_graph (variant_graph.cc:108-454) on FASTA + VCF files.  Returns OracleGraph with .ref set.
+	exclude_sample / exclude_copy restate the delegate's should_include() (all copies of the sample when exclude_copy < 0)."""
 	L = lib()
 	err = C.create_string_buffer(512)
 	refp, reflen = C.c_void_p(), C.c_uint64()
-	h = L.v2mo_build_variant_graph(str(fasta_path).encode(), seq_id.encode() if seq_id else None, str(vcf_path).encode(), chr_id.encode(),
-		C.byref(refp), C.byref(reflen), err, len(err))
+	h = L.v2mo_build_variant_graph_ex(str(fasta_path).encode(), seq_id.encode() if seq_id else None, str(vcf_path).encode(), chr_id.encode(),
+		exclude_sample.encode() if exclude_sample else None, exclude_copy, C.byref(refp), C.byref(reflen), err, len(err))
 	if not h:
 		raise ValueError(err.value.decode())
 	ref = C.string_at(refp, reflen.value)

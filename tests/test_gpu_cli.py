@@ -1,0 +1,93 @@
+"""End to end through the C++ host (vcf2multialign_amd/bin/vcf2multialign): FASTA + VCF in, A2M out, every row
+spliced on the GPU, compared byte for byte with the oracle / the derived goldens."""
+
+import os
+import subprocess
+
+import pytest
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CLI = os.path.join(ROOT, "vcf2multialign_amd", "bin", "vcf2multialign")
+FIX = os.path.join(HERE, "golden", "reference-fixtures", "variant-graph")
+DERIVED = os.path.join(HERE, "golden", "derived")
+
+
+def run(args, cwd=None):
+	assert os.path.exists(CLI), "build the host driver first (__graft_entry__.build())"
+	return subprocess.run([CLI] + args, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+
+
+@pytest.mark.parametrize("stem,fasta", [("test-1a", "test-1.fa"), ("test-1b", "test-1.fa"), ("test-2", "test-2.fa"), ("test-3", "test-3.fa"), ("test-4", "test-4.fa")])
+def test_haplotypes_on_reference_fixtures(tmp_path, stem, fasta):
+	common = ["--haplotypes", "--input-reference=" + os.path.join(FIX, fasta), "--input-variants=" + os.path.join(FIX, stem + ".vcf"), "--chromosome=1"]
+	out = tmp_path / "out.a2m"
+	r = run(common + ["--output-sequences-a2m=" + str(out)])
+	assert r.returncode == 0, r.stderr.decode()
+	assert out.read_bytes() == open(os.path.join(DERIVED, stem + ".haplotypes.a2m"), "rb").read()
+	if stem.startswith("test-1"):   # the expected overlap of tests/variant_graph.cc:267, in main.cc:168-170's wording
+		assert b"Overlapping alternative alleles. Line number: 8 current variant position: 9 variant identifiers: a5 sample: SAMPLE2 chromosome copy: 0 genotype: 1\n" == r.stdout
+	r = run(common + ["-s", str(out), "--unaligned"])
+	assert r.returncode == 0, r.stderr.decode()
+	assert out.read_bytes() == open(os.path.join(DERIVED, stem + ".haplotypes.unaligned.fa"), "rb").read()
+	r = run(common + ["-s", str(out), "--omit-reference", "--dst-chromosome=chrT"])
+	assert r.returncode == 0, r.stderr.decode()
+	assert out.read_bytes() == open(os.path.join(DERIVED, stem + ".haplotypes.chr.noref.a2m"), "rb").read()
+
+
+def test_two_diploid_samples_config1(tmp_path):
+	"""BASELINE config 1: tiny ref + VCF, --haplotypes, 2 diploid samples (a two-sample column subset of test-1a)."""
+	lines = open(os.path.join(FIX, "test-1a.vcf")).read().splitlines()
+	vcf = tmp_path / "two.vcf"
+	vcf.write_text("\n".join(l if l.startswith("##") else "\t".join(l.split("\t")[:11]) for l in lines) + "\n")
+	fa = os.path.join(FIX, "test-1.fa")
+	out = tmp_path / "out.a2m"
+	r = run(["-H", "-r", fa, "-a", str(vcf), "-c", "1", "-s", str(out), "--output-graph-statistics"])
+	assert r.returncode == 0, r.stderr.decode()
+	g = oracle.build_variant_graph(fa, str(vcf), "1")
+	exp = tmp_path / "exp.a2m"
+	g.haplotype_output_a2m(g.ref, str(exp))
+	assert out.read_bytes() == exp.read_bytes()
+	assert out.read_bytes().count(b">") == 5
+	assert b"Total ploidy: 4" in r.stdout
+
+
+def test_separate_files_and_sample_filter(tmp_path):
+	g = synth.build_case(tmp_path, 61, 20000, 300, 4)
+	fa, vcf = str(tmp_path / "synth.fa"), str(tmp_path / "synth.vcf")
+	excl = tmp_path / "excl.tsv"
+	excl.write_text("1\tS1\t0\n1\tS1\t1\n2\tS0\t0\n")
+	wd = tmp_path / "sep"
+	wd.mkdir()
+	r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", "--output-sequences-separate", "-x", str(excl)], cwd=str(wd))
+	assert r.returncode == 0, r.stderr.decode()
+	go = oracle.build_variant_graph(fa, vcf, "1", exclude_sample="S1")
+	names = sorted(os.listdir(wd))
+	assert names == sorted(["REF.a2m"] + ["S%d.%d.a2m" % (s, c) for s in (0, 2, 3) for c in (1, 2)])
+	# output_sequence_file passes the file name as FASTA id and no newline follows the body (output.cc:36,42)
+	assert (wd / "REF.a2m").read_bytes() == b">REF.a2m\n" + go.output_sequence(go.ref)
+	assert (wd / "S2.2.a2m").read_bytes() == b">S2.2.a2m\n" + go.output_sequence(go.ref, copy_index=3)
+	assert g.total_chromosome_copies == 8 and go.total_chromosome_copies == 6
+
+
+def test_one_megabase_end_to_end(tmp_path):
+	g = synth.build_case(tmp_path, 62, 1000000, 12000, 40, long_every=500)
+	fa, vcf = str(tmp_path / "synth.fa"), str(tmp_path / "synth.vcf")
+	out, exp = tmp_path / "out.a2m", tmp_path / "exp.a2m"
+	r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(out)])
+	assert r.returncode == 0, r.stderr.decode()
+	g.haplotype_output_a2m(g.ref, str(exp))
+	assert out.stat().st_size == exp.stat().st_size == sum(len(">%s\n" % i) for i in ["REF"] + ["S%d-%d" % (s, c) for s in range(40) for c in (1, 2)]) + 81 * (g.aligned_length + 1)
+	assert out.read_bytes() == exp.read_bytes()
+
+
+def test_unsupported_and_bad_arguments():
+	assert run(["--founder-sequences=2", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
+	assert run(["-H", "-r", "x", "-a", "y"]).returncode != 0
+	r = run(["-H", "-r", "/nonexistent.fa", "-a", "/nonexistent.vcf", "-c", "1"])
+	assert r.returncode != 0 and b"Unable to read the reference" in r.stderr

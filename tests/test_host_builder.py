@@ -1,0 +1,113 @@
+"""The C++ host's graph builder (vcf2multialign_amd/csrc/host: readers.cc + graph_builder.cc) against the reference's
+golden graph tables and against the oracle's independent builder.  CPU only: the final transpose is the GPU's."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ARRAYS = ("reference_positions", "aligned_positions", "alt_edge_targets", "alt_edge_count_csum", "label_offsets", "paths_by_edge_and_chrom_copy", "ploidy_csum")
+
+
+@pytest.fixture(scope="module")
+def HostGraph():
+	from vcf2multialign_amd import build
+	build.build_native()
+	from vcf2multialign_amd.host import HostGraph
+	return HostGraph
+
+
+def _same(o, h):
+	for k in ARRAYS:
+		assert np.array_equal(getattr(o, k), getattr(h, k)), k
+	assert o.label_bytes == h.label_bytes
+	assert o.sample_names == h.sample_names
+	assert o.ref == h.ref
+	assert o.paths_by_edge_and_chrom_copy_dims == h.paths_by_edge_and_chrom_copy_dims
+	assert o.overlaps() == h.overlaps
+
+
+def _goldens():
+	with open(os.path.join(HERE, "golden", "reference_goldens.json")) as f:
+		return json.load(f)["variant_graph"]
+
+
+@pytest.mark.parametrize("case", _goldens(), ids=lambda c: c["vcf"])
+def test_reference_graph_tables(HostGraph, case, fixtures_dir):   # tests/variant_graph.cc:247-339
+	d = os.path.join(fixtures_dir, "variant-graph")
+	h = HostGraph(os.path.join(d, case["fasta"]), os.path.join(d, case["vcf"]), case["chromosome"])
+	assert len(h.reference_positions) == len(case["nodes"])
+	o = h.label_offsets
+	for n in case["nodes"]:
+		i = n["node"]
+		assert (int(h.reference_positions[i]), int(h.aligned_positions[i])) == (n["ref_pos"], n["aln_pos"])
+		lo, hi = int(h.alt_edge_count_csum[i]), int(h.alt_edge_count_csum[i + 1])
+		got = [{"target": int(h.alt_edge_targets[e]), "label": h.label_bytes[int(o[e]):int(o[e + 1])].decode()} for e in range(lo, hi)]
+		assert got == n["alt_edges"]
+	assert [{k: x[k] for k in ("sample", "chrom_copy_idx", "ref_pos", "var_id", "gt")} for x in h.overlaps] == case["expected_overlaps"]
+	_same(oracle.build_variant_graph(os.path.join(d, case["fasta"]), os.path.join(d, case["vcf"]), case["chromosome"]), h)
+
+
+@pytest.mark.parametrize("name", ["test-1", "test-1-2", "test-2", "test-3", "test-4"])
+def test_founder_fixture_graphs(HostGraph, name, fixtures_dir):
+	d = os.path.join(fixtures_dir, "founder-sequences")
+	vcf = "test-1.vcf" if name == "test-1-2" else name + ".vcf"
+	_same(oracle.build_variant_graph(os.path.join(d, name + ".fa"), os.path.join(d, vcf), "1"), HostGraph(os.path.join(d, name + ".fa"), os.path.join(d, vcf), "1"))
+
+
+@pytest.mark.parametrize("seed,kw", [
+	(101, {}), (102, {"mix": (1.0, 0.0, 0.0)}), (103, {"long_every": 25}), (104, {"multi_allelic": 0.4, "density": 0.4}),
+	(105, {"ploidy": 1}), (106, {"ploidy": 3}),
+])
+def test_synthetic_vcfs_match_the_oracle_builder(HostGraph, tmp_path, seed, kw):
+	rng = np.random.default_rng(seed)
+	ref = synth.random_reference(rng, 30000)
+	n_samples = 70 if seed == 101 else 9          # 140 copies: three 64-row words in the path matrix
+	recs = synth.random_records(rng, ref, 700, n_samples, **kw)
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, n_samples, phased=(seed % 2 == 0))
+	_same(oracle.build_variant_graph(fa, vcf, "1"), HostGraph(fa, vcf, "1"))
+
+
+def test_other_chromosomes_and_missing_alleles(HostGraph, tmp_path):
+	ref = b"ACGTACGTACGTACGTACGT"
+	vcf = tmp_path / "x.vcf"
+	fa = tmp_path / "x.fa"
+	fa.write_bytes(b">chrA some description\n" + ref[:10] + b"\n" + ref[10:] + b"\n>chrB\nTTTT\n")
+	vcf.write_text(
+		"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\tS2\n"
+		"chrB\t1\tb1\tT\tA\t.\t.\t.\tGT\t1|1\t1|1\n"
+		"chrA\t3\ta1;rs1\tG\tT,<DEL>,*\t.\t.\t.\tGT:DP\t1|.:3\t./2:4\n"
+		"chrA\t7\ta2\tGT\tG\t.\t.\t.\tDP:GT\t9:0/1\t9:1|0\n"
+		"chrB\t2\tb2\tT\tA\t.\t.\t.\tGT\t1|1\t1|1\n")
+	o = oracle.build_variant_graph(str(fa), str(vcf), "chrA", seq_id="chrA")
+	h = HostGraph(str(fa), str(vcf), "chrA", seq_id="chrA")
+	_same(o, h)
+	assert h.handled_variants == 2 and h.chr_id_mismatches == 2
+	assert len(h.alt_edge_targets) == 3            # T, <DEL>, and the deletion G; '*' makes no edge
+	assert h.ref == ref
+
+
+def test_sample_exclusion(HostGraph, tmp_path):   # variant_graph.cc:215-273
+	g = synth.build_case(tmp_path, 107, 8000, 150, 5)
+	fa, vcf = os.path.join(str(tmp_path), "synth.fa"), os.path.join(str(tmp_path), "synth.vcf")
+	for sample, copy in (("S2", -1), ("S0", 1), ("S4", 0)):
+		o = oracle.build_variant_graph(fa, vcf, "1", exclude_sample=sample, exclude_copy=copy)
+		h = HostGraph(fa, vcf, "1", exclude_sample=sample, exclude_copy=copy)
+		_same(o, h)
+		assert int(h.ploidy_csum[-1]) == (8 if copy < 0 else 9)
+		assert ("S2" in h.sample_names) == (sample != "S2")
+	assert g.total_chromosome_copies == 10
+
+
+def test_malformed_input_is_an_error(HostGraph, tmp_path):
+	fa, vcf = synth.write_inputs(str(tmp_path), b"ACGTACGT", [(5, b"C", [b"T"], np.array([[1, 0]])), (2, b"G", [b"T"], np.array([[1, 0]]))], 1)
+	with pytest.raises(ValueError):
+		HostGraph(fa, vcf, "1")                     # non-increasing positions (variant_graph.cc:292-297)
+	fa, vcf = synth.write_inputs(str(tmp_path), b"ACGTACGT", [(2, b"T", [b"A"], np.array([[1, 0]]))], 1)
+	with pytest.raises(ValueError):
+		HostGraph(fa, vcf, "1")                     # REF column mismatch (delegate decides; the test delegate refuses)

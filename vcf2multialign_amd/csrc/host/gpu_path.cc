@@ -1,0 +1,52 @@
+#include "gpu_path.hh"
+
+namespace v2m::host {
+
+gpu_context::gpu_context(int device)
+{
+	int const rc(v2m_ctx_create(device, &m_ctx));
+	if (V2M_OK != rc) throw gpu_error(rc, v2m_last_error(nullptr));
+}
+
+gpu_context::~gpu_context() { v2m_ctx_destroy(m_ctx); }
+
+void gpu_context::check(int rc) const
+{
+	if (V2M_OK != rc) throw gpu_error(rc, v2m_last_error(m_ctx));
+}
+
+
+bit_matrix transpose_matrix(gpu_context &gpu, bit_matrix const &mat)
+{
+	if (0 == mat.cols) return bit_matrix{};                           // transpose_matrix.cc:48-49
+	bit_matrix dst(mat.cols, mat.rows);
+	gpu.check(v2m_transpose_bits(gpu.get(), mat.words.data(), mat.rows, mat.cols, dst.words.data()));
+	return dst;
+}
+
+
+void transpose_paths(gpu_context &gpu, variant_graph &graph)
+{
+	graph.paths_by_chrom_copy_and_edge = transpose_matrix(gpu, graph.paths_by_edge_and_chrom_copy);
+}
+
+
+void upload_graph(gpu_context &gpu, sequence_type const &ref_seq, variant_graph const &g)
+{
+	v2m_graph_view view{};
+	view.node_count = g.node_count();
+	view.edge_count = g.edge_count();
+	view.reference_positions = g.reference_positions.data();
+	view.aligned_positions = g.aligned_positions.data();
+	view.alt_edge_targets = g.alt_edge_targets.data();
+	view.alt_edge_count_csum = g.alt_edge_count_csum.data();
+	view.alt_edge_label_offsets = g.alt_edge_label_offsets.data();
+	view.alt_edge_label_bytes = g.alt_edge_label_bytes.data();
+	auto const &paths(g.paths_by_chrom_copy_and_edge);
+	view.paths_by_chrom_copy_and_edge = paths.words.empty() ? nullptr : paths.words.data();
+	view.path_rows = paths.rows;
+	view.path_cols = paths.cols;
+	gpu.check(v2m_upload_graph(gpu.get(), &view, ref_seq.data(), ref_seq.size()));
+}
+
+} // namespace v2m::host

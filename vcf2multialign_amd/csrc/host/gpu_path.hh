@@ -1,0 +1,39 @@
+// gpu_path.hh -- the host's view of the GPU hot path: thin C++ wrappers over the C ABI (include/v2m_hip.h).
+#pragma once
+
+#include <stdexcept>
+#include <string>
+
+#include "../../../include/v2m_hip.h"
+#include "readers.hh"
+#include "variant_graph.hh"
+
+namespace v2m::host {
+
+struct gpu_error : std::runtime_error {
+	int code;
+	gpu_error(int code_, std::string const &what) : std::runtime_error(what), code(code_) {}
+};
+
+class gpu_context {
+public:
+	explicit gpu_context(int device = 0);
+	~gpu_context();
+	gpu_context(gpu_context const &) = delete;
+	gpu_context &operator=(gpu_context const &) = delete;
+	v2m_ctx *get() const { return m_ctx; }
+	void check(int rc) const;   // throws gpu_error with v2m_last_error()
+private:
+	v2m_ctx *m_ctx{};
+};
+
+// transpose_matrix (include/vcf2multialign/transpose_matrix.hh:14) on the GPU.
+[[nodiscard]] bit_matrix transpose_matrix(gpu_context &gpu, bit_matrix const &mat);
+
+// The last step of build_variant_graph (variant_graph.cc:453).
+void transpose_paths(gpu_context &gpu, variant_graph &graph);
+
+// Makes `graph` + `ref_seq` the resident graph of the context.
+void upload_graph(gpu_context &gpu, sequence_type const &ref_seq, variant_graph const &graph);
+
+} // namespace v2m::host

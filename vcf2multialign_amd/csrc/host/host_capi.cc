@@ -1,0 +1,95 @@
+// host_capi.cc -- C API over the host-side graph builder so that the Python tests can compare it with the
+// oracle's builder array by array (no GPU involved: the transpose is not part of the host builder).
+
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+#include "readers.hh"
+
+namespace vh = v2m::host;
+
+namespace {
+
+struct recorded_overlap { vh::u64 lineno, ref_pos; std::string var_id, sample; vh::u32 copy, gt; };
+
+struct host_graph {
+	vh::variant_graph graph;
+	vh::sequence_type ref;
+	vh::build_graph_statistics stats;
+	std::vector<recorded_overlap> overlaps;
+	std::string sample_blob;
+};
+
+struct recording_delegate final : vh::build_graph_delegate {
+	host_graph *hg{};
+	std::string excluded_sample;   // optional: exclude every copy of this sample
+	int excluded_copy{-1};         // or only this copy
+	bool should_include(std::string_view sample_name, vh::u32 copy) const override
+	{
+		if (excluded_sample.empty() || sample_name != excluded_sample) return true;
+		return excluded_copy >= 0 && int(copy) != excluded_copy;
+	}
+	void report_overlapping_alternative(vh::u64 lineno, vh::u64 ref_pos, std::string_view var_id, std::string_view sample_name, vh::u32 copy, vh::u32 gt) override
+	{
+		hg->overlaps.push_back({lineno, ref_pos, std::string(var_id), std::string(sample_name), copy, gt});
+	}
+	bool ref_column_mismatch(vh::u64, vh::u64, std::string_view, std::string_view) override { throw std::runtime_error("REF column mismatch"); }
+};
+
+} // namespace
+
+extern "C" {
+
+void *v2mh_build_variant_graph(char const *fasta, char const *seq_id, char const *vcf, char const *chr, char const *exclude_sample, int exclude_copy, char *err, size_t errlen)
+{
+	auto *hg(new host_graph);
+	try {
+		if (!vh::read_single_fasta_sequence(fasta, hg->ref, seq_id)) throw std::runtime_error("unable to read the reference sequence");
+		recording_delegate d;
+		d.hg = hg;
+		if (exclude_sample) { d.excluded_sample = exclude_sample; d.excluded_copy = exclude_copy; }
+		vh::build_variant_graph(hg->ref, vcf, chr, hg->graph, hg->stats, d);
+		for (auto const &s : hg->graph.sample_names) { hg->sample_blob += s; hg->sample_blob.push_back('\0'); }
+		return hg;
+	} catch (std::exception const &e) {
+		if (err && errlen) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+		delete hg;
+		return nullptr;
+	}
+}
+
+void v2mh_free(void *h) { delete static_cast<host_graph *>(h); }
+
+#define HG(h) (*static_cast<host_graph *>(h))
+uint64_t v2mh_node_count(void *h) { return HG(h).graph.node_count(); }
+uint64_t v2mh_edge_count(void *h) { return HG(h).graph.edge_count(); }
+uint64_t v2mh_sample_count(void *h) { return HG(h).graph.sample_names.size(); }
+uint64_t v2mh_ref_length(void *h) { return HG(h).ref.size(); }
+char const *v2mh_reference(void *h) { return HG(h).ref.data(); }
+uint64_t const *v2mh_reference_positions(void *h) { return HG(h).graph.reference_positions.data(); }
+uint64_t const *v2mh_aligned_positions(void *h) { return HG(h).graph.aligned_positions.data(); }
+uint64_t const *v2mh_alt_edge_targets(void *h) { return HG(h).graph.alt_edge_targets.data(); }
+uint64_t const *v2mh_alt_edge_count_csum(void *h) { return HG(h).graph.alt_edge_count_csum.data(); }
+uint64_t const *v2mh_label_offsets(void *h) { return HG(h).graph.alt_edge_label_offsets.data(); }
+char const *v2mh_label_bytes(void *h) { return HG(h).graph.alt_edge_label_bytes.data(); }
+char const *v2mh_sample_blob(void *h) { return HG(h).sample_blob.data(); }
+uint64_t v2mh_sample_blob_size(void *h) { return HG(h).sample_blob.size(); }
+uint32_t const *v2mh_ploidy_csum(void *h) { return HG(h).graph.ploidy_csum.data(); }
+uint64_t v2mh_ploidy_csum_size(void *h) { return HG(h).graph.ploidy_csum.size(); }
+uint64_t v2mh_handled_variants(void *h) { return HG(h).stats.handled_variants; }
+uint64_t v2mh_chr_id_mismatches(void *h) { return HG(h).stats.chr_id_mismatches; }
+uint64_t const *v2mh_paths_by_edge_and_chrom_copy(void *h, uint64_t *rows, uint64_t *cols)
+{
+	auto const &m(HG(h).graph.paths_by_edge_and_chrom_copy);
+	*rows = m.rows; *cols = m.cols;
+	return m.words.data();
+}
+uint64_t v2mh_overlap_count(void *h) { return HG(h).overlaps.size(); }
+void v2mh_overlap_get(void *h, uint64_t i, uint64_t *lineno, uint64_t *ref_pos, char const **var_id, char const **sample, uint32_t *copy, uint32_t *gt)
+{
+	auto const &o(HG(h).overlaps[i]);
+	*lineno = o.lineno; *ref_pos = o.ref_pos; *var_id = o.var_id.c_str(); *sample = o.sample.c_str(); *copy = o.copy; *gt = o.gt;
+}
+
+} // extern "C"

@@ -1,0 +1,254 @@
+// main.cc -- thin command-line driver with the reference's flag names (vcf2multialign/cmdline.ggo:4-55,
+// vcf2multialign/main.cc:370-552) for the part this repository implements: --haplotypes with FASTA + VCF input,
+// A2M / separate / unaligned output, sample filters, overlap reports.  The per-row splicing and the path-matrix
+// transpose run on the GPU (there is no CPU path); everything else is host code.
+
+#include <getopt.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <set>
+#include <sstream>
+#include <string>
+#include <tuple>
+
+#include "gpu_path.hh"
+#include "output.hh"
+#include "readers.hh"
+
+namespace vh = v2m::host;
+
+namespace {
+
+struct options {
+	bool haplotypes{}, founder_sequences{};
+	char const *input_reference{}, *reference_sequence{}, *input_variants{}, *chromosome{};
+	char const *output_sequences_a2m{}, *dst_chromosome{}, *output_overlaps{};
+	char const *include_samples{}, *exclude_samples{};
+	bool output_sequences_separate{}, separate_plain{}, omit_reference{}, unaligned{}, verbose{}, graph_statistics{};
+	bool ref_mismatch_error{};
+	int device{0};
+};
+
+void usage()
+{
+	std::cerr <<
+		"Usage: vcf2multialign --haplotypes --input-reference=filename.fa --input-variants=filename.vcf --chromosome=id [<options>]\n"
+		"  -H, --haplotypes                   Produce predicted haplotype sequences\n"
+		"  -r, --input-reference=filename     Reference FASTA file path\n"
+		"  -e, --reference-sequence=id        Reference sequence identifier in the input FASTA\n"
+		"  -a, --input-variants=filename      Variant call file path\n"
+		"  -c, --chromosome=id                Chromosome identifier\n"
+		"  -s, --output-sequences-a2m=file    Output reference-guided multiple alignment as A2M\n"
+		"      --output-sequences-separate    Output one sequence per file\n"
+		"      --separate-output-format=fmt   A2M (default) or plain\n"
+		"  -m, --dst-chromosome=id            Chromosome identifier in output\n"
+		"      --omit-reference               Omit the reference sequence from the output\n"
+		"      --unaligned                    Output unaligned sequences instead of an MSA\n"
+		"      --output-overlaps=file         Output overlapping variants as TSV instead of stdout\n"
+		"      --output-graph-statistics      Output graph statistics to stdout\n"
+		"      --ref-mismatch-handling=how    warning (default) or error\n"
+		"      --include-samples=file         TSV (chrom, sample, copy_idx) of the only copies to include\n"
+		"  -x, --exclude-samples=file         TSV (chrom, sample, copy_idx) of copies to exclude\n"
+		"      --device=n                     HIP device to run on (default 0)\n"
+		"      --verbose\n"
+		"Not supported by this build: --founder-sequences, --input-graph, --output-graph, --output-graphviz, --pipe.\n";
+}
+
+typedef std::set<std::tuple<std::string, std::string, unsigned>> sample_set;
+
+// main.cc:42-120 (sample filter lists): TSV rows (chrom, sample, copy_idx)
+sample_set read_sample_list(char const *path, char const *chromosome)
+{
+	sample_set out;
+	std::ifstream is(path);
+	if (!is) { std::cerr << "ERROR: Unable to open " << path << '\n'; std::exit(EXIT_FAILURE); }
+	std::string line;
+	while (std::getline(is, line)) {
+		if (line.empty()) continue;
+		std::istringstream ls(line);
+		std::string chrom, sample; unsigned copy{};
+		if (!(std::getline(ls, chrom, '\t') && std::getline(ls, sample, '\t') && (ls >> copy))) continue;
+		if (chromosome && chrom != chromosome) continue;
+		out.emplace(chrom, sample, copy);
+	}
+	return out;
+}
+
+struct build_delegate final : vh::build_graph_delegate {
+	sample_set const *included{}, *excluded{};
+	std::string chromosome;
+	std::ostream *overlaps{&std::cout};
+	bool mismatch_is_error{};
+	bool is_tsv{};
+
+	bool should_include(std::string_view sample_name, vh::u32 chrom_copy_idx) const override
+	{
+		auto const key(std::make_tuple(chromosome, std::string(sample_name), unsigned(chrom_copy_idx)));
+		if (included) return included->count(key) > 0;
+		if (excluded) return excluded->count(key) == 0;
+		return true;
+	}
+
+	static std::string joined_ids(std::string_view var_id, char const *sep)
+	{
+		std::string out;   // the VCF ID column holds ';'-separated identifiers
+		for (char const c : var_id) { if (';' == c) out += sep; else out.push_back(c); }
+		return out;
+	}
+
+	void report_overlapping_alternative(vh::u64 lineno, vh::u64 ref_pos, std::string_view var_id, std::string_view sample_name, vh::u32 chrom_copy_idx, vh::u32 gt) override
+	{
+		if (is_tsv)   // main.cc:159-165
+			*overlaps << lineno << '\t' << ref_pos << '\t' << joined_ids(var_id, ",") << '\t' << sample_name << '\t' << chrom_copy_idx << '\t' << gt << '\n';
+		else          // main.cc:168-170
+			*overlaps << "Overlapping alternative alleles. Line number: " << lineno << " current variant position: " << ref_pos
+				<< " variant identifiers: " << joined_ids(var_id, ", ") << " sample: " << sample_name << " chromosome copy: " << chrom_copy_idx << " genotype: " << gt << '\n';
+	}
+
+	bool ref_column_mismatch(vh::u64 var_idx, vh::u64 ref_pos, std::string_view ref_in_vcf, std::string_view expected) override
+	{
+		std::cerr << (mismatch_is_error ? "ERROR: " : "WARNING: ") << "REF column contents do not match the reference sequence in variant " << var_idx
+			<< ", position " << (1 + ref_pos) << ". Expected: \"" << expected << "\" Actual: \"" << ref_in_vcf << "\"\n";   // main.cc:179-189
+		if (mismatch_is_error) std::exit(EXIT_FAILURE);
+		return true;
+	}
+};
+
+struct progress_delegate final : vh::output_delegate {
+	bool verbose{};
+	void will_handle_sample(std::string const &, vh::u32, vh::u32) override {}
+	void will_handle_founder_sequence(vh::u32) override {}
+	void handled_sequences(vh::u32 count) override
+	{
+		if (verbose && 0 == count % 10) std::cerr << "Handled " << count << " sequences...\n";   // main.cc:313-330
+	}
+};
+
+} // namespace
+
+
+int main(int argc, char **argv)
+{
+	options opt;
+	enum { o_separate = 1000, o_sep_format, o_omit_ref, o_unaligned, o_overlaps, o_stats, o_mismatch, o_include, o_device, o_verbose, o_unsupported };
+	static option const longopts[] = {
+		{"haplotypes", no_argument, nullptr, 'H'}, {"founder-sequences", required_argument, nullptr, 'F'},
+		{"input-reference", required_argument, nullptr, 'r'}, {"reference-sequence", required_argument, nullptr, 'e'},
+		{"input-variants", required_argument, nullptr, 'a'}, {"chromosome", required_argument, nullptr, 'c'},
+		{"output-sequences-a2m", required_argument, nullptr, 's'}, {"output-sequences-separate", no_argument, nullptr, o_separate},
+		{"separate-output-format", required_argument, nullptr, o_sep_format}, {"dst-chromosome", required_argument, nullptr, 'm'},
+		{"omit-reference", no_argument, nullptr, o_omit_ref}, {"unaligned", no_argument, nullptr, o_unaligned},
+		{"output-overlaps", required_argument, nullptr, o_overlaps}, {"output-graph-statistics", no_argument, nullptr, o_stats},
+		{"ref-mismatch-handling", required_argument, nullptr, o_mismatch}, {"include-samples", required_argument, nullptr, o_include},
+		{"exclude-samples", required_argument, nullptr, 'x'}, {"device", required_argument, nullptr, o_device}, {"verbose", no_argument, nullptr, o_verbose},
+		{"input-graph", required_argument, nullptr, o_unsupported}, {"output-graph", required_argument, nullptr, o_unsupported},
+		{"output-graphviz", required_argument, nullptr, o_unsupported}, {"pipe", required_argument, nullptr, o_unsupported},
+		{"minimum-distance", required_argument, nullptr, o_unsupported}, {"input-cut-positions", required_argument, nullptr, o_unsupported},
+		{"output-cut-positions", required_argument, nullptr, o_unsupported}, {"keep-ref-edges", no_argument, nullptr, o_unsupported},
+		{"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
+	int c;
+	while (-1 != (c = getopt_long(argc, argv, "HF:r:e:a:c:s:m:x:h", longopts, nullptr))) {
+		switch (c) {
+			case 'H': opt.haplotypes = true; break;
+			case 'F': opt.founder_sequences = true; break;
+			case 'r': opt.input_reference = optarg; break;
+			case 'e': opt.reference_sequence = optarg; break;
+			case 'a': opt.input_variants = optarg; break;
+			case 'c': opt.chromosome = optarg; break;
+			case 's': opt.output_sequences_a2m = optarg; break;
+			case 'm': opt.dst_chromosome = optarg; break;
+			case 'x': opt.exclude_samples = optarg; break;
+			case o_separate: opt.output_sequences_separate = true; break;
+			case o_sep_format:
+				if (0 == std::strcmp(optarg, "plain")) opt.separate_plain = true;
+				else if (0 != std::strcmp(optarg, "A2M")) { std::cerr << "ERROR: --separate-output-format must be A2M or plain.\n"; return EXIT_FAILURE; }
+				break;
+			case o_omit_ref: opt.omit_reference = true; break;
+			case o_unaligned: opt.unaligned = true; break;
+			case o_overlaps: opt.output_overlaps = optarg; break;
+			case o_stats: opt.graph_statistics = true; break;
+			case o_mismatch:
+				if (0 == std::strcmp(optarg, "error")) opt.ref_mismatch_error = true;
+				else if (0 != std::strcmp(optarg, "warning")) { std::cerr << "ERROR: --ref-mismatch-handling must be warning or error.\n"; return EXIT_FAILURE; }
+				break;
+			case o_include: opt.include_samples = optarg; break;
+			case o_device: opt.device = std::atoi(optarg); break;
+			case o_verbose: opt.verbose = true; break;
+			case 'h': usage(); return EXIT_SUCCESS;
+			case o_unsupported: std::cerr << "ERROR: option " << argv[optind - 1] << " is not supported by this build.\n"; return EXIT_FAILURE;
+			default: usage(); return EXIT_FAILURE;
+		}
+	}
+
+	// main.cc:577-611
+	if (opt.founder_sequences) { std::cerr << "ERROR: --founder-sequences (cut-position search and matching) is not supported by this build.\n"; return EXIT_FAILURE; }
+	if (!opt.haplotypes) { std::cerr << "ERROR: --haplotypes is required.\n"; return EXIT_FAILURE; }
+	if (!opt.input_reference || !opt.input_variants || !opt.chromosome) { std::cerr << "ERROR: --input-reference, --input-variants and --chromosome are required.\n"; return EXIT_FAILURE; }
+	if (opt.include_samples && opt.exclude_samples) { std::cerr << "ERROR: --include-samples and --exclude-samples are mutually exclusive.\n"; return EXIT_FAILURE; }
+
+	try {
+		vh::gpu_context gpu(opt.device);   // fails here, loudly, without a usable MI355X
+
+		vh::sequence_type ref_seq;
+		std::cerr << "Reading the reference sequence..." << std::flush;
+		if (!vh::read_single_fasta_sequence(opt.input_reference, ref_seq, opt.reference_sequence)) {
+			std::cerr << " ERROR: Unable to read the reference sequence.\n";
+			return EXIT_FAILURE;
+		}
+		std::cerr << " Done. Reference length is " << ref_seq.size() << ".\n";
+
+		vh::variant_graph graph;
+		{
+			sample_set included, excluded;
+			build_delegate delegate;
+			delegate.chromosome = opt.chromosome;
+			delegate.mismatch_is_error = opt.ref_mismatch_error;
+			if (opt.include_samples) { included = read_sample_list(opt.include_samples, opt.chromosome); delegate.included = &included; }
+			if (opt.exclude_samples) { excluded = read_sample_list(opt.exclude_samples, opt.chromosome); delegate.excluded = &excluded; }
+			std::ofstream overlaps_os;
+			if (opt.output_overlaps) {
+				overlaps_os.open(opt.output_overlaps);
+				delegate.overlaps = &overlaps_os;
+				delegate.is_tsv = true;
+			}
+			std::cerr << "Building the variant graph...\n";
+			vh::build_graph_statistics stats;
+			vh::build_variant_graph(ref_seq, opt.input_variants, opt.chromosome, graph, stats, delegate);
+			vh::transpose_paths(gpu, graph);   // variant_graph.cc:453, on the GPU
+			std::cerr << "Done. Handled variants: " << stats.handled_variants << " Chromosome ID mismatches: " << stats.chr_id_mismatches << '\n';
+			if (0 == stats.handled_variants) std::cerr << "WARNING: no variants matched the chromosome identifier \"" << opt.chromosome << "\".\n";
+		}
+
+		if (opt.graph_statistics) {   // main.cc:428-435
+			std::cout << "Nodes:        " << graph.node_count() << '\n';
+			std::cout << "ALT edges:    " << graph.edge_count() << '\n';
+			std::cout << "Total ploidy: " << graph.total_chromosome_copies() << '\n';
+		}
+
+		vh::upload_graph(gpu, ref_seq, graph);
+		progress_delegate delegate;
+		delegate.verbose = opt.verbose;
+		vh::haplotype_output output(gpu, nullptr, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
+		if (opt.output_sequences_a2m) {
+			std::cerr << "Outputting sequences as A2M...\n";
+			output.output_a2m(graph, opt.output_sequences_a2m);
+			std::cerr << "Done.\n";
+		}
+		if (opt.output_sequences_separate) {
+			std::cerr << "Outputting sequences one by one..." << std::flush;
+			output.output_separate(graph, !opt.separate_plain);
+			std::cerr << " Done.\n";
+		}
+	} catch (vh::gpu_error const &e) {
+		std::cerr << "ERROR (GPU path, code " << e.code << "): " << e.what() << '\n';
+		return EXIT_FAILURE;
+	} catch (std::exception const &e) {
+		std::cerr << "ERROR: " << e.what() << '\n';
+		return EXIT_FAILURE;
+	}
+	return EXIT_SUCCESS;
+}

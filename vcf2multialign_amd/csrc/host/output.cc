@@ -1,0 +1,165 @@
+#include "output.hh"
+
+#include <fstream>
+#include <stdexcept>
+
+namespace v2m::host {
+
+output::output(gpu_context &gpu, char const *pipe_cmd, char const *chromosome_id, bool should_output_reference, bool should_output_unaligned, output_delegate &delegate):
+	m_gpu(gpu), m_chromosome_id(chromosome_id), m_delegate(&delegate),
+	m_should_output_reference(should_output_reference), m_should_output_unaligned(should_output_unaligned)
+{
+	if (pipe_cmd) throw std::runtime_error("--pipe is not supported by this build");   // output.cc:26-38,49-68
+}
+
+
+std::string output::prefixed(std::string const &name, char sep) const
+{
+	return m_chromosome_id ? std::string(m_chromosome_id) + sep + name : name;
+}
+
+
+void output::splice(row_set const &rows, v2m_sink_fn sink, void *user)
+{
+	v2m_row_batch batch{};
+	batch.n_rows = rows.copy_index.size();
+	batch.copy_index = rows.copy_index.data();
+	if (rows.any_cuts) {
+		batch.cut_offsets = rows.cut_offsets.data();
+		batch.cut_nodes = rows.cut_nodes.data();
+		batch.cut_copies = rows.cut_copies.data();
+	}
+	m_gpu.check(v2m_splice_rows(m_gpu.get(), &batch, m_should_output_unaligned ? V2M_SPLICE_UNALIGNED : 0u, sink, user));
+}
+
+
+namespace {
+	struct a2m_state { std::ostream *stream; std::vector<std::string> const *ids; output_delegate *delegate; };
+
+	int a2m_sink(void *user, uint64_t row, char const *bytes, uint64_t length)
+	{
+		auto &st(*static_cast<a2m_state *>(user));
+		*st.stream << '>' << (*st.ids)[row] << '\n';                       // sequence_writer.cc:35-36
+		st.stream->write(bytes, std::streamsize(length));
+		*st.stream << '\n';                                                // haplotype_output.cc:57,76
+		st.delegate->handled_sequences(u32(1 + row));                      // haplotype_output.cc:58,78-79
+		return st.stream->good() ? 0 : 1;
+	}
+
+	struct separate_state { std::vector<std::string> const *names; };
+
+	int separate_sink(void *user, uint64_t row, char const *bytes, uint64_t length)
+	{
+		auto const &name((*static_cast<separate_state *>(user)->names)[row]);
+		std::ofstream os(name, std::ios::binary | std::ios::trunc);
+		if (!os) return 1;
+		// output_sequence_file always passes dst_name as the FASTA identifier, whatever
+		// should_include_fasta_header says (output.cc:36,42), and no newline follows the body.
+		os << '>' << name << '\n';
+		os.write(bytes, std::streamsize(length));
+		return os.good() ? 0 : 1;
+	}
+}
+
+
+void output::write_a2m(row_set const &rows, std::ostream &stream)
+{
+	a2m_state st{&stream, &rows.ids, m_delegate};
+	splice(rows, a2m_sink, &st);
+}
+
+
+void output::write_separate(row_set const &rows)
+{
+	separate_state st{&rows.ids};
+	splice(rows, separate_sink, &st);
+}
+
+
+void output::output_a2m(variant_graph const &graph, char const *dst_name)          // output.cc:47-76 without the pipe branch
+{
+	std::ofstream stream(dst_name, std::ios::binary | std::ios::trunc);
+	if (!stream) throw std::runtime_error(std::string("unable to open ") + dst_name + " for writing");
+	output_a2m(graph, stream);
+	stream.flush();
+	if (!stream) throw std::runtime_error(std::string("error while writing ") + dst_name);
+}
+
+
+// --- haplotype_output (haplotype_output.cc:38-132) ------------------------------------------------------------
+output::row_set haplotype_output::rows_for(variant_graph const &graph, char sep, char const *suffix)
+{
+	row_set rows;
+	bool const a2m('\t' == sep);
+	if (m_should_output_reference) {                                                // :48-59 / :87-103
+		rows.ids.push_back(prefixed("REF", sep) + suffix);
+		rows.copy_index.push_back(V2M_PLOIDY_MAX);
+	}
+	for (std::size_t sample_idx(0); sample_idx < graph.sample_names.size(); ++sample_idx) {   // :62 / :106
+		auto const &sample(graph.sample_names[sample_idx]);
+		for (u32 chr_copy_idx(0); chr_copy_idx < graph.sample_ploidy(sample_idx); ++chr_copy_idx) {
+			m_delegate->will_handle_sample(sample, u32(sample_idx), chr_copy_idx);
+			rows.ids.push_back(prefixed(sample + (a2m ? '-' : '.') + std::to_string(1 + chr_copy_idx), sep) + suffix);   // :69-72 / :117
+			rows.copy_index.push_back(graph.ploidy_csum[sample_idx] + chr_copy_idx);                                // :28-31
+		}
+	}
+	return rows;
+}
+
+
+void haplotype_output::output_a2m(variant_graph const &graph, std::ostream &stream)
+{
+	write_a2m(rows_for(graph, '\t', ""), stream);
+}
+
+
+void haplotype_output::output_separate(variant_graph const &graph, bool should_include_fasta_header)
+{
+	char const *const suffix(should_include_fasta_header ? (m_should_output_unaligned ? ".fa" : ".a2m") : "");   // :94-100
+	write_separate(rows_for(graph, '.', suffix));
+}
+
+
+// --- founder_sequence_greedy_output (founder_sequence_greedy_output.cc:515-597) ----------------------------------
+output::row_set founder_sequence_greedy_output::rows_for(char sep, char const *suffix)
+{
+	if (m_cut_positions.empty() || 0 != m_cut_positions.front())
+		throw std::runtime_error("cut positions must start with node 0");            // asserted at founder_sequence_greedy_output.cc:101-102
+	std::size_t const col_rows(m_cut_positions.size() - 1);
+	if (m_assigned_samples.size() != col_rows * m_founder_count)
+		throw std::runtime_error("assigned_samples must have (cut positions - 1) x founders entries");
+
+	row_set rows;
+	rows.any_cuts = true;
+	if (m_should_output_reference) {                                                // :519-531
+		rows.ids.push_back(prefixed("REF", sep) + suffix);
+		rows.copy_index.push_back(V2M_PLOIDY_MAX);
+		rows.cut_offsets.push_back(rows.cut_nodes.size());
+	}
+	for (u32 col(0); col < m_founder_count; ++col) {                                // :533-549
+		m_delegate->will_handle_founder_sequence(col);
+		rows.ids.push_back(prefixed(std::to_string(1 + col), sep) + suffix);        // :542
+		rows.copy_index.push_back(V2M_PLOIDY_MAX);
+		for (std::size_t k(0); k < col_rows; ++k) {                                 // the delegate's copy switch at each cut node (:106-114)
+			rows.cut_nodes.push_back(m_cut_positions[k]);
+			rows.cut_copies.push_back(m_assigned_samples[col * col_rows + k]);
+		}
+		rows.cut_offsets.push_back(rows.cut_nodes.size());
+	}
+	return rows;
+}
+
+
+void founder_sequence_greedy_output::output_a2m(variant_graph const &, std::ostream &stream)
+{
+	write_a2m(rows_for('\t', ""), stream);
+}
+
+
+void founder_sequence_greedy_output::output_separate(variant_graph const &, bool should_include_fasta_header)
+{
+	char const *const suffix(should_include_fasta_header ? (m_should_output_unaligned ? ".fa" : ".a2m") : "");
+	write_separate(rows_for('.', suffix));
+}
+
+} // namespace v2m::host

@@ -1,0 +1,88 @@
+// output.hh -- the output classes of the reference (include/vcf2multialign/output.hh:26-130) over the GPU path.
+//
+// Same class names, constructor arguments and row/identifier conventions; output_a2m() batches all rows of a
+// file into one v2m_splice_rows() call instead of calling output_sequence() per row.  --pipe is not supported
+// (pipe_cmd must be null).  founder_sequence_greedy_output takes its cut positions and matchings as input:
+// finding them (find_cut_positions / find_matchings) is a sequential host algorithm outside this round's scope.
+#pragma once
+
+#include <cstdint>
+#include <ostream>
+#include <string>
+#include <vector>
+
+#include "gpu_path.hh"
+
+namespace v2m::host {
+
+struct output_delegate {
+	virtual ~output_delegate() {}
+	virtual void will_handle_sample(std::string const &sample, u32 sample_idx, u32 chr_copy_idx) = 0;
+	virtual void will_handle_founder_sequence(u32 idx) = 0;
+	virtual void handled_sequences(u32 sequence_count) = 0;
+};
+
+struct null_output_delegate final : output_delegate {
+	void will_handle_sample(std::string const &, u32, u32) override {}
+	void will_handle_founder_sequence(u32) override {}
+	void handled_sequences(u32) override {}
+};
+
+class output {
+public:
+	output(gpu_context &gpu, char const *pipe_cmd, char const *chromosome_id, bool should_output_reference, bool should_output_unaligned, output_delegate &delegate);
+	virtual ~output() {}
+
+	// The graph must be the one uploaded to the context (upload_graph()).
+	virtual void output_separate(variant_graph const &graph, bool should_include_fasta_header) = 0;
+	void output_a2m(variant_graph const &graph, char const *dst_name);
+	virtual void output_a2m(variant_graph const &graph, std::ostream &stream) = 0;
+
+protected:
+	struct row_set {
+		std::vector<std::string> ids;           // FASTA identifiers (a2m) or file names (separate)
+		std::vector<std::uint32_t> copy_index;
+		std::vector<std::uint64_t> cut_offsets{0}, cut_nodes;
+		std::vector<std::uint32_t> cut_copies;
+		bool any_cuts{};
+	};
+	void splice(row_set const &rows, v2m_sink_fn sink, void *user);
+	void write_a2m(row_set const &rows, std::ostream &stream);
+	void write_separate(row_set const &rows);
+	std::string prefixed(std::string const &name, char sep) const;
+
+	gpu_context &m_gpu;
+	char const *m_chromosome_id{};
+	output_delegate *m_delegate{};
+	bool m_should_output_reference{};
+	bool m_should_output_unaligned{};
+};
+
+class haplotype_output final : public output {
+public:
+	using output::output;
+	using output::output_a2m;
+	void output_separate(variant_graph const &graph, bool should_include_fasta_header) override;
+	void output_a2m(variant_graph const &graph, std::ostream &stream) override;
+private:
+	row_set rows_for(variant_graph const &graph, char sep, char const *suffix);
+};
+
+class founder_sequence_greedy_output final : public output {
+public:
+	using output::output;
+	using output::output_a2m;
+	// cut_positions: node indices, first 0, last the sink; assigned_samples: (cuts - 1) rows x founders columns,
+	// column-major, one column per founder (founder_sequence_greedy_output.cc:171,544).
+	void set_cut_positions(std::vector<u64> cut_positions) { m_cut_positions = std::move(cut_positions); }
+	void set_assigned_samples(std::vector<u32> column_major, u32 founder_count) { m_assigned_samples = std::move(column_major); m_founder_count = founder_count; }
+	void output_separate(variant_graph const &graph, bool should_include_fasta_header) override;
+	void output_a2m(variant_graph const &graph, std::ostream &stream) override;
+private:
+	row_set rows_for(char sep, char const *suffix);
+	std::vector<u64> m_cut_positions;
+	std::vector<u32> m_assigned_samples;
+	u32 m_founder_count{};
+};
+
+} // namespace v2m::host

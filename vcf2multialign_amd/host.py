@@ -1,0 +1,88 @@
+"""Binding of the C++ host library's graph builder (libv2m_host.so: csrc/host/readers.cc + graph_builder.cc),
+used by the tests to compare it with the oracle's builder.  The transpose is not part of it (GPU)."""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import build as _build
+
+_u64p = C.POINTER(C.c_uint64)
+_lib = None
+
+
+def _load():
+	global _lib
+	if _lib is None:
+		if not os.path.exists(_build.HOST_LIB_PATH):
+			raise ImportError(_build.HOST_LIB_PATH + " is missing: run __graft_entry__.build()")
+		try:
+			import torch  # noqa: F401  (one HIP runtime per process, see _native.load)
+		except ImportError:
+			pass
+		L = C.CDLL(_build.HOST_LIB_PATH)
+		L.v2mh_build_variant_graph.restype = C.c_void_p
+		L.v2mh_build_variant_graph.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+		L.v2mh_free.argtypes = [C.c_void_p]
+		for n in ("node_count", "edge_count", "sample_count", "ref_length", "sample_blob_size", "ploidy_csum_size", "handled_variants", "chr_id_mismatches", "overlap_count"):
+			f = getattr(L, "v2mh_" + n)
+			f.restype = C.c_uint64
+			f.argtypes = [C.c_void_p]
+		for n in ("reference_positions", "aligned_positions", "alt_edge_targets", "alt_edge_count_csum", "label_offsets"):
+			f = getattr(L, "v2mh_" + n)
+			f.restype = _u64p
+			f.argtypes = [C.c_void_p]
+		for n in ("reference", "label_bytes", "sample_blob", "ploidy_csum"):
+			f = getattr(L, "v2mh_" + n)
+			f.restype = C.c_void_p
+			f.argtypes = [C.c_void_p]
+		L.v2mh_paths_by_edge_and_chrom_copy.restype = _u64p
+		L.v2mh_paths_by_edge_and_chrom_copy.argtypes = [C.c_void_p, _u64p, _u64p]
+		L.v2mh_overlap_get.argtypes = [C.c_void_p, C.c_uint64, _u64p, _u64p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+		_lib = L
+	return _lib
+
+
+def _arr(ptr, n, dtype):
+	if n == 0 or not ptr:
+		return np.zeros(0, dtype=dtype)
+	return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+class HostGraph:
+	"""Result of the host's build_variant_graph (without the final transpose)."""
+
+	def __init__(self, fasta_path, vcf_path, chr_id, seq_id=None, exclude_sample=None, exclude_copy=-1):
+		L = _load()
+		err = C.create_string_buffer(512)
+		h = L.v2mh_build_variant_graph(str(fasta_path).encode(), seq_id.encode() if seq_id else None, str(vcf_path).encode(), chr_id.encode(),
+			exclude_sample.encode() if exclude_sample else None, exclude_copy, err, len(err))
+		if not h:
+			raise ValueError(err.value.decode())
+		try:
+			N, E, S = L.v2mh_node_count(h), L.v2mh_edge_count(h), L.v2mh_sample_count(h)
+			self.ref = C.string_at(L.v2mh_reference(h), L.v2mh_ref_length(h))
+			self.reference_positions = _arr(L.v2mh_reference_positions(h), N, np.uint64)
+			self.aligned_positions = _arr(L.v2mh_aligned_positions(h), N, np.uint64)
+			self.alt_edge_targets = _arr(L.v2mh_alt_edge_targets(h), E, np.uint64)
+			self.alt_edge_count_csum = _arr(L.v2mh_alt_edge_count_csum(h), N + 1, np.uint64)
+			self.label_offsets = _arr(L.v2mh_label_offsets(h), E + 1, np.uint64)
+			self.label_bytes = C.string_at(L.v2mh_label_bytes(h), int(self.label_offsets[-1])) if E else b""
+			blob = C.string_at(L.v2mh_sample_blob(h), L.v2mh_sample_blob_size(h))
+			self.sample_names = [s.decode() for s in blob.split(b"\0")[:-1]] if S else []
+			n_pc = L.v2mh_ploidy_csum_size(h)
+			self.ploidy_csum = np.ctypeslib.as_array(C.cast(L.v2mh_ploidy_csum(h), C.POINTER(C.c_uint32)), shape=(n_pc,)).copy() if n_pc else np.zeros(1, np.uint32)
+			r, c = C.c_uint64(), C.c_uint64()
+			p = L.v2mh_paths_by_edge_and_chrom_copy(h, C.byref(r), C.byref(c))
+			self.paths_by_edge_and_chrom_copy_dims = (r.value, c.value)
+			self.paths_by_edge_and_chrom_copy = _arr(p, r.value * c.value // 64, np.uint64)
+			self.handled_variants = L.v2mh_handled_variants(h)
+			self.chr_id_mismatches = L.v2mh_chr_id_mismatches(h)
+			self.overlaps = []
+			for i in range(L.v2mh_overlap_count(h)):
+				ln, rp, vid, smp, ci, gt = C.c_uint64(), C.c_uint64(), C.c_char_p(), C.c_char_p(), C.c_uint32(), C.c_uint32()
+				L.v2mh_overlap_get(h, i, C.byref(ln), C.byref(rp), C.byref(vid), C.byref(smp), C.byref(ci), C.byref(gt))
+				self.overlaps.append({"lineno": ln.value, "ref_pos": rp.value, "var_id": vid.value.decode(), "sample": smp.value.decode(), "chrom_copy_idx": ci.value, "gt": gt.value})
+		finally:
+			L.v2mh_free(h)
