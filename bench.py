@@ -90,12 +90,15 @@ def main():
 	n_rows = len(rows)
 	total_rows = H + 1
 
+	batch_rows = max(1, min(args.batch_rows, n_rows))
+	if os.environ.get("V2M_BENCH_OUT_FIRST"):
+		out = torch.empty(batch_rows * pitch, dtype=torch.uint8, device=dev)
 	thr = torch.from_numpy(ds.edge_thresholds.astype(np.int64)).to(torch.int32).to(dev) if E else torch.zeros(1, dtype=torch.int32, device=dev)
 	words = Ep // 64 * hp_local
 	paths_src = torch.empty(max(words, 1), dtype=torch.int64, device=dev)   # paths_by_edge_and_chrom_copy (this rank's copies x Ep)
 	paths_dst = torch.empty(max(words, 1), dtype=torch.int64, device=dev)   # paths_by_chrom_copy_and_edge (Ep x this rank's copies)
-	batch_rows = max(1, min(args.batch_rows, n_rows))
-	out = torch.empty(batch_rows * pitch, dtype=torch.uint8, device=dev)
+	if not os.environ.get("V2M_BENCH_OUT_FIRST"):
+		out = torch.empty(batch_rows * pitch, dtype=torch.uint8, device=dev)
 	torch.cuda.synchronize()
 	if hp_local:
 		ds.fill_paths_device(ctx.stream, paths_src.data_ptr(), thr.data_ptr(), copy_base=c0, n_rows=hp_local)
@@ -134,6 +137,9 @@ def main():
 
 	# ---- roofline of the dominant kernel, from HIP events on the kernel's own stream ---------------
 	launches, splice_ms = ctx.profile_get(N.KERNEL_SPLICE_ALIGNED)
+	per_launch = ctx.profile_launches(N.KERNEL_SPLICE_ALIGNED)
+	if rank == 0 and os.environ.get("V2M_BENCH_LOG_LAUNCHES"):
+		log("[bench] splice launches (ms): " + " ".join("%.2f" % x for x in per_launch))
 	_, resolve_ms = ctx.profile_get(N.KERNEL_RESOLVE)
 	_, transpose_ms = ctx.profile_get(N.KERNEL_TRANSPOSE)
 	label_bytes = len(g.label_bytes)
@@ -147,6 +153,17 @@ def main():
 	achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
 
 	value = total_rows * L * args.steps / elapsed / 1e9
+
+	# HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
+	# (profiles/pmc_traffic.json); it is only quoted when the run matches the profiled configuration.
+	traffic, traffic_source = None, None
+	try:
+		with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+			rec = json.load(f).get(args.config)
+		if rec and rec["batch_rows"] == batch_rows and rec["n_gpus"] == world:
+			traffic, traffic_source = rec["hbm_bytes_per_launch"], rec["source"]
+	except (OSError, ValueError, KeyError):
+		pass
 
 	result = {
 		"metric": "aligned A2M Gbases/sec",
@@ -166,10 +183,11 @@ def main():
 				% (args.config, R, ds.n_variants, E, ds.samples, H, L),
 			"rows_total": total_rows, "aligned_length": L, "batch_rows": batch_rows,
 			"sharding": "chromosome copies in blocks of 64 per rank, graph + reference replicated, no collective",
+			"tuning": ctx.info,
 		},
 		"roofline": {
 			"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-			"frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+			"frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (PMC: WRITE_SIZE + 2*FETCH_SIZE)", "traffic_source": traffic_source,
 			"kernel": "splice_aligned_kernel", "launches": launches, "avg_launch_ms": round(1e3 * avg_launch_s, 4),
 			"algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
 			"other_kernels_ms_per_step": {"resolve_effective_edges_kernel": round(resolve_ms / args.steps, 3), "transpose_bits_kernel": round(transpose_ms / args.steps, 3)},

@@ -84,6 +84,10 @@ int v2m_ctx_synchronize(v2m_ctx *ctx);
 /* The hipStream_t all kernels of this ctx are launched on (for event timing by the caller). */
 void *v2m_ctx_stream(v2m_ctx *ctx);
 
+/* Human-readable note on what the context has auto-tuned so far (e.g. the store flavour of the aligned
+ * splice, calibrated on the first >= 1 GiB launch).  Never NULL; empty before any tuning. */
+const char *v2m_ctx_info(const v2m_ctx *ctx);
+
 uint32_t v2m_abi_version(void);
 
 /* ---- transpose_matrix ------------------------------------------------------------------- */
@@ -204,6 +208,8 @@ enum {
 int v2m_profile_enable(v2m_ctx *ctx, int enabled);
 int v2m_profile_reset(v2m_ctx *ctx);
 int v2m_profile_get(v2m_ctx *ctx, int kernel, uint64_t *launches_out, double *total_ms_out);
+/* Per-launch device times (ms) in launch order; writes min(capacity, launches) values, returns the launch count in *launches_out. */
+int v2m_profile_get_launches(v2m_ctx *ctx, int kernel, double *ms_out, uint64_t capacity, uint64_t *launches_out);
 
 #ifdef __cplusplus
 }

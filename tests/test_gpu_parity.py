@@ -168,6 +168,17 @@ def test_random_path_bits_skip_rule(v2m, ctx, tmp_path, monkeypatch, density, ma
 		assert a == b, "row %d differs" % i
 
 
+@pytest.mark.parametrize("nt", ["0", "1"])
+def test_both_store_flavours(v2m, ctx, tmp_path, monkeypatch, nt):
+	"""The aligned kernel exists with plain and with nontemporal output stores (chosen by calibration on large
+	launches); both must give the same bytes."""
+	monkeypatch.setenv("V2M_NT_STORES", nt)
+	g = synth.build_case(tmp_path, 8, 100000, 1500, 10, long_every=60)
+	_upload(v2m, ctx, g)
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies))
+	assert ctx.splice_rows(rows) == _oracle_rows(g, rows)
+
+
 def test_founder_rows_synthetic(v2m, ctx, tmp_path):
 	"""Copy switching at cut nodes that no edge spans (founder_sequence_greedy_output.cc:106-114)."""
 	g = synth.build_case(tmp_path, 21, 80000, 1200, 10)

@@ -52,6 +52,7 @@ SIGNATURES = {
 	"v2m_last_error": (C.c_char_p, [C.c_void_p]),
 	"v2m_ctx_synchronize": (C.c_int, [C.c_void_p]),
 	"v2m_ctx_stream": (C.c_void_p, [C.c_void_p]),
+	"v2m_ctx_info": (C.c_char_p, [C.c_void_p]),
 	"v2m_transpose_bits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
 	"v2m_transpose_bits_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
 	"v2m_upload_graph": (C.c_int, [C.c_void_p, C.POINTER(GraphView), C.c_void_p, C.c_uint64]),
@@ -65,6 +66,7 @@ SIGNATURES = {
 	"v2m_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
 	"v2m_profile_reset": (C.c_int, [C.c_void_p]),
 	"v2m_profile_get": (C.c_int, [C.c_void_p, C.c_int, _u64p, C.POINTER(C.c_double)]),
+	"v2m_profile_get_launches": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, _u64p]),
 }
 
 _lib = None

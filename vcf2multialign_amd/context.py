@@ -84,6 +84,10 @@ class Context:
 	def stream(self):
 		return self._lib.v2m_ctx_stream(self._h)
 
+	@property
+	def info(self):
+		return self._lib.v2m_ctx_info(self._h).decode()
+
 	def synchronize(self):
 		self._check(self._lib.v2m_ctx_synchronize(self._h))
 
@@ -182,6 +186,19 @@ class Context:
 		n, ms = C.c_uint64(), C.c_double()
 		self._check(self._lib.v2m_profile_get(self._h, kernel, C.byref(n), C.byref(ms)))
 		return n.value, ms.value
+
+
+def _profile_launches(self, kernel):
+	"""Per-launch device times (ms) of `kernel` since the last profile_reset()."""
+	n = C.c_uint64()
+	self._check(self._lib.v2m_profile_get_launches(self._h, kernel, None, 0, C.byref(n)))
+	out = np.zeros(n.value, dtype=np.float64)
+	if n.value:
+		self._check(self._lib.v2m_profile_get_launches(self._h, kernel, out.ctypes.data, n.value, C.byref(n)))
+	return out
+
+
+Context.profile_launches = _profile_launches
 
 
 def checksum_rows_host(rows_bytes):

@@ -94,6 +94,10 @@ struct v2m_ctx {
 	dev_buf owned_paths;
 	u64 path_rows{}, path_cols{};
 
+	// store flavour of the aligned splice: -1 = not calibrated yet, 0 = plain, 1 = nontemporal
+	int store_mode{-1};
+	std::string info;
+
 	// per-call scratch
 	dev_buf d_eff, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial, d_tile_counts, d_row_lengths;
 	dev_buf ring[2];
@@ -223,21 +227,19 @@ int prepare_rows(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row
 }
 
 
-bool nontemporal_stores()
+// Tuning knobs (read per call so that one process can A/B them).
+// V2M_NT_STORES=0/1 forces plain / nontemporal output stores; unset = calibrate once per context (below).
+int forced_store_mode()
 {
-	static int const v = [] {
-		char const *e = std::getenv("V2M_NT_STORES");
-		return (e && *e) ? std::atoi(e) : 0;
-	}();
-	return v != 0;
+	char const *e = std::getenv("V2M_NT_STORES");
+	if (!(e && *e)) return -1;
+	return std::atoi(e) != 0 ? 1 : 0;
 }
 
 u32 rows_per_group_for(u64 n_rows)
 {
-	static int const v = [] {
-		char const *e = std::getenv("V2M_ROWS_PER_GROUP");
-		return (e && *e) ? std::atoi(e) : 0;
-	}();
+	char const *e = std::getenv("V2M_ROWS_PER_GROUP");
+	int const v((e && *e) ? std::atoi(e) : 0);
 	if (v > 0) return u32(v);
 	return u32(std::min<u64>(16, std::max<u64>(1, n_rows)));
 }
@@ -310,9 +312,8 @@ int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin,
 	if (int const rc = make_grid(ctx, n_rows, g)) return rc;
 	v2m::tile_tables tt{ctx->d_tile_edge_begin.as<u32>(), ctx->d_cross_offsets.as<u32>(), ctx->d_cross_edges.as<u32>()};
 	u64 const store_limit((ctx->aligned_len + 15) & ~u64(15));
-	{
-		timed_launch tl(ctx, V2M_KERNEL_SPLICE_ALIGNED);
-		if (nontemporal_stores())
+	auto launch = [&](bool nt) {
+		if (nt)
 			hipLaunchKernelGGL(v2m::splice_aligned_kernel<true>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 				ctx->d_template.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
 				d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, store_limit, '-');
@@ -320,6 +321,41 @@ int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin,
 			hipLaunchKernelGGL(v2m::splice_aligned_kernel<false>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 				ctx->d_template.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
 				d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, store_limit, '-');
+	};
+
+	// Output rows are written once and never re-read by the GPU, so nontemporal stores (which keep the
+	// rows from displacing the template and edge tables in L2 / Infinity Cache) usually win: 7.2-7.6 ms
+	// against 8.1-8.5 ms per 51-GB launch at config 3.  But on some boxes / memory layouts they are stuck
+	// in a slower mode for the whole life of a process (9.1-9.3 ms, tools/probe_nt*.py), while plain stores
+	// stay put.  The flavour is therefore calibrated once per context, on the first launch that writes
+	// >= 1 GiB: that launch is issued twice per flavour (the output is the same every time) and the
+	// faster one is kept.
+	int mode(forced_store_mode());
+	if (mode < 0) mode = ctx->store_mode;
+	if (mode < 0 && n_rows * ctx->aligned_len >= (u64(1) << 30)) {
+		hipEvent_t ev[5];
+		for (auto &e : ev) V2M_HIP_TRY(ctx, hipEventCreate(&e));
+		V2M_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+		for (int i(0); i < 4; ++i) {
+			launch(0 == (i & 1));   // nt, plain, nt, plain
+			V2M_HIP_TRY(ctx, hipEventRecord(ev[i + 1], ctx->stream));
+		}
+		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		float t[4];
+		for (int i(0); i < 4; ++i) V2M_HIP_TRY(ctx, hipEventElapsedTime(&t[i], ev[i], ev[i + 1]));
+		for (auto &e : ev) (void) hipEventDestroy(e);
+		float const nt_ms(std::min(t[0], t[2])), plain_ms(std::min(t[1], t[3]));
+		ctx->store_mode = nt_ms <= plain_ms ? 1 : 0;
+		char buf[160];
+		std::snprintf(buf, sizeof(buf), "aligned splice stores: %s (calibrated on %llu rows: nontemporal %.3f ms, plain %.3f ms)",
+			ctx->store_mode ? "nontemporal" : "plain", (unsigned long long) n_rows, nt_ms, plain_ms);
+		ctx->info = buf;
+		mode = ctx->store_mode;
+	}
+	if (mode < 0) mode = 1;   // small launches before any calibration
+	{
+		timed_launch tl(ctx, V2M_KERNEL_SPLICE_ALIGNED);
+		launch(0 != mode);
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
@@ -456,6 +492,8 @@ int v2m_ctx_synchronize(v2m_ctx *ctx)
 }
 
 void *v2m_ctx_stream(v2m_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+const char *v2m_ctx_info(const v2m_ctx *ctx) { return ctx ? ctx->info.c_str() : ""; }
 
 
 // ---- transpose ------------------------------------------------------------------------------
@@ -821,6 +859,21 @@ int v2m_profile_get(v2m_ctx *ctx, int kernel, uint64_t *launches_out, double *to
 	}
 	if (launches_out) *launches_out = ctx->events[kernel].size();
 	if (total_ms_out) *total_ms_out = total;
+	return V2M_OK;
+}
+
+int v2m_profile_get_launches(v2m_ctx *ctx, int kernel, double *ms_out, uint64_t capacity, uint64_t *launches_out)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (kernel < 0 || kernel >= V2M_KERNEL_COUNT) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "unknown kernel id %d", kernel);
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	auto const &ev(ctx->events[kernel]);
+	for (u64 i(0); i < ev.size() && i < capacity && ms_out; ++i) {
+		float ms(0);
+		V2M_HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[i].begin, ev[i].end));
+		ms_out[i] = ms;
+	}
+	if (launches_out) *launches_out = ev.size();
 	return V2M_OK;
 }
 
