@@ -37,6 +37,30 @@ def log(*a):
 	print(*a, file=sys.stderr, flush=True)
 
 
+def _hip_runtime():
+	import ctypes
+	# the HIP runtime already loaded by torch (one runtime per process)
+	return ctypes.CDLL("libamdhip64.so.7")
+
+
+def _hip_memset(torch, ptr, nbytes):
+	import ctypes
+	rt = _hip_runtime()
+	rt.hipMemsetAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+	rc = rt.hipMemsetAsync(ptr, 45, nbytes, ctypes.c_void_p(torch.cuda.current_stream().cuda_stream))
+	assert rc == 0, "hipMemsetAsync failed"
+
+
+def _device_bytes(torch, ptr, nbytes):
+	import ctypes
+	rt = _hip_runtime()
+	rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+	buf = ctypes.create_string_buffer(nbytes)
+	rc = rt.hipMemcpy(buf, ptr, nbytes, 2)   # hipMemcpyDeviceToHost
+	assert rc == 0, "hipMemcpy failed"
+	return buf.raw
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
@@ -44,6 +68,7 @@ def main():
 	ap.add_argument("--warmup", type=int, default=1)
 	ap.add_argument("--config", default="config3", help="synthetic workload (vcf2multialign_amd/synth.py CONFIGS)")
 	ap.add_argument("--batch-rows", type=int, default=512, help="rows per splice launch (one device output buffer of this many rows is reused)")
+	ap.add_argument("--output-candidates", type=int, default=3, help="device buffers v2m_alloc_output may try for the output (1 = plain allocation)")
 	ap.add_argument("--cpu-baseline-rows", type=int, default=64, help="haplotypes (plus REF) the CPU oracle is timed on; 0 disables")
 	ap.add_argument("--verify-rows", type=int, default=3, help="rows of the last batch checked against the CPU oracle after timing; 0 disables")
 	args = ap.parse_args()
@@ -91,14 +116,13 @@ def main():
 	total_rows = H + 1
 
 	batch_rows = max(1, min(args.batch_rows, n_rows))
-	if os.environ.get("V2M_BENCH_OUT_FIRST"):
-		out = torch.empty(batch_rows * pitch, dtype=torch.uint8, device=dev)
+	# Output buffer: placement matters on this hardware, so the library picks it by measurement.
+	out_bytes = batch_rows * pitch
+	out_ptr = ctx.alloc_output(out_bytes, candidates=args.output_candidates)
 	thr = torch.from_numpy(ds.edge_thresholds.astype(np.int64)).to(torch.int32).to(dev) if E else torch.zeros(1, dtype=torch.int32, device=dev)
 	words = Ep // 64 * hp_local
 	paths_src = torch.empty(max(words, 1), dtype=torch.int64, device=dev)   # paths_by_edge_and_chrom_copy (this rank's copies x Ep)
 	paths_dst = torch.empty(max(words, 1), dtype=torch.int64, device=dev)   # paths_by_chrom_copy_and_edge (Ep x this rank's copies)
-	if not os.environ.get("V2M_BENCH_OUT_FIRST"):
-		out = torch.empty(batch_rows * pitch, dtype=torch.uint8, device=dev)
 	torch.cuda.synchronize()
 	if hp_local:
 		ds.fill_paths_device(ctx.stream, paths_src.data_ptr(), thr.data_ptr(), copy_base=c0, n_rows=hp_local)
@@ -111,7 +135,7 @@ def main():
 			ctx.transpose_bits_device(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())
 			ctx.set_paths_device(paths_dst.data_ptr(), Ep, hp_local)
 		for b in batches:
-			ctx.splice_rows_device(b, out.data_ptr(), pitch)
+			ctx.splice_rows_device(b, out_ptr, pitch)
 
 	def fence():
 		ctx.synchronize()
@@ -194,6 +218,19 @@ def main():
 		},
 	}
 
+	# Context for the roofline number: what a plain device memset of the very same output buffer reaches in this
+	# process (the achievable write rate varies by +-10 % between processes / boxes).
+	if rank == 0:
+		ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+		fills = []
+		for _ in range(3):
+			ev0.record()
+			_hip_memset(torch, out_ptr, out_bytes)
+			ev1.record()
+			torch.cuda.synchronize()
+			fills.append(ev0.elapsed_time(ev1))
+		result["roofline"]["memset_same_buffer_GBs"] = round(out_bytes / (min(fills) * 1e-3) / 1e9, 1)
+
 	# ---- CPU oracle: parity of sampled rows, and the timed single-thread baseline (rank 0, N=1) ----
 	if rank == 0 and (args.verify_rows or (world == 1 and args.cpu_baseline_rows)):
 		import oracle
@@ -205,11 +242,11 @@ def main():
 		if args.verify_rows:
 			# re-run the first batch (REF + first copies) and compare device checksums + full bytes of sampled rows
 			k = min(args.verify_rows, batch_rows, n_cols)
-			ctx.splice_rows_device(batches[0], out.data_ptr(), pitch)
-			sums = ctx.checksum_rows_device(out.data_ptr(), pitch, k, length=L)
+			ctx.splice_rows_device(batches[0], out_ptr, pitch)
+			sums = ctx.checksum_rows_device(out_ptr, pitch, k, length=L)
 			bodies = [og.output_sequence(ds.reference, copy_index=int(r)) for r in rows[:k]]
 			ok = bool(np.array_equal(sums, v2m.checksum_rows_host(bodies)))
-			host_row = out[(k - 1) * pitch:(k - 1) * pitch + L].cpu().numpy().tobytes()
+			host_row = _device_bytes(torch, out_ptr + (k - 1) * pitch, L)
 			ok = ok and host_row == bodies[k - 1]
 			result["parity"] = {"rows_checked": k, "bit_exact": ok, "method": "device row checksums + one full row vs CPU oracle"}
 			if not ok:
@@ -229,6 +266,7 @@ def main():
 	if world > 1:
 		dist.barrier()
 		dist.destroy_process_group()
+	ctx.free_output(out_ptr)
 	ctx.close()
 	if rank == 0 and result.get("parity", {}).get("bit_exact") is False:
 		sys.exit(3)

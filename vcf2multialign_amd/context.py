@@ -169,6 +169,15 @@ class Context:
 			d_out, row_pitch, lengths.ctypes.data if want_lengths and rows.n_rows else None))
 		return lengths
 
+	def alloc_output(self, nbytes, candidates=3):
+		"""v2m_alloc_output: device memory for row output, picked among `candidates` allocations by measured write rate."""
+		p = C.c_void_p()
+		self._check(self._lib.v2m_alloc_output(self._h, nbytes, candidates, C.byref(p)))
+		return p.value
+
+	def free_output(self, ptr):
+		self._check(self._lib.v2m_free_output(self._h, ptr))
+
 	def checksum_rows_device(self, d_rows, row_pitch, n_rows, length=0, lengths=None):
 		out = np.zeros(n_rows, dtype=np.uint64)
 		la = None if lengths is None else np.ascontiguousarray(lengths, dtype=np.uint64)

@@ -440,11 +440,26 @@ __device__ __forceinline__ void fill_patch_bytes(
 	}
 }
 
+// Workgroup -> (tile, row group).  The grid is cut into super-blocks of `tile_run` consecutive tiles x all row
+// groups; inside one, consecutive workgroups take consecutive TILES of the same row group.  The ~1000
+// workgroups in flight therefore write a few long contiguous runs per row (what a memset looks like to the
+// TLB and to DRAM pages) instead of 16 KiB islands 100 MB apart, while a super-block's template tiles
+// (tile_run x 16 KiB) stay L2-resident for the row groups that follow.
+__device__ __forceinline__ void map_block(u32 b, u32 n_groups, u32 n_tiles, u32 tile_run, u32 &tile, u32 &group)
+{
+	u32 const per_super = tile_run * n_groups;
+	u32 const super = b / per_super, within = b % per_super;
+	u32 const t0 = super * tile_run;
+	u32 const run = (n_tiles - t0 < tile_run) ? n_tiles - t0 : tile_run;
+	group = within / run;
+	tile = t0 + within % run;
+}
+
 template <bool kNonTemporal>
 __global__ __launch_bounds__(kSpliceThreads) void splice_aligned_kernel(
 	vec4u const *__restrict__ tmpl, u64 const *__restrict__ eff, u64 eff_words_per_row,
 	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
-	char *__restrict__ out, u64 row_pitch, u32 n_rows, u32 rows_per_group, u32 n_groups,
+	char *__restrict__ out, u64 row_pitch, u32 n_rows, u32 rows_per_group, u32 n_groups, u32 n_tiles, u32 tile_run,
 	u64 store_limit /* aligned length rounded up to 16 */, char gap)
 {
 	__shared__ vec4u lds[2][kTileChunks];
@@ -452,10 +467,8 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_aligned_kernel(
 	__shared__ u32 long_count;
 
 	int const t = threadIdx.x;
-	// consecutive workgroups = same tile, next row group: the tile of the template (and the
-	// edge tables behind it) is hot in every XCD's L2 while the groups sweep the rows.
-	u32 const tile = blockIdx.x / n_groups;
-	u32 const group = blockIdx.x % n_groups;
+	u32 tile, group;
+	map_block(blockIdx.x, n_groups, n_tiles, tile_run, tile, group);
 	u32 const row_begin = group * rows_per_group;
 	u32 const row_end = (row_begin + rows_per_group < n_rows) ? row_begin + rows_per_group : n_rows;
 	u32 const tile_base = tile * (u32) kTileBytes;
@@ -548,7 +561,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
 	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
 	u32 *__restrict__ tile_counts /* [n_rows][n_tiles]: counts (pass 1) / exclusive offsets (pass 2) */, u32 n_tiles,
-	char *__restrict__ out, u64 row_pitch, u32 n_rows, u32 rows_per_group, u32 n_groups)
+	char *__restrict__ out, u64 row_pitch, u32 n_rows, u32 rows_per_group, u32 n_groups, u32 tile_run)
 {
 	__shared__ vec4u lds[kTileChunks];
 	__shared__ vec4u comp[kTileChunks + 1];
@@ -558,8 +571,8 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 
 	int const t = threadIdx.x;
 	int const lane = t & 63, wave = t >> 6;
-	u32 const tile = blockIdx.x / n_groups;
-	u32 const group = blockIdx.x % n_groups;
+	u32 tile, group;
+	map_block(blockIdx.x, n_groups, n_tiles, tile_run, tile, group);
 	u32 const row_begin = group * rows_per_group;
 	u32 const row_end = (row_begin + rows_per_group < n_rows) ? row_begin + rows_per_group : n_rows;
 	u32 const tile_base = tile * (u32) kTileBytes;
@@ -706,6 +719,25 @@ __global__ __launch_bounds__(256) void scan_tile_counts_kernel(u32 *__restrict__
 		__syncthreads();
 	}
 	if (t == 0) row_lengths[blockIdx.x] = carry_s;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Write-rate probe for output buffers (v2m_alloc_output): the splice kernel's store pattern -- n_groups x 16
+// rows `pitch` apart advancing together in 16-KiB segments, nontemporal 16-B/lane stores -- with no reads.
+// On MI355X the rate this pattern reaches differs by ~25 % between physical regions of HBM
+// (tools/streams_probe.hip), so output buffers are chosen by measurement.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kSpliceThreads) void probe_write_kernel(char *__restrict__ out, u64 pitch, u32 n_groups)
+{
+	u32 const tile = blockIdx.x / n_groups, group = blockIdx.x % n_groups;
+	vec4u const v = {0, 0, 0, 0};
+	for (u32 r = 0; r < 16; ++r) {
+		char *const dst = out + (u64) (group * 16 + r) * pitch + (u64) tile * kTileBytes;
+#pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k)
+			__builtin_nontemporal_store(v, (vec4u *) (dst + (threadIdx.x + kSpliceThreads * k) * 16));
+	}
 }
 
 

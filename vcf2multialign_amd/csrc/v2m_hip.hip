@@ -285,15 +285,24 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 
 
 struct splice_grid {
-	u32 rows_per_group, n_groups;
+	u32 rows_per_group, n_groups, tile_run;
 	u64 n_blocks;
 };
+
+u32 tile_run_for(u32 n_tiles)
+{
+	char const *e = std::getenv("V2M_TILE_RUN");   // tuning knob
+	int const v((e && *e) ? std::atoi(e) : 0);
+	u32 const run(v > 0 ? u32(v) : 64u);
+	return std::max<u32>(1, std::min(run, n_tiles));
+}
 
 int make_grid(v2m_ctx *ctx, u64 n_rows, splice_grid &g)
 {
 	g.rows_per_group = rows_per_group_for(n_rows);
 	g.n_groups = u32((n_rows + g.rows_per_group - 1) / g.rows_per_group);
 	g.n_blocks = u64(ctx->n_tiles) * g.n_groups;
+	g.tile_run = tile_run_for(ctx->n_tiles);
 	if (g.n_blocks > 0x7FFFFFFFull)
 		return fail(ctx, V2M_ERR_UNSUPPORTED, "splice grid too large (%llu workgroups); use smaller batches", (unsigned long long) g.n_blocks);
 	return V2M_OK;
@@ -316,11 +325,11 @@ int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin,
 		if (nt)
 			hipLaunchKernelGGL(v2m::splice_aligned_kernel<true>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 				ctx->d_template.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
-				d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, store_limit, '-');
+				d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, ctx->n_tiles, g.tile_run, store_limit, '-');
 		else
 			hipLaunchKernelGGL(v2m::splice_aligned_kernel<false>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 				ctx->d_template.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
-				d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, store_limit, '-');
+				d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, ctx->n_tiles, g.tile_run, store_limit, '-');
 	};
 
 	// Output rows are written once and never re-read by the GPU, so nontemporal stores (which keep the
@@ -349,7 +358,8 @@ int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin,
 		char buf[160];
 		std::snprintf(buf, sizeof(buf), "aligned splice stores: %s (calibrated on %llu rows: nontemporal %.3f ms, plain %.3f ms)",
 			ctx->store_mode ? "nontemporal" : "plain", (unsigned long long) n_rows, nt_ms, plain_ms);
-		ctx->info = buf;
+		if (!ctx->info.empty()) ctx->info += "; ";
+		ctx->info += buf;
 		mode = ctx->store_mode;
 	}
 	if (mode < 0) mode = 1;   // small launches before any calibration
@@ -395,12 +405,12 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 		timed_launch tl(ctx, V2M_KERNEL_SPLICE_UNALIGNED);
 		hipLaunchKernelGGL(v2m::splice_unaligned_kernel<true>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 			ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
-			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups);
+			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
 		hipLaunchKernelGGL(v2m::scan_tile_counts_kernel, dim3(unsigned(n_rows)), dim3(256), 0, ctx->stream,
 			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, ctx->d_row_lengths.as<u64>());
 		hipLaunchKernelGGL(v2m::splice_unaligned_kernel<false>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 			ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
-			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups);
+			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
@@ -785,6 +795,71 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 	(void) hipStreamSynchronize(ctx->stream);
 	(void) hipStreamSynchronize(ctx->copy_stream);
 	return rc;
+}
+
+
+// ---- placement-probed output buffers -----------------------------------------------------------
+
+int v2m_alloc_output(v2m_ctx *ctx, uint64_t bytes, int candidates, void **d_out)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (!d_out || 0 == bytes) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad v2m_alloc_output arguments");
+	*d_out = nullptr;
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	// the probe writes n_groups x 16 pseudo-rows of whole tiles; too small a buffer cannot be probed meaningfully
+	u32 const n_groups(32);
+	u64 const pitch((bytes / (n_groups * 16)) & ~u64(v2m::kTileBytes - 1));
+	bool const probe(candidates > 1 && pitch >= u64(64) * v2m::kTileBytes);
+	std::vector<void *> bufs;
+	std::vector<float> ms;
+	for (int c(0); c < (probe ? candidates : 1); ++c) {
+		void *p(nullptr);
+		hipError_t const st(hipMalloc(&p, bytes));
+		if (hipSuccess != st) {
+			(void) hipGetLastError();
+			if (bufs.empty()) return fail(ctx, V2M_ERR_OUT_OF_MEMORY, "hipMalloc of %llu bytes failed: %s", (unsigned long long) bytes, hipGetErrorString(st));
+			break;   // keep what fits
+		}
+		bufs.push_back(p);
+	}
+	std::size_t best(0);
+	if (probe && bufs.size() > 1) {
+		hipEvent_t a, b;
+		V2M_HIP_TRY(ctx, hipEventCreate(&a));
+		V2M_HIP_TRY(ctx, hipEventCreate(&b));
+		u32 const n_tiles(u32(pitch / v2m::kTileBytes));
+		for (void *p : bufs) {
+			float t_best(1e30f);
+			for (int rep(0); rep < 3; ++rep) {
+				V2M_HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
+				hipLaunchKernelGGL(v2m::probe_write_kernel, dim3(n_tiles * n_groups), dim3(v2m::kSpliceThreads), 0, ctx->stream, static_cast<char *>(p), pitch, n_groups);
+				V2M_HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
+				V2M_HIP_TRY(ctx, hipEventSynchronize(b));
+				float t(0);
+				V2M_HIP_TRY(ctx, hipEventElapsedTime(&t, a, b));
+				if (rep) t_best = std::min(t_best, t);   // first run is a warm-up (page-table population)
+			}
+			ms.push_back(t_best);
+		}
+		(void) hipEventDestroy(a);
+		(void) hipEventDestroy(b);
+		best = std::size_t(std::min_element(ms.begin(), ms.end()) - ms.begin());
+		std::string note("output buffer chosen among " + std::to_string(bufs.size()) + " candidates by probe write rate (GB/s):");
+		for (float const t : ms) { char b2[32]; std::snprintf(b2, sizeof(b2), " %.0f", double(pitch) * n_groups * 16 / (t * 1e6)); note += b2; }
+		if (!ctx->info.empty()) ctx->info += "; ";
+		ctx->info += note;
+	}
+	for (std::size_t i(0); i < bufs.size(); ++i)
+		if (i != best) (void) hipFree(bufs[i]);
+	*d_out = bufs[best];
+	return V2M_OK;
+}
+
+int v2m_free_output(v2m_ctx *ctx, void *d_ptr)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (d_ptr) V2M_HIP_TRY(ctx, hipFree(d_ptr));
+	return V2M_OK;
 }
 
 
