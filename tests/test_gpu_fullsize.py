@@ -1,0 +1,160 @@
+"""Full-size runs of BASELINE.json's shapes on the GPU, checked through size-independent properties plus the CPU
+oracle on sampled rows (the oracle needs ~0.1 s per 10 MB row; the GPU writes 20 GB in a few ms).
+
+config 2: synthetic 10 Mb reference, 100k SNV-only records, 1000 diploid samples -> all 2001 rows (20 GB).
+config 3: synthetic 100 Mb reference, 1M SNV+indel records, 2504 diploid samples -> the full 5056 x 1M path-matrix
+          transpose, and a 96-row window of the splice (9.6 GB)."""
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+	import torch
+	import vcf2multialign_amd as v2m
+	from vcf2multialign_amd import synth
+	return torch, v2m, synth
+
+
+def _device_paths(torch, v2m, ds, ctx, copy_base=0, hp=None):
+	"""paths_by_edge_and_chrom_copy generated in HBM, transposed on the GPU.  Returns (src, dst) int64 tensors."""
+	hp = ds.path_cols if hp is None else hp
+	dev = torch.device("cuda", 0)
+	thr = torch.from_numpy(ds.edge_thresholds.astype(np.int64)).to(torch.int32).to(dev)
+	src = torch.empty(ds.path_rows // 64 * hp, dtype=torch.int64, device=dev)
+	dst = torch.empty_like(src)
+	torch.cuda.synchronize()
+	ds.fill_paths_device(ctx.stream, src.data_ptr(), thr.data_ptr(), copy_base, hp)
+	ctx.transpose_bits_device(src.data_ptr(), hp, ds.path_rows, dst.data_ptr())
+	ctx.synchronize()
+	return src, dst
+
+
+def _oracle_for(ds, copies):
+	"""Oracle graph whose path matrix holds the CPU re-derivation of the given chromosome copies (as copies 0..k-1)."""
+	g = ds.graph
+	cols = np.concatenate([ds.copy_column(c) for c in copies] + [np.zeros(ds.path_rows // 64, np.uint64)] * ((-len(copies)) % 64))
+	return oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
+		g.label_offsets, g.label_bytes, cols, ds.path_rows, 64 * ((len(copies) + 63) // 64))
+
+
+def test_config3_transpose_full_size(env):
+	torch, v2m, synth = env
+	ds = synth.dataset("config3")
+	with v2m.Context(0) as ctx:
+		src, dst = _device_paths(torch, v2m, ds, ctx)
+		hp, ep = ds.path_cols, ds.path_rows
+		assert (hp, ep) == (5056, 1000000)
+		# involution, word for word, on the device
+		back = torch.empty_like(src)
+		ctx.transpose_bits_device(dst.data_ptr(), ep, hp, back.data_ptr())
+		ctx.synchronize()
+		assert torch.equal(back, src)
+		# the number of set bits survives (popcount via bytes)
+		def popcount(t):
+			b = t.view(torch.uint8)
+			lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=b.device)
+			return int(lut[b.long()].sum().item()) if b.numel() < (1 << 28) else sum(int(lut[c.long()].sum().item()) for c in b.split(1 << 27))
+		assert popcount(src) == popcount(dst)
+		# sampled destination columns (= chromosome copies) against the CPU re-derivation of the genotype hash
+		wpc = ep // 64
+		for copy in (0, 1, 63, 64, 2503, 5007):
+			got = dst[copy * wpc:(copy + 1) * wpc].cpu().numpy().view(np.uint64)
+			assert np.array_equal(got, ds.copy_column(copy)), "copy %d" % copy
+		# padding columns (copies >= H) are empty
+		assert int(dst[5008 * wpc:].abs().sum().item()) == 0
+
+
+def test_config2_all_rows(env):
+	torch, v2m, synth = env
+	ds = synth.dataset("config2")
+	g = ds.graph
+	L = g.aligned_length
+	assert L == 10_000_000 and ds.n_copies == 2000     # SNV only: no alignment gaps
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(g, ds.reference)
+		src, dst = _device_paths(torch, v2m, ds, ctx)
+		ctx.set_paths_device(dst.data_ptr(), ds.path_rows, ds.path_cols)
+		rows = [v2m.PLOIDY_MAX] + list(range(ds.n_copies))
+		pitch = ctx.min_row_pitch
+		out = torch.empty(len(rows) * pitch, dtype=torch.uint8, device="cuda")
+		torch.cuda.synchronize()
+		ctx.splice_rows_device(rows, out.data_ptr(), pitch)
+		sums = ctx.checksum_rows_device(out.data_ptr(), pitch, len(rows), length=L)
+
+		# REF row == the reference itself (no indels in this config)
+		assert sums[0] == v2m.checksum_rows_host([ds.reference])[0]
+		assert out[:L].cpu().numpy().tobytes() == ds.reference
+		# sampled rows against the oracle, full bytes
+		sample = [0, 1, 2, 999, 1000, 1999]
+		og = _oracle_for(ds, sample)
+		for k, copy in enumerate(sample):
+			exp = og.output_sequence(ds.reference, copy_index=k)
+			r = 1 + copy
+			assert out[r * pitch:r * pitch + L].cpu().numpy().tobytes() == exp, "copy %d" % copy
+			assert sums[r] == v2m.checksum_rows_host([exp])[0]
+		# every row differs from REF exactly at its set SNV sites: check the count for all rows on the device
+		ref_dev = out[:L]
+		wpc = ds.path_rows // 64
+		for copy in (5, 77, 1234):
+			diff = int((out[(1 + copy) * pitch:(1 + copy) * pitch + L] != ref_dev).sum().item())
+			bits = int(np.unpackbits(ds.copy_column(copy).view(np.uint8)).sum())
+			assert diff == bits    # SNV-only, no overlaps: every set edge changes exactly one base
+		# idempotence and batch-split invariance: same rows in three uneven launches into a fresh buffer
+		out2 = torch.zeros_like(out)
+		torch.cuda.synchronize()
+		for lo, hi in ((0, 1), (1, 700), (700, len(rows))):
+			ctx.splice_rows_device(rows[lo:hi], out2.data_ptr() + lo * pitch, pitch)
+		sums2 = ctx.checksum_rows_device(out2.data_ptr(), pitch, len(rows), length=L)
+		assert np.array_equal(sums, sums2)
+		# unaligned == aligned here (nothing to remove), lengths all R
+		lengths = ctx.splice_rows_device(rows[:300], out2.data_ptr(), (ctx.max_unaligned_length + 255) // 256 * 256, unaligned=True, want_lengths=True)
+		assert set(lengths.tolist()) == {L}
+		usums = ctx.checksum_rows_device(out2.data_ptr(), (ctx.max_unaligned_length + 255) // 256 * 256, 300, length=L)
+		assert np.array_equal(usums, sums[:300])
+
+
+def test_config3_row_window(env):
+	torch, v2m, synth = env
+	ds = synth.dataset("config3")
+	g = ds.graph
+	L = g.aligned_length
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(g, ds.reference)
+		# this window's copies only: the last two 64-copy words of the matrix (copies 4928..5055, 80 of them real)
+		base, hp = 4928, 128
+		src, dst = _device_paths(torch, v2m, ds, ctx, copy_base=base, hp=hp)
+		ctx.set_paths_device(dst.data_ptr(), ds.path_rows, hp)
+		n_real = ds.n_copies - base                 # 80 real copies, the rest of the 128 is padding
+		rows = [v2m.PLOIDY_MAX] + list(range(95))   # includes padding copies: they must come out as REF
+		pitch = ctx.min_row_pitch
+		out = torch.empty(len(rows) * pitch, dtype=torch.uint8, device="cuda")
+		torch.cuda.synchronize()
+		ctx.splice_rows_device(rows, out.data_ptr(), pitch)
+		sums = ctx.checksum_rows_device(out.data_ptr(), pitch, len(rows), length=L)
+		sample = [0, 1, 40, n_real - 1]
+		og = _oracle_for(ds, [base + c for c in sample])
+		ref_row = og.output_sequence(ds.reference)
+		assert len(ref_row) == L and sums[0] == v2m.checksum_rows_host([ref_row])[0]
+		for k, c in enumerate(sample):
+			exp = og.output_sequence(ds.reference, copy_index=k)
+			assert sums[1 + c] == v2m.checksum_rows_host([exp])[0], "copy %d" % (base + c)
+		assert out[(1 + 40) * pitch:(1 + 40) * pitch + L].cpu().numpy().tobytes() == og.output_sequence(ds.reference, copy_index=2)
+		for c in range(n_real, 95):                 # padding copies carry no bits
+			assert sums[1 + c] == sums[0]
+		# unaligned: row lengths and bytes of the sampled rows
+		upitch = (ctx.max_unaligned_length + 255) // 256 * 256
+		uout = torch.empty(8 * upitch, dtype=torch.uint8, device="cuda")
+		torch.cuda.synchronize()
+		urows = [v2m.PLOIDY_MAX] + sample
+		lengths = ctx.splice_rows_device(urows, uout.data_ptr(), upitch, unaligned=True, want_lengths=True)
+		exp = [og.output_sequence(ds.reference, unaligned=True)] + [og.output_sequence(ds.reference, copy_index=k, unaligned=True) for k in range(len(sample))]
+		assert exp[0] == ds.reference
+		assert lengths.tolist() == [len(e) for e in exp]
+		usums = ctx.checksum_rows_device(uout.data_ptr(), upitch, len(urows), lengths=lengths)
+		assert np.array_equal(usums, v2m.checksum_rows_host(exp))
