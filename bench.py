@@ -68,6 +68,8 @@ def main():
 	ap.add_argument("--warmup", type=int, default=1)
 	ap.add_argument("--config", default="config3", help="synthetic workload (vcf2multialign_amd/synth.py CONFIGS)")
 	ap.add_argument("--batch-rows", type=int, default=512, help="rows per splice launch (one device output buffer of this many rows is reused)")
+	ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal of N > 1)")
+	ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this HIP device")
 	ap.add_argument("--output-candidates", type=int, default=3, help="device buffers v2m_alloc_output may try for the output (1 = plain allocation)")
 	ap.add_argument("--cpu-baseline-rows", type=int, default=64, help="haplotypes (plus REF) the CPU oracle is timed on; 0 disables")
 	ap.add_argument("--verify-rows", type=int, default=3, help="rows of the last batch checked against the CPU oracle after timing; 0 disables")
@@ -89,11 +91,16 @@ def main():
 	from vcf2multialign_amd import synth
 	from vcf2multialign_amd.sharding import max_over_ranks, shard_copies
 
-	torch.cuda.set_device(local_rank)
-	dev = torch.device("cuda", local_rank)
+	dev_index = local_rank if args.force_device is None else args.force_device
+	torch.cuda.set_device(dev_index)
+	dev = torch.device("cuda", dev_index)
+	red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the timing / parity reductions live
 	if world > 1:
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-		dist.init_process_group("nccl", device_id=dev)
+		if args.dist_backend == "nccl":
+			dist.init_process_group("nccl", device_id=dev)
+		else:
+			dist.init_process_group(args.dist_backend)
 
 	# ---- workload: generated on every rank (deterministic), resident in HBM before timing ----------
 	t0 = time.time()
@@ -105,7 +112,7 @@ def main():
 	if rank == 0:
 		log("[bench] %s: R=%d variants/edges=%d nodes=%d L=%d copies=%d (generated in %.1fs)" % (args.config, R, E, NN, L, H, time.time() - t0))
 
-	ctx = v2m.Context(local_rank)
+	ctx = v2m.Context(dev_index)
 	ctx.upload_graph(g, ds.reference)
 	pitch = ctx.min_row_pitch
 
@@ -156,7 +163,7 @@ def main():
 	elapsed = time.perf_counter() - t_begin
 	if world > 1:
 		dist.barrier()
-		elapsed = max_over_ranks(elapsed, dist, dev)
+		elapsed = max_over_ranks(elapsed, dist, red_dev)
 	ctx.profile_enable(False)
 
 	# ---- roofline of the dominant kernel, from HIP events on the kernel's own stream ---------------
@@ -231,35 +238,50 @@ def main():
 			fills.append(ev0.elapsed_time(ev1))
 		result["roofline"]["memset_same_buffer_GBs"] = round(out_bytes / (min(fills) * 1e-3) / 1e9, 1)
 
-	# ---- CPU oracle: parity of sampled rows, and the timed single-thread baseline (rank 0, N=1) ----
-	if rank == 0 and (args.verify_rows or (world == 1 and args.cpu_baseline_rows)):
+	# ---- CPU oracle: every rank checks sampled rows of its own shard; rank 0 at N=1 times the baseline ----
+	def oracle_graph(copies):
+		"""Oracle graph whose path matrix holds the CPU re-derivation (genotype hash) of the given global copies."""
 		import oracle
-		n_cols = max(args.cpu_baseline_rows if world == 1 else 0, 64)
-		n_cols = min(64 * ((n_cols + 63) // 64), 64 * ((H + 63) // 64))
-		cols = np.concatenate([ds.copy_column(c) if c < H else np.zeros(Ep // 64, np.uint64) for c in range(n_cols)]) if Ep else np.zeros(0, np.uint64)
-		og = oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
-			g.label_offsets, g.label_bytes, cols, Ep, n_cols, g.sample_names[:n_cols // ds.ploidy], g.ploidy_csum[:n_cols // ds.ploidy + 1])
-		if args.verify_rows:
-			# re-run the first batch (REF + first copies) and compare device checksums + full bytes of sampled rows
-			k = min(args.verify_rows, batch_rows, n_cols)
+		n_cols = 64 * ((len(copies) + 63) // 64)
+		cols = [ds.copy_column(c) for c in copies] + [np.zeros(Ep // 64, np.uint64)] * (n_cols - len(copies))
+		return oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
+			g.label_offsets, g.label_bytes, np.concatenate(cols) if Ep else np.zeros(0, np.uint64), Ep, n_cols,
+			["S%d" % i for i in range(n_cols // ds.ploidy)], np.arange(n_cols // ds.ploidy + 1, dtype=np.uint32) * ds.ploidy)
+
+	if args.verify_rows:
+		k = min(args.verify_rows, batches[0].n_rows) if batches else 0
+		ok = True
+		if k:
+			# re-run the first batch of this rank and compare device checksums + one full row with the oracle
 			ctx.splice_rows_device(batches[0], out_ptr, pitch)
 			sums = ctx.checksum_rows_device(out_ptr, pitch, k, length=L)
-			bodies = [og.output_sequence(ds.reference, copy_index=int(r)) for r in rows[:k]]
-			ok = bool(np.array_equal(sums, v2m.checksum_rows_host(bodies)))
-			host_row = _device_bytes(torch, out_ptr + (k - 1) * pitch, L)
-			ok = ok and host_row == bodies[k - 1]
-			result["parity"] = {"rows_checked": k, "bit_exact": ok, "method": "device row checksums + one full row vs CPU oracle"}
-			if not ok:
-				log("[bench] PARITY FAILURE against the CPU oracle")
-		if world == 1 and args.cpu_baseline_rows:
-			nb = min(args.cpu_baseline_rows, H)
-			nbytes, secs = og.haplotype_output_a2m(ds.reference, None, first_copy=0, n_copies=nb)
-			bases = (nb + 1) * L
-			result["cpu_baseline"] = {
-				"value": round(bases / secs / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
-				"sample": "REF + first %d haplotypes of %s (%.2f Gbases) through the oracle's output_sequence/haplotype_output_a2m into a discarding std::ostream, %.1f s; rows are independent, so the rate carries to the full %d rows; host has %d logical CPUs"
-					% (nb, args.config, bases / 1e9, secs, total_rows, os.cpu_count()),
-			}
+			local = rows[:k]
+			copies = [c0 + r for r in local if r != v2m.PLOIDY_MAX]
+			og = oracle_graph(copies)
+			col_of = {c: i for i, c in enumerate(copies)}
+			bodies = [og.output_sequence(ds.reference) if r == v2m.PLOIDY_MAX else og.output_sequence(ds.reference, copy_index=col_of[c0 + r]) for r in local]
+			ok = bool(np.array_equal(sums, v2m.checksum_rows_host(bodies))) and _device_bytes(torch, out_ptr + (k - 1) * pitch, L) == bodies[k - 1]
+		checked = k
+		if world > 1:
+			flags = torch.tensor([1 if ok else 0, checked], dtype=torch.int64, device=red_dev)
+			lo = flags.clone()
+			dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+			dist.all_reduce(flags, op=dist.ReduceOp.SUM)
+			ok, checked = bool(lo[0].item()), int(flags[1].item())
+		result["parity"] = {"rows_checked": checked, "bit_exact": ok, "method": "per rank: device row checksums + one full row of its first batch vs the CPU oracle"}
+		if not ok:
+			log("[bench] PARITY FAILURE against the CPU oracle")
+
+	if rank == 0 and world == 1 and args.cpu_baseline_rows:
+		nb = min(args.cpu_baseline_rows, H)
+		og = oracle_graph(list(range(nb)))
+		nbytes, secs = og.haplotype_output_a2m(ds.reference, None, first_copy=0, n_copies=nb)
+		bases = (nb + 1) * L
+		result["cpu_baseline"] = {
+			"value": round(bases / secs / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
+			"sample": "REF + first %d haplotypes of %s (%.2f Gbases) through the oracle's output_sequence/haplotype_output_a2m into a discarding std::ostream, %.1f s; rows are independent, so the rate carries to the full %d rows; host has %d logical CPUs"
+				% (nb, args.config, bases / 1e9, secs, total_rows, os.cpu_count()),
+		}
 
 	if rank == 0:
 		print(json.dumps(result), flush=True)
@@ -268,7 +290,7 @@ def main():
 		dist.destroy_process_group()
 	ctx.free_output(out_ptr)
 	ctx.close()
-	if rank == 0 and result.get("parity", {}).get("bit_exact") is False:
+	if result.get("parity", {}).get("bit_exact") is False:
 		sys.exit(3)
 
 
