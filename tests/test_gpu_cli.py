@@ -86,8 +86,50 @@ def test_one_megabase_end_to_end(tmp_path):
 	assert out.read_bytes() == exp.read_bytes()
 
 
+def _founder_goldens():
+	import json
+	with open(os.path.join(HERE, "golden", "reference_goldens.json")) as f:
+		return json.load(f)["founder_sequences"]
+
+
+@pytest.mark.parametrize("case", _founder_goldens(), ids=lambda c: c["vcf"] + "+" + c["fasta"])
+def test_founder_sequences_end_to_end(tmp_path, case):
+	"""tests/founder_sequences.cc:78-114 through the product: build -> find_cut_positions(0) -> find_matchings(2) on
+	the host, rows on the GPU, the complete expected A2M text of the reference's test."""
+	d = os.path.join(HERE, "golden", "reference-fixtures", "founder-sequences")
+	out = tmp_path / "founders.a2m"
+	r = run(["--founder-sequences=2", "--minimum-distance=0", "-r", os.path.join(d, case["fasta"]), "-a", os.path.join(d, case["vcf"]), "-c", "1", "-s", str(out), "--verbose"])
+	assert r.returncode == 0, r.stderr.decode()
+	assert out.read_bytes().decode() == case["expected_a2m"]
+	assert ("Cut positions: " + " ".join(str(c) for c in case["cut_positions"]) + "\n").encode() in r.stdout
+	assert b"Maximum segmentation height: " in r.stdout
+
+
+def test_founders_on_a_larger_graph(tmp_path):
+	"""25 founders over a 200 kb synthetic graph: every founder row must be a mosaic of sample rows that switches only
+	at the reported cut positions (checked against the oracle's walk with the same cuts)."""
+	g = synth.build_case(tmp_path, 63, 200000, 2500, 20)
+	fa, vcf = str(tmp_path / "synth.fa"), str(tmp_path / "synth.vcf")
+	out = tmp_path / "founders.a2m"
+	r = run(["-F", "25", "-d", "50", "-r", fa, "-a", vcf, "-c", "1", "-s", str(out), "--verbose"])
+	assert r.returncode == 0, r.stderr.decode()
+	stdout = r.stdout.decode().splitlines()
+	cuts = [int(x) for x in next(l for l in stdout if l.startswith("Cut positions:")).split()[2:]]
+	cols = [[int(x) for x in l.split("\t")[1:]] for l in stdout[stdout.index("Matchings:") + 1:stdout.index("Matchings:") + 26]]
+	assert cuts[0] == 0 and cuts[-1] == g.node_count - 1 and all(b - a > 0 for a, b in zip(cuts, cuts[1:]))
+	assert all(int(g.aligned_positions[b]) - int(g.aligned_positions[a]) >= 50 for a, b in zip(cuts[:-2], cuts[1:-1]))
+	lines = out.read_bytes().split(b"\n")
+	assert lines[0] == b">REF" and lines[1] == g.output_sequence(g.ref)
+	for f, col in enumerate(cols):
+		assert len(col) == len(cuts) - 1
+		assert lines[2 + 2 * f] == b">%d" % (1 + f)
+		assert lines[3 + 2 * f] == g.output_sequence(g.ref, cuts=list(zip(cuts[:-1], col))), "founder %d" % (1 + f)
+
+
 def test_unsupported_and_bad_arguments():
-	assert run(["--founder-sequences=2", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
+	assert run(["--founder-sequences=0", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
+	assert run(["-H", "--founder-sequences=2", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
+	assert run(["-H", "--pipe=cat", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
 	assert run(["-H", "-r", "x", "-a", "y"]).returncode != 0
 	r = run(["-H", "-r", "/nonexistent.fa", "-a", "/nonexistent.vcf", "-c", "1"])
 	assert r.returncode != 0 and b"Unable to read the reference" in r.stderr

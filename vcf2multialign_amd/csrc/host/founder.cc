@@ -1,0 +1,356 @@
+#include "founder.hh"
+
+#include <algorithm>
+#include <map>
+#include <numeric>
+
+namespace v2m::host {
+
+namespace {
+
+constexpr u64 kDivergenceMax = UINT64_MAX;
+
+// Divergence values order with "no match yet" (kDivergenceMax) FIRST (pbwt.hh:25-42).
+struct divergence_less {
+	bool operator()(u64 a, u64 b) const { return a + 1 < b + 1; }
+};
+
+// Positional BWT over the ALT edges, one binary column per edge (pbwt.hh:21-145): the copies sorted by their
+// reversed edge-usage prefixes, the divergence array, and how often each divergence value occurs.
+class edge_pbwt {
+public:
+	std::vector<u32> order;        // "permutation": copies in prefix order
+	std::vector<u64> divergence;
+	std::map<u64, u32, divergence_less> value_counts;
+
+	explicit edge_pbwt(u32 copies) : order(copies), divergence(copies, kDivergenceMax)
+	{
+		std::iota(order.begin(), order.end(), 0u);
+		if (copies) {                                       // pbwt.hh:62-70
+			divergence[0] = 0;
+			value_counts[0] = 1;
+			if (copies > 1) value_counts[kDivergenceMax] = copies - 1;
+		}
+	}
+
+	// One step of Durbin's algorithm 2 for edge `edge` whose usage bits are `column` (pbwt.hh:77-134).
+	void advance(u64 const *column, u64 column_words, u64 edge)
+	{
+		m_prev_order.swap(order);                           // swap_vectors(), pbwt.hh:137-145
+		m_prev_divergence.swap(divergence);
+		u32 const n(u32(m_prev_order.size()));
+		order.resize(n);
+		divergence.resize(n);
+
+		u32 ones(0);
+		for (u64 w(0); w < column_words; ++w) ones += u32(__builtin_popcountll(column[w]));
+		u32 zero_at(0), one_at(n - ones);
+		divergence_less const less;
+		u64 p(edge + 1), q(edge + 1);
+		for (u32 i(0); i < n; ++i) {
+			u32 const copy(m_prev_order[i]);
+			u64 const d(m_prev_divergence[i]);
+			if (less(p, d)) p = d;
+			if (less(q, d)) q = d;
+			auto const it(value_counts.find(d));
+			if (0 == --it->second) value_counts.erase(it);
+			bool const uses_edge((column[copy >> 6] >> (copy & 63)) & 1);
+			if (!uses_edge) {
+				++value_counts[p];
+				order[zero_at] = copy; divergence[zero_at] = p; ++zero_at;
+				p = 0;
+			} else {
+				++value_counts[q];
+				order[one_at] = copy; divergence[one_at] = q; ++one_at;
+				q = 0;
+			}
+		}
+	}
+
+private:
+	std::vector<u32> m_prev_order;
+	std::vector<u64> m_prev_divergence;
+};
+
+struct cut_candidate {
+	u64 edge;        // first edge of the node
+	u64 prev_edge;   // edge of the best predecessor, kEdgeMax = none
+	u64 node;
+	u32 score;
+
+	void improve(u32 class_count, cut_candidate const &pred)                 // find_cut_positions.cc:55-63
+	{
+		u32 const candidate(std::max(class_count, pred.score));
+		if (candidate < score) { score = candidate; prev_edge = pred.edge; }
+	}
+};
+
+inline u64 const *edge_column(variant_graph const &g, u64 edge)
+{
+	auto const &m(g.paths_by_edge_and_chrom_copy);
+	return m.words.data() + edge * m.words_per_column();
+}
+
+} // namespace
+
+
+u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &out)
+{
+	out.clear();
+	u32 const copies(graph.total_chromosome_copies());
+	u64 const words_per_column(graph.paths_by_edge_and_chrom_copy.words_per_column());
+	edge_pbwt pbwt(copies);
+
+	std::vector<cut_candidate> cuts;
+	cuts.push_back({0, kEdgeMax, 0, 0});                                      // :111-112
+	auto const by_edge([](cut_candidate const &c, u64 e) { return c.edge < e; });
+
+	u64 rightmost_target(0), edge(0), last_cut_edge(kEdgeMax);
+	for (u64 node(0); node < graph.node_count(); ++node) {
+		// a node no ALT edge jumps over ends a bridge: candidate cut (:126); one candidate per distinct edge index (:129)
+		if (rightmost_target <= node && last_cut_edge != edge) {
+			cuts.push_back({edge, kEdgeMax, node, copies});
+			last_cut_edge = edge;
+			cut_candidate &current(cuts.back());
+
+			// Divergence values from the largest down: the number of path classes of the segment that starts at the
+			// corresponding edge grows as we go left, so every earlier candidate needs to be looked at once (:134-165).
+			auto right_bound(cuts.end());
+			auto const &vc(pbwt.value_counts);
+			u32 class_count(vc.empty() ? 0 : vc.rbegin()->second);
+			if (!vc.empty()) {
+				for (auto it(std::next(vc.rbegin())); it != vc.rend(); ++it) {   // all values but the largest, descending
+					auto const pred(std::lower_bound(cuts.begin(), right_bound, it->first, by_edge));
+					if (pred != right_bound) {
+						right_bound = pred;
+						if (min_distance <= graph.aligned_positions[node] - graph.aligned_positions[pred->node])
+							current.improve(class_count, *pred);
+					}
+					class_count += it->second;
+				}
+			}
+			if (cuts.begin() != right_bound) {                                // the segment may reach further left still
+				--right_bound;
+				current.improve(class_count, *right_bound);
+			}
+		}
+
+		for (u64 e(graph.alt_edge_count_csum[node]); e < graph.alt_edge_count_csum[node + 1]; ++e) {   // :170-176
+			pbwt.advance(edge_column(graph, edge), words_per_column, edge);
+			++edge;
+			rightmost_target = std::max(rightmost_target, graph.alt_edge_targets[e]);
+		}
+	}
+
+	if (cuts.size() <= 1) return kCutPositionScoreMax;                        // :182-183
+
+	// walk the predecessor links back from the last candidate (:185-209)
+	auto it(cuts.cend() - 1);
+	u32 const score(it->score);
+	for (;;) {
+		out.push_back(it->node);
+		if (kEdgeMax == it->prev_edge) break;
+		it = std::lower_bound(cuts.cbegin(), it, it->prev_edge, by_edge);
+	}
+	if (0 != out.back()) out.push_back(0);
+	std::reverse(out.begin(), out.end());
+	if (out.back() != graph.node_count() - 1) out.back() = graph.node_count() - 1;   // the sink usually has no ALT in-edges
+	return score;
+}
+
+
+namespace {
+
+struct joined_class {                                                         // founder_sequence_greedy_output.cc:48-69
+	u32 lhs_rep, rhs_rep, size;
+	bool operator<(joined_class const &o) const { return size < o.size; }
+};
+
+// The matching state that survives from one cut to the next.
+struct matcher {
+	u32 founders;
+	std::size_t rows;
+	std::vector<u32> &assigned;                    // rows x founders, column-major
+	std::multimap<u32, u32> founder_by_class;      // class representative of the previous block -> founder
+	std::vector<char> reserved;
+	std::vector<u32> loose_rhs;
+
+	u32 &slot(std::size_t row, u32 founder) { return assigned[founder * rows + row]; }
+
+	// second cut: seed row 0 (:248-302)
+	void seed(std::vector<joined_class> const &joined, u32 lhs_distinct)
+	{
+		u32 free_founders(founders);
+		u32 reserved_left(std::min(free_founders, lhs_distinct));
+		free_founders -= reserved_left;
+		u32 next_founder(0);
+		auto const give([&](joined_class const &c) {
+			founder_by_class.emplace(c.lhs_rep, next_founder);
+			slot(0, next_founder) = c.lhs_rep;
+			++next_founder;
+		});
+		for (auto c(joined.rbegin()); c != joined.rend(); ++c) {              // largest joined class first
+			if (reserved[c->lhs_rep]) {
+				if (free_founders) { --free_founders; give(*c); }
+			} else if (reserved_left) {
+				--reserved_left;
+				reserved[c->lhs_rep] = 1;
+				give(*c);
+			}
+		}
+		while (free_founders && !joined.empty())                              // every founder gets a class (:291-302)
+			for (auto c(joined.rbegin()); c != joined.rend() && free_founders; ++c) { --free_founders; give(*c); }
+	}
+
+	// every cut from the second on: continue the founders into the block on the right (:304-442)
+	void extend(std::size_t row, std::vector<joined_class> const &joined, u32 rhs_distinct)
+	{
+		std::fill(reserved.begin(), reserved.end(), 0);
+		loose_rhs.clear();
+		u32 free_founders(founders);
+		u32 reserved_left(std::min(free_founders, rhs_distinct));
+		free_founders -= reserved_left;
+
+		auto const follow([&](joined_class const &c) -> bool {               // a founder currently on c.lhs_rep moves to c.rhs_rep
+			auto const it(founder_by_class.find(c.lhs_rep));
+			if (founder_by_class.end() == it) return false;
+			u32 const founder(it->second);
+			founder_by_class.erase(it);
+			slot(row, founder) = c.rhs_rep;
+			return true;
+		});
+		auto const place_anywhere([&](u32 rhs_rep) {
+			if (founder_by_class.empty()) return;
+			auto const it(founder_by_class.begin());
+			u32 const founder(it->second);
+			founder_by_class.erase(it);
+			slot(row, founder) = rhs_rep;
+		});
+
+		// steps 1-3 (:353-403)
+		bool first_pass(true), stop(false);
+		while (!stop) {
+			bool moved(false);
+			for (auto c(joined.rbegin()); c != joined.rend(); ++c) {
+				if (reserved[c->rhs_rep]) {
+					if (free_founders) {
+						if (follow(*c)) { moved = true; --free_founders; }
+					} else if (!first_pass) {
+						stop = true;
+						break;
+					}
+				} else if (reserved_left) {
+					--reserved_left;
+					if (follow(*c)) reserved[c->rhs_rep] = 1;
+					else loose_rhs.push_back(c->rhs_rep);
+				}
+			}
+			if (stop || !free_founders) break;
+			if (first_pass) { first_pass = false; continue; }
+			if (!moved) break;
+		}
+
+		// step 4 (:405-416): right-hand classes that nobody could follow into
+		for (u32 const rhs_rep : loose_rhs) {
+			if (!reserved[rhs_rep]) {
+				place_anywhere(rhs_rep);
+				reserved[rhs_rep] = 1;
+			}
+		}
+		// step 5 (:418-428): founders still without a continuation
+		while (!founder_by_class.empty() && !joined.empty())
+			for (auto c(joined.rbegin()); c != joined.rend() && !founder_by_class.empty(); ++c) place_anywhere(c->rhs_rep);
+
+		founder_by_class.clear();                                             // :431-436
+		for (u32 f(0); f < founders; ++f) founder_by_class.insert({slot(row, f), f});
+	}
+};
+
+} // namespace
+
+
+bool find_matchings(
+	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
+	std::vector<u32> &assigned)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	if (cut_positions.size() < 2 || 0 == copies) return false;               // :163-167
+
+	std::size_t const rows(cut_positions.size() - 1);
+	assigned.assign(rows * founder_count, kPloidyMax);                         // :171-172
+	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}};
+
+	auto const &paths(graph.paths_by_edge_and_chrom_copy);
+	u64 const words_per_column(paths.words_per_column());
+	edge_pbwt pbwt(copies);
+	std::vector<u32> lhs_class(copies, kPloidyMax), rhs_class(copies, kPloidyMax);
+	std::vector<joined_class> joined;
+	u32 lhs_distinct(0), rhs_distinct(0), lhs_first_class(0), rhs_first_class(0);
+	bool lhs_first_is_ref(true), rhs_first_is_ref(true);
+	u64 edge(0), prev_cut_edge(0), cut_pair_edge(0);
+	std::size_t next_cut(1), cuts_seen(0);
+
+	for (u64 node(0); node < graph.node_count(); ++node) {
+		if (next_cut < cut_positions.size() && node == cut_positions[next_cut]) {
+			// classes of the block that ends here, and of the two-block span ending here (:215-251)
+			lhs_class.swap(rhs_class);
+			std::fill(rhs_class.begin(), rhs_class.end(), kPloidyMax);
+			lhs_distinct = rhs_distinct;
+			lhs_first_class = rhs_first_class;
+			rhs_distinct = 0;
+			rhs_first_class = pbwt.order.front();
+			u32 rep(kPloidyMax);
+			joined.clear();
+			for (u32 i(0); i < copies; ++i) {
+				u32 const copy(pbwt.order[i]);
+				u64 const d(pbwt.divergence[i]);
+				if (prev_cut_edge < d) { rep = copy; ++rhs_distinct; }        // plain integer comparison: kDivergenceMax starts a class
+				rhs_class[copy] = rep;
+				if (cuts_seen) {
+					if (cut_pair_edge < d) joined.push_back({lhs_class[copy], rep, 0});
+					++joined.back().size;
+				}
+			}
+
+			if (cuts_seen) {
+				std::sort(joined.begin(), joined.end());                      // by size, smallest first; ties as std::sort leaves them (:256)
+				if (!keep_ref_edges && lhs_first_is_ref && rhs_first_is_ref)  // :258-264
+					std::erase_if(joined, [&](joined_class const &c) { return c.lhs_rep == lhs_first_class && c.rhs_rep == rhs_first_class; });
+				if (1 == cuts_seen) m.seed(joined, lhs_distinct);
+				m.extend(cuts_seen, joined, rhs_distinct);
+			}
+
+			++cuts_seen;                                                      // :444-451
+			++next_cut;
+			cut_pair_edge = prev_cut_edge;
+			prev_cut_edge = edge;
+			lhs_first_is_ref = rhs_first_is_ref;
+			rhs_first_is_ref = true;
+		}
+
+		for (u64 e(graph.alt_edge_count_csum[node]); e < graph.alt_edge_count_csum[node + 1]; ++e) {   // :454-462
+			pbwt.advance(edge_column(graph, edge), words_per_column, edge);
+			rhs_first_is_ref = rhs_first_is_ref && !paths.test(pbwt.order.front(), edge);
+			++edge;
+		}
+	}
+
+	if (1 == cuts_seen) {                                                     // a single block (:468-507)
+		u32 rep(kPloidyMax);
+		joined.clear();
+		for (u32 i(0); i < copies; ++i) {
+			if (0 < pbwt.divergence[i]) { rep = pbwt.order[i]; ++rhs_distinct; joined.push_back({kPloidyMax, rep, 0}); }
+			rhs_class[pbwt.order[i]] = rep;
+			++joined.back().size;
+		}
+		std::sort(joined.begin(), joined.end());
+		if (!keep_ref_edges && rhs_first_is_ref)
+			std::erase_if(joined, [&](joined_class const &c) { return c.rhs_rep == rhs_first_class; });
+		u32 founder(0);
+		for (auto c(joined.rbegin()); c != joined.rend() && founder < founder_count; ++c, ++founder)
+			assigned[founder * rows + 0] = c->rhs_rep;
+	}
+	return true;
+}
+
+} // namespace v2m::host

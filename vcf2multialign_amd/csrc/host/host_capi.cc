@@ -1,10 +1,12 @@
 // host_capi.cc -- C API over the host-side graph builder so that the Python tests can compare it with the
 // oracle's builder array by array (no GPU involved: the transpose is not part of the host builder).
 
+#include <algorithm>
 #include <cstring>
 #include <stdexcept>
 #include <string>
 
+#include "founder.hh"
 #include "readers.hh"
 
 namespace vh = v2m::host;
@@ -90,6 +92,25 @@ void v2mh_overlap_get(void *h, uint64_t i, uint64_t *lineno, uint64_t *ref_pos, 
 {
 	auto const &o(HG(h).overlaps[i]);
 	*lineno = o.lineno; *ref_pos = o.ref_pos; *var_id = o.var_id.c_str(); *sample = o.sample.c_str(); *copy = o.copy; *gt = o.gt;
+}
+
+// find_cut_positions + find_matchings on a built graph.  cuts_out must hold node_count entries; assigned_out
+// (cuts - 1) * founder_count entries (column-major).  Returns the number of cut positions, 0 if there is no
+// solution; *score_out receives the segmentation score.
+uint64_t v2mh_find_founders(void *h, uint64_t min_distance, uint32_t founder_count, int keep_ref_edges,
+	uint64_t *cuts_out, uint32_t *assigned_out, uint64_t assigned_capacity, uint32_t *score_out)
+{
+	auto const &g(HG(h).graph);
+	std::vector<vh::u64> cuts;
+	vh::u32 const score(vh::find_cut_positions(g, min_distance, cuts));
+	if (score_out) *score_out = score;
+	if (vh::kCutPositionScoreMax == score) return 0;
+	std::vector<vh::u32> assigned;
+	if (!vh::find_matchings(g, cuts, founder_count, 0 != keep_ref_edges, assigned)) return 0;
+	if (assigned.size() > assigned_capacity) return 0;
+	std::copy(cuts.begin(), cuts.end(), cuts_out);
+	std::copy(assigned.begin(), assigned.end(), assigned_out);
+	return cuts.size();
 }
 
 } // extern "C"

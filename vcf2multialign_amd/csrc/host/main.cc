@@ -15,6 +15,7 @@
 #include <string>
 #include <tuple>
 
+#include "founder.hh"
 #include "gpu_path.hh"
 #include "output.hh"
 #include "readers.hh"
@@ -24,7 +25,10 @@ namespace vh = v2m::host;
 namespace {
 
 struct options {
-	bool haplotypes{}, founder_sequences{};
+	bool haplotypes{};
+	long founder_sequences{0};
+	long minimum_distance{0};
+	bool founder_mode{}, keep_ref_edges{};
 	char const *input_reference{}, *reference_sequence{}, *input_variants{}, *chromosome{};
 	char const *output_sequences_a2m{}, *dst_chromosome{}, *output_overlaps{};
 	char const *include_samples{}, *exclude_samples{};
@@ -55,7 +59,10 @@ void usage()
 		"  -x, --exclude-samples=file         TSV (chrom, sample, copy_idx) of copies to exclude\n"
 		"      --device=n                     HIP device to run on (default 0)\n"
 		"      --verbose\n"
-		"Not supported by this build: --founder-sequences, --input-graph, --output-graph, --output-graphviz, --pipe.\n";
+		"  -F, --founder-sequences=count      Produce founder sequences instead of haplotypes\n"
+		"  -d, --minimum-distance=distance    Minimum node distance (MSA co-ordinates) between cut positions\n"
+		"      --keep-ref-edges               Take the reference edges into account when matching\n"
+		"Not supported by this build: --input-graph, --output-graph, --output-graphviz, --pipe, --input/--output-cut-positions.\n";
 }
 
 typedef std::set<std::tuple<std::string, std::string, unsigned>> sample_set;
@@ -134,7 +141,7 @@ struct progress_delegate final : vh::output_delegate {
 int main(int argc, char **argv)
 {
 	options opt;
-	enum { o_separate = 1000, o_sep_format, o_omit_ref, o_unaligned, o_overlaps, o_stats, o_mismatch, o_include, o_device, o_verbose, o_unsupported };
+	enum { o_keep_ref = 900, o_separate = 1000, o_sep_format, o_omit_ref, o_unaligned, o_overlaps, o_stats, o_mismatch, o_include, o_device, o_verbose, o_unsupported };
 	static option const longopts[] = {
 		{"haplotypes", no_argument, nullptr, 'H'}, {"founder-sequences", required_argument, nullptr, 'F'},
 		{"input-reference", required_argument, nullptr, 'r'}, {"reference-sequence", required_argument, nullptr, 'e'},
@@ -147,14 +154,16 @@ int main(int argc, char **argv)
 		{"exclude-samples", required_argument, nullptr, 'x'}, {"device", required_argument, nullptr, o_device}, {"verbose", no_argument, nullptr, o_verbose},
 		{"input-graph", required_argument, nullptr, o_unsupported}, {"output-graph", required_argument, nullptr, o_unsupported},
 		{"output-graphviz", required_argument, nullptr, o_unsupported}, {"pipe", required_argument, nullptr, o_unsupported},
-		{"minimum-distance", required_argument, nullptr, o_unsupported}, {"input-cut-positions", required_argument, nullptr, o_unsupported},
-		{"output-cut-positions", required_argument, nullptr, o_unsupported}, {"keep-ref-edges", no_argument, nullptr, o_unsupported},
+		{"minimum-distance", required_argument, nullptr, 'd'}, {"input-cut-positions", required_argument, nullptr, o_unsupported},
+		{"output-cut-positions", required_argument, nullptr, o_unsupported}, {"keep-ref-edges", no_argument, nullptr, o_keep_ref},
 		{"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
 	int c;
-	while (-1 != (c = getopt_long(argc, argv, "HF:r:e:a:c:s:m:x:h", longopts, nullptr))) {
+	while (-1 != (c = getopt_long(argc, argv, "HF:d:r:e:a:c:s:m:x:h", longopts, nullptr))) {
 		switch (c) {
 			case 'H': opt.haplotypes = true; break;
-			case 'F': opt.founder_sequences = true; break;
+			case 'F': opt.founder_mode = true; opt.founder_sequences = std::atol(optarg); break;
+			case 'd': opt.minimum_distance = std::atol(optarg); break;
+			case o_keep_ref: opt.keep_ref_edges = true; break;
 			case 'r': opt.input_reference = optarg; break;
 			case 'e': opt.reference_sequence = optarg; break;
 			case 'a': opt.input_variants = optarg; break;
@@ -185,8 +194,9 @@ int main(int argc, char **argv)
 	}
 
 	// main.cc:577-611
-	if (opt.founder_sequences) { std::cerr << "ERROR: --founder-sequences (cut-position search and matching) is not supported by this build.\n"; return EXIT_FAILURE; }
-	if (!opt.haplotypes) { std::cerr << "ERROR: --haplotypes is required.\n"; return EXIT_FAILURE; }
+	if (opt.haplotypes == opt.founder_mode) { std::cerr << "ERROR: exactly one of --haplotypes and --founder-sequences is required.\n"; return EXIT_FAILURE; }
+	if (opt.founder_mode && opt.founder_sequences <= 0) { std::cerr << "ERROR: --founder-sequences must be positive.\n"; return EXIT_FAILURE; }   // main.cc:595-599
+	if (opt.minimum_distance < 0) { std::cerr << "ERROR: --minimum-distance must be non-negative.\n"; return EXIT_FAILURE; }                    // main.cc:607-611
 	if (!opt.input_reference || !opt.input_variants || !opt.chromosome) { std::cerr << "ERROR: --input-reference, --input-variants and --chromosome are required.\n"; return EXIT_FAILURE; }
 	if (opt.include_samples && opt.exclude_samples) { std::cerr << "ERROR: --include-samples and --exclude-samples are mutually exclusive.\n"; return EXIT_FAILURE; }
 
@@ -232,16 +242,49 @@ int main(int argc, char **argv)
 		vh::upload_graph(gpu, ref_seq, graph);
 		progress_delegate delegate;
 		delegate.verbose = opt.verbose;
-		vh::haplotype_output output(gpu, nullptr, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
-		if (opt.output_sequences_a2m) {
-			std::cerr << "Outputting sequences as A2M...\n";
-			output.output_a2m(graph, opt.output_sequences_a2m);
-			std::cerr << "Done.\n";
-		}
-		if (opt.output_sequences_separate) {
-			std::cerr << "Outputting sequences one by one..." << std::flush;
-			output.output_separate(graph, !opt.separate_plain);
-			std::cerr << " Done.\n";
+		auto const do_output([&](vh::output &output) {   // main.cc:456-473
+			if (opt.output_sequences_a2m) {
+				std::cerr << "Outputting sequences as A2M...\n";
+				output.output_a2m(graph, opt.output_sequences_a2m);
+				std::cerr << "Done.\n";
+			}
+			if (opt.output_sequences_separate) {
+				std::cerr << "Outputting sequences one by one..." << std::flush;
+				output.output_separate(graph, !opt.separate_plain);
+				std::cerr << " Done.\n";
+			}
+		});
+
+		if (opt.haplotypes) {
+			vh::haplotype_output output(gpu, nullptr, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
+			do_output(output);
+		} else {                                            // main.cc:487-550
+			vh::founder_sequence_greedy_output output(gpu, nullptr, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
+			std::cerr << "Optimising cut positions...\n";
+			std::vector<vh::u64> cuts;
+			vh::u32 const score(vh::find_cut_positions(graph, vh::u64(opt.minimum_distance), cuts));
+			if (vh::kCutPositionScoreMax == score) { std::cerr << "ERROR: Unable to optimise cut positions.\n"; return EXIT_FAILURE; }
+			if (opt.verbose) {
+				std::cout << "Cut positions:";
+				for (auto const cp : cuts) std::cout << ' ' << cp;
+				std::cout << '\n';
+			}
+			std::cout << "Maximum segmentation height: " << (1 + vh::u64(score)) << '\n';   // main.cc:520
+			std::cerr << "Finding matchings in the variant graph...\n";
+			std::vector<vh::u32> assigned;
+			if (!vh::find_matchings(graph, cuts, vh::u32(opt.founder_sequences), opt.keep_ref_edges, assigned)) { std::cerr << "ERROR: Unable to find matchings.\n"; return EXIT_FAILURE; }
+			if (opt.verbose) {                              // main.cc:534-545
+				std::cout << "Matchings:\n";
+				std::size_t const rows(cuts.size() - 1);
+				for (long col(0); col < opt.founder_sequences; ++col) {
+					std::cout << col << ':';
+					for (std::size_t r(0); r < rows; ++r) std::cout << '\t' << assigned[col * rows + r];
+					std::cout << '\n';
+				}
+			}
+			output.set_cut_positions(std::move(cuts));
+			output.set_assigned_samples(std::move(assigned), vh::u32(opt.founder_sequences));
+			do_output(output);
 		}
 	} catch (vh::gpu_error const &e) {
 		std::cerr << "ERROR (GPU path, code " << e.code << "): " << e.what() << '\n';

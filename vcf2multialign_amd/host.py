@@ -39,6 +39,8 @@ def _load():
 			f.argtypes = [C.c_void_p]
 		L.v2mh_paths_by_edge_and_chrom_copy.restype = _u64p
 		L.v2mh_paths_by_edge_and_chrom_copy.argtypes = [C.c_void_p, _u64p, _u64p]
+		L.v2mh_find_founders.restype = C.c_uint64
+		L.v2mh_find_founders.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]
 		L.v2mh_overlap_get.argtypes = [C.c_void_p, C.c_uint64, _u64p, _u64p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
 		_lib = L
 	return _lib
@@ -60,7 +62,8 @@ class HostGraph:
 			exclude_sample.encode() if exclude_sample else None, exclude_copy, err, len(err))
 		if not h:
 			raise ValueError(err.value.decode())
-		try:
+		self._h = h
+		if True:
 			N, E, S = L.v2mh_node_count(h), L.v2mh_edge_count(h), L.v2mh_sample_count(h)
 			self.ref = C.string_at(L.v2mh_reference(h), L.v2mh_ref_length(h))
 			self.reference_positions = _arr(L.v2mh_reference_positions(h), N, np.uint64)
@@ -84,5 +87,23 @@ class HostGraph:
 				ln, rp, vid, smp, ci, gt = C.c_uint64(), C.c_uint64(), C.c_char_p(), C.c_char_p(), C.c_uint32(), C.c_uint32()
 				L.v2mh_overlap_get(h, i, C.byref(ln), C.byref(rp), C.byref(vid), C.byref(smp), C.byref(ci), C.byref(gt))
 				self.overlaps.append({"lineno": ln.value, "ref_pos": rp.value, "var_id": vid.value.decode(), "sample": smp.value.decode(), "chrom_copy_idx": ci.value, "gt": gt.value})
-		finally:
-			L.v2mh_free(h)
+
+	def __del__(self):
+		try:
+			if getattr(self, "_h", None):
+				_load().v2mh_free(self._h)
+				self._h = None
+		except Exception:
+			pass
+
+	def find_founders(self, founder_count, min_distance=0, keep_ref_edges=False):
+		"""find_cut_positions + find_matchings (host algorithms).  Returns (cut_positions, assigned_samples column-major, score)
+		or None when there is no solution."""
+		n = len(self.reference_positions)
+		cuts = np.zeros(n, dtype=np.uint64)
+		assigned = np.zeros(max(1, n * founder_count), dtype=np.uint32)
+		score = C.c_uint32()
+		k = _load().v2mh_find_founders(self._h, min_distance, founder_count, int(keep_ref_edges), cuts.ctypes.data, assigned.ctypes.data, assigned.size, C.byref(score))
+		if k == 0:
+			return None
+		return cuts[:k].tolist(), assigned[:(k - 1) * founder_count].tolist(), score.value
