@@ -3,7 +3,10 @@
 
 #include <hip/hip_runtime.h>
 
+#include <unistd.h>
+
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 
 #include "synth.hh"
@@ -99,6 +102,28 @@ void v2ms_copy_column(void *h, uint64_t seed, uint64_t copy, uint64_t *words_out
 	for (u64 e(0); e < d.graph.edge_count() && e / 64 < n_words; ++e)
 		if (v2m::synth::path_bit(seed, e, copy, d.edge_thresholds[e]))
 			words_out[e >> 6] |= u64(1) << (e & 63);
+}
+
+// A v2m_sink_fn implemented in C for end-to-end measurements of v2m_splice_rows (tools/sink_bench.py): writes
+// '>' id '\n' body '\n' to a file descriptor like the A2M writer does (fd < 0: only counts).
+struct v2ms_sink_state { int fd; uint64_t rows; uint64_t bytes; };
+
+int v2ms_fd_sink(void *user, uint64_t row, char const *bytes, uint64_t length)
+{
+	auto *st(static_cast<v2ms_sink_state *>(user));
+	++st->rows;
+	st->bytes += length;
+	if (st->fd < 0) return 0;
+	char header[64];
+	int const n(std::snprintf(header, sizeof(header), ">row%llu\n", (unsigned long long) row));
+	if (n != ::write(st->fd, header, size_t(n))) return 1;
+	uint64_t done(0);
+	while (done < length) {
+		ssize_t const w(::write(st->fd, bytes + done, length - done));
+		if (w <= 0) return 1;
+		done += uint64_t(w);
+	}
+	return 1 == ::write(st->fd, "\n", 1) ? 0 : 1;
 }
 
 } // extern "C"
