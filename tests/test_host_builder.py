@@ -111,3 +111,52 @@ def test_malformed_input_is_an_error(HostGraph, tmp_path):
 	fa, vcf = synth.write_inputs(str(tmp_path), b"ACGTACGT", [(2, b"T", [b"A"], np.array([[1, 0]]))], 1)
 	with pytest.raises(ValueError):
 		HostGraph(fa, vcf, "1")                     # REF column mismatch (delegate decides; the test delegate refuses)
+
+
+@pytest.mark.parametrize("threads", [1, 2, 5])
+def test_threaded_parse_is_identical_to_sequential(HostGraph, tmp_path, threads):
+	"""Workers parse 8-MB chunks, one thread merges in file order: same graph, same overlap reports in the same order."""
+	rng = np.random.default_rng(120)
+	ref = synth.random_reference(rng, 400000)
+	recs = synth.random_records(rng, ref, 9000, 500, multi_allelic=0.1, long_every=300)   # ~19 MB of VCF text: three chunks
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, 500)
+	assert os.path.getsize(vcf) > 17 * (1 << 20)
+	o = oracle.build_variant_graph(fa, vcf, "1")
+	h = HostGraph(fa, vcf, "1", threads=threads)
+	_same(o, h)
+	assert len(h.overlaps) > 10
+
+
+def test_text_pipeline_equals_direct_generator(HostGraph, tmp_path):
+	"""The synthetic generator pushes records straight into graph_builder and derives genotype bits from a hash; writing
+	the same dataset as FASTA + VCF text and parsing it back must give the same graph and the same path bits."""
+	from vcf2multialign_amd import synth as vsynth
+	ds = vsynth.dataset("mini3")
+	fa, vcf = str(tmp_path / "m.fa"), str(tmp_path / "m.vcf")
+	ds.write_fasta_and_vcf(fa, vcf)
+	h = HostGraph(fa, vcf, "1")
+	g = ds.graph
+	for k in ("reference_positions", "aligned_positions", "alt_edge_targets", "alt_edge_count_csum", "label_offsets"):
+		assert np.array_equal(getattr(g, k), getattr(h, k)), k
+	assert g.label_bytes == h.label_bytes and h.ref == ds.reference
+	hp, ep = h.paths_by_edge_and_chrom_copy_dims
+	assert (hp, ep) == (ds.path_cols, ds.path_rows)
+	m = h.paths_by_edge_and_chrom_copy.reshape(ep, hp // 64)
+	for copy in (0, 1, 63, 64, 199):
+		bits = ((m[:, copy // 64] >> np.uint64(copy % 64)) & np.uint64(1)).astype(np.uint8)
+		assert np.array_equal(bits, np.unpackbits(ds.copy_column(copy).view(np.uint8), bitorder="little")[:ep]), copy
+
+
+def test_errors_surface_in_file_order(HostGraph, tmp_path):
+	ref = b"ACGTACGTACGTACGTACGT"
+	vcf = tmp_path / "bad.vcf"
+	fa = tmp_path / "bad.fa"
+	fa.write_bytes(b">1\n" + ref + b"\n")
+	vcf.write_text(
+		"##fileformat=VCFv4.2\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tS1\n"
+		"1\t3\ta\tG\tT\t.\t.\t.\tGT\t1|0\n"
+		"1\t5\tb\tA\tT\t.\t.\t.\tGT\t1|x\n"
+		"1\t2\tc\tC\tT\t.\t.\t.\tGT\t1|0\n")
+	with pytest.raises(ValueError) as e:
+		HostGraph(str(fa), str(vcf), "1", threads=3)
+	assert "line 4" in str(e.value) and "bad GT allele" in str(e.value)

@@ -43,7 +43,7 @@ struct recording_delegate final : vh::build_graph_delegate {
 
 extern "C" {
 
-void *v2mh_build_variant_graph(char const *fasta, char const *seq_id, char const *vcf, char const *chr, char const *exclude_sample, int exclude_copy, char *err, size_t errlen)
+void *v2mh_build_variant_graph(char const *fasta, char const *seq_id, char const *vcf, char const *chr, char const *exclude_sample, int exclude_copy, unsigned threads, char *err, size_t errlen)
 {
 	auto *hg(new host_graph);
 	try {
@@ -51,7 +51,7 @@ void *v2mh_build_variant_graph(char const *fasta, char const *seq_id, char const
 		recording_delegate d;
 		d.hg = hg;
 		if (exclude_sample) { d.excluded_sample = exclude_sample; d.excluded_copy = exclude_copy; }
-		vh::build_variant_graph(hg->ref, vcf, chr, hg->graph, hg->stats, d);
+		vh::build_variant_graph(hg->ref, vcf, chr, hg->graph, hg->stats, d, threads);
 		for (auto const &s : hg->graph.sample_names) { hg->sample_blob += s; hg->sample_blob.push_back('\0'); }
 		return hg;
 	} catch (std::exception const &e) {

@@ -5,9 +5,12 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <condition_variable>
 #include <cstring>
 #include <fstream>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 #include "graph_builder.hh"
 
@@ -82,13 +85,138 @@ struct field_cursor {
 	}
 };
 
-struct included_copy {
-	u32 sample_vcf_index, copy_vcf_index, row;   // row = ploidy_csum[output sample] + output copy
-};
-
 [[noreturn]] void bad(u64 lineno, char const *what)
 {
 	throw std::runtime_error("VCF line " + std::to_string(lineno) + ": " + what);
+}
+
+// ---- record parsing (runs on worker threads) ------------------------------------------------------------------
+
+struct parsed_genotype { u32 row, alt_number, sample, copy; };
+
+struct parsed_record {
+	u64 line_in_chunk;        // 1-based within the chunk
+	u64 data_line_in_chunk;   // counts only non-header lines
+	u64 ref_pos;
+	std::string_view id, ref;
+	u32 alt_begin, n_alts;
+	u64 geno_begin, geno_end;
+};
+
+struct parsed_chunk {
+	std::vector<parsed_record> records;
+	std::vector<alt_allele> alts;
+	std::vector<parsed_genotype> genos;
+	u64 n_lines{}, n_data_lines{}, chr_mismatches{};
+	std::string error;        // first error, with its chunk-relative line in error_line
+	u64 error_line{};
+};
+
+struct parse_context {
+	std::string_view wanted_chr;
+	std::size_t n_samples{};
+	// (sample, copy) -> row of paths_by_edge_and_chrom_copy, or -1 when the copy is not included;
+	// copies of sample s are row_lookup[copy_begin[s] .. copy_begin[s + 1])
+	std::vector<std::int32_t> row_lookup;
+	std::vector<u32> copy_begin;
+};
+
+struct chunk_error { u64 line; char const *what; };
+
+// Parses the lines of text[begin, end) (whole lines) into `out`.
+void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &out)
+{
+	std::size_t pos(0);
+	try {
+		while (pos < text.size()) {
+			std::size_t eol(text.find('\n', pos));
+			if (std::string_view::npos == eol) eol = text.size();
+			std::string_view line(text.substr(pos, eol - pos));
+			pos = eol + 1;
+			++out.n_lines;
+			if (!line.empty() && '\r' == line.back()) line.remove_suffix(1);
+			if (line.empty() || '#' == line.front()) continue;
+			++out.n_data_lines;
+
+			field_cursor fc(line, '\t');
+			std::string_view chrom, pos_f, id, ref, alt_f, skip, format;
+			if (!(fc.next(chrom) && fc.next(pos_f) && fc.next(id) && fc.next(ref) && fc.next(alt_f) && fc.next(skip) && fc.next(skip) && fc.next(skip)))
+				throw chunk_error{out.n_lines, "fewer than 8 columns"};
+			if (chrom != ctx.wanted_chr) { ++out.chr_mismatches; continue; }              // variant_graph.cc:203-207
+			if (!fc.next(format)) throw chunk_error{out.n_lines, "variant does not have a genotype"};   // :209-213
+			std::size_t gt_index(SIZE_MAX);
+			{
+				field_cursor ff(format, ':');
+				std::string_view f;
+				for (std::size_t i(0); ff.next(f); ++i) if (f == "GT") { gt_index = i; break; }
+				if (SIZE_MAX == gt_index) throw chunk_error{out.n_lines, "variant does not have a genotype"};
+			}
+
+			parsed_record rec{};
+			rec.line_in_chunk = out.n_lines;
+			rec.data_line_in_chunk = out.n_data_lines;
+			rec.id = id;
+			rec.ref = ref;
+			if (pos_f.empty()) throw chunk_error{out.n_lines, "empty POS"};
+			for (char const c : pos_f) { if (c < '0' || '9' < c) throw chunk_error{out.n_lines, "bad POS"}; rec.ref_pos = 10 * rec.ref_pos + u64(c - '0'); }
+			if (0 == rec.ref_pos) throw chunk_error{out.n_lines, "POS must be 1-based"};
+			--rec.ref_pos;                                                                 // zero_based_pos (:292)
+
+			rec.alt_begin = u32(out.alts.size());
+			{
+				field_cursor ac(alt_f, ',');
+				for (std::string_view a; ac.next(a);) out.alts.push_back({classify_alt(a), a});
+			}
+			rec.n_alts = u32(out.alts.size()) - rec.alt_begin;
+
+			// genotypes of the included copies (:379-425); allele 0 and '.' are not recorded (:393-397)
+			rec.geno_begin = out.genos.size();
+			std::size_t sample(0);
+			for (std::string_view field; fc.next(field); ++sample) {
+				if (sample >= ctx.n_samples) throw chunk_error{out.n_lines, "more sample columns than in the header"};
+				std::string_view gt(field);
+				if (gt_index || std::string_view::npos != field.find(':')) {
+					field_cursor sf(field, ':');
+					std::size_t i(0);
+					bool found(false);
+					for (std::string_view f; sf.next(f); ++i) if (i == gt_index) { gt = f; found = true; break; }
+					if (!found) throw chunk_error{out.n_lines, "sample without GT"};
+				}
+				u32 const c_begin(ctx.copy_begin[sample]), c_end(ctx.copy_begin[sample + 1]);
+				u32 copy(0);
+				std::size_t a(0);
+				while (a <= gt.size()) {
+					std::size_t b(a);
+					while (b < gt.size() && '|' != gt[b] && '/' != gt[b]) ++b;
+					if (c_begin + copy < c_end) {
+						std::int32_t const row(ctx.row_lookup[c_begin + copy]);
+						if (row >= 0) {
+							std::string_view const tok(gt.substr(a, b - a));
+							if (tok.empty()) throw chunk_error{out.n_lines, "empty GT allele"};
+							if (tok != ".") {
+								u32 allele(0);
+								for (char const c : tok) { if (c < '0' || '9' < c) throw chunk_error{out.n_lines, "bad GT allele"}; allele = 10 * allele + u32(c - '0'); }
+								if (allele) {
+									if (allele > rec.n_alts) throw chunk_error{out.n_lines, "GT allele exceeds the ALT count"};
+									out.genos.push_back({u32(row), allele, u32(sample), copy});
+								}
+							}
+						}
+					}
+					++copy;
+					a = b + 1;
+				}
+				for (u32 c(copy); c_begin + c < c_end; ++c)                               // libbio_assert_lt(chr_idx_input, gt.size()), :390
+					if (ctx.row_lookup[c_begin + c] >= 0) throw chunk_error{out.n_lines, "GT has fewer alleles than in the first record"};
+			}
+			if (sample != ctx.n_samples) throw chunk_error{out.n_lines, "sample column count differs from the header"};
+			rec.geno_end = out.genos.size();
+			out.records.push_back(rec);
+		}
+	} catch (chunk_error const &e) {
+		out.error = e.what;
+		out.error_line = e.line;
+	}
 }
 
 } // namespace
@@ -96,155 +224,211 @@ struct included_copy {
 
 void build_variant_graph(
 	sequence_type const &ref_seq, char const *variants_path, char const *chr_id,
-	variant_graph &graph, build_graph_statistics &stats, build_graph_delegate &delegate)
+	variant_graph &graph, build_graph_statistics &stats, build_graph_delegate &delegate, unsigned threads)
 {
 	mapped_file const file(variants_path);
 	std::string_view const text(file.data, file.size);
 	std::string_view const ref_sv(ref_seq.data(), ref_seq.size());
-	std::string_view const wanted_chr(chr_id);
 
 	graph = variant_graph{};
 	graph_builder builder(graph, /* track_paths */ true);
 
+	// ---- header, then the first record on the requested chromosome: it fixes ploidy and inclusion (:215-288) ----
+	parse_context ctx;
+	ctx.wanted_chr = chr_id;
 	std::vector<std::string> vcf_sample_names;
-	std::vector<included_copy> included;          // sorted by sample_vcf_index, then copy
-	std::vector<std::string_view> sample_fields;
-	std::vector<alt_allele> alts;
-	bool is_first(true);
-	u64 lineno(0), var_idx(0);
-	std::string_view cur_id;          // what the overlap callback reports: the record and copy being handled
-	u32 cur_sample(0), cur_copy(0);
-
-	std::size_t pos(0);
-	while (pos < text.size()) {
-		std::size_t eol(text.find('\n', pos));
-		if (std::string_view::npos == eol) eol = text.size();
-		std::string_view line(text.substr(pos, eol - pos));
-		pos = eol + 1;
-		++lineno;
-		if (!line.empty() && '\r' == line.back()) line.remove_suffix(1);
-		if (line.empty()) continue;
-		if ('#' == line.front()) {
+	std::size_t body_begin(0);
+	u64 header_lines(0);
+	{
+		std::size_t pos(0);
+		while (pos < text.size()) {
+			std::size_t eol(text.find('\n', pos));
+			if (std::string_view::npos == eol) eol = text.size();
+			std::string_view line(text.substr(pos, eol - pos));
+			if (!line.empty() && '\r' == line.back()) line.remove_suffix(1);
+			if (!line.empty() && '#' != line.front()) break;
 			if (line.substr(0, 6) == "#CHROM") {
 				field_cursor fc(line, '\t');
 				std::string_view f;
-				for (unsigned i(0); fc.next(f); ++i)
-					if (i >= 9) vcf_sample_names.emplace_back(f);
+				for (unsigned i(0); fc.next(f); ++i) if (i >= 9) vcf_sample_names.emplace_back(f);
 			}
-			continue;
+			pos = eol + 1;
+			++header_lines;
 		}
-
-		++var_idx;
-		field_cursor fc(line, '\t');
-		std::string_view chrom, pos_f, id, ref, alt_f, skip, format;
-		if (!(fc.next(chrom) && fc.next(pos_f) && fc.next(id) && fc.next(ref) && fc.next(alt_f) && fc.next(skip) && fc.next(skip) && fc.next(skip)))
-			bad(lineno, "fewer than 8 columns");
-		if (chrom != wanted_chr) { ++stats.chr_id_mismatches; continue; }                 // variant_graph.cc:203-207
-		if (!fc.next(format)) bad(lineno, "variant does not have a genotype");              // :209-213
-		std::size_t gt_index(SIZE_MAX);
-		{
-			field_cursor ff(format, ':');
-			std::string_view f;
-			for (std::size_t i(0); ff.next(f); ++i) if (f == "GT") { gt_index = i; break; }
-			if (SIZE_MAX == gt_index) bad(lineno, "variant does not have a genotype");
-		}
-		sample_fields.clear();
-		for (std::string_view f; fc.next(f);) sample_fields.push_back(f);
-		if (sample_fields.size() != vcf_sample_names.size()) bad(lineno, "sample column count differs from the header");
-
-		auto gt_of([&](std::size_t sample) -> std::string_view {
-			field_cursor sf(sample_fields[sample], ':');
-			std::string_view f;
-			for (std::size_t i(0); sf.next(f); ++i) if (i == gt_index) return f;
-			bad(lineno, "sample without GT");
-		});
-
-		if (is_first) {                                                                     // :215-288
-			is_first = false;
+		body_begin = std::min(pos, text.size());
+	}
+	ctx.n_samples = vcf_sample_names.size();
+	ctx.copy_begin.assign(ctx.n_samples + 1, 0);
+	bool have_first(false);
+	{
+		std::size_t pos(body_begin);
+		u64 lineno(header_lines);
+		while (pos < text.size() && !have_first) {
+			std::size_t eol(text.find('\n', pos));
+			if (std::string_view::npos == eol) eol = text.size();
+			std::string_view line(text.substr(pos, eol - pos));
+			pos = eol + 1;
+			++lineno;
+			if (!line.empty() && '\r' == line.back()) line.remove_suffix(1);
+			if (line.empty() || '#' == line.front()) continue;
+			field_cursor fc(line, '\t');
+			std::string_view f, format;
+			if (!fc.next(f)) continue;
+			if (f != ctx.wanted_chr) continue;
+			for (int i(1); i < 8; ++i) if (!fc.next(f)) bad(lineno, "fewer than 8 columns");
+			if (!fc.next(format)) bad(lineno, "variant does not have a genotype");
+			std::size_t gt_index(SIZE_MAX);
+			{
+				field_cursor ff(format, ':');
+				std::string_view x;
+				for (std::size_t i(0); ff.next(x); ++i) if (x == "GT") { gt_index = i; break; }
+				if (SIZE_MAX == gt_index) bad(lineno, "variant does not have a genotype");
+			}
 			std::vector<std::string> names;
 			std::vector<u32> ploidies;
 			u32 row(0);
-			for (std::size_t s(0); s < vcf_sample_names.size(); ++s) {
-				// alleles are separated by '|' or '/': count them
-				std::string_view const gt(gt_of(s));
+			std::size_t s(0);
+			for (std::string_view field; fc.next(field); ++s) {
+				if (s >= ctx.n_samples) bad(lineno, "more sample columns than in the header");
+				std::string_view gt;
+				{
+					field_cursor sf(field, ':');
+					std::size_t i(0);
+					bool found(false);
+					for (std::string_view x; sf.next(x); ++i) if (i == gt_index) { gt = x; found = true; break; }
+					if (!found) bad(lineno, "sample without GT");
+				}
 				u32 ploidy(1);
 				for (char const c : gt) if ('|' == c || '/' == c) ++ploidy;
 				u32 kept(0);
 				for (u32 c(0); c < ploidy; ++c) {
-					if (delegate.should_include(vcf_sample_names[s], c)) {
-						included.push_back({u32(s), c, row++});
-						++kept;
-					}
+					bool const inc(delegate.should_include(vcf_sample_names[s], c));       // :231
+					ctx.row_lookup.push_back(inc ? std::int32_t(row) : -1);
+					if (inc) { ++row; ++kept; }
 				}
+				ctx.copy_begin[s + 1] = u32(ctx.row_lookup.size());
 				if (kept) { names.push_back(vcf_sample_names[s]); ploidies.push_back(kept); }   // samples with no included copy are dropped (:250-273)
 			}
+			if (s != ctx.n_samples) bad(lineno, "sample column count differs from the header");
 			builder.begin(std::move(names), ploidies);
-			builder.on_overlap([&](overlap_info const &o) {
-				delegate.report_overlapping_alternative(lineno, o.ref_pos, cur_id, vcf_sample_names[cur_sample], cur_copy, o.alt_number);
-			});
-		}
-
-		++stats.handled_variants;
-		u64 ref_pos(0);
-		if (pos_f.empty()) bad(lineno, "empty POS");
-		for (char const c : pos_f) { if (c < '0' || '9' < c) bad(lineno, "bad POS"); ref_pos = 10 * ref_pos + u64(c - '0'); }
-		if (0 == ref_pos) bad(lineno, "POS must be 1-based");
-		--ref_pos;                                                                           // zero_based_pos (:292)
-
-		{                                                                                    // :307-314
-			std::string_view const expected(ref_pos <= ref_sv.size() ? ref_sv.substr(ref_pos, ref.size()) : std::string_view{});
-			if (ref != expected && !delegate.ref_column_mismatch(var_idx, ref_pos, ref, expected))
-				return;
-		}
-
-		cur_id = id;
-		alts.clear();
-		{
-			field_cursor ac(alt_f, ',');
-			for (std::string_view a; ac.next(a);) alts.push_back({classify_alt(a), a});
-		}
-		if (!builder.add_record(ref_pos, ref.size(), alts.data(), alts.size()))
-			throw std::runtime_error("variant " + std::to_string(var_idx) + " has non-increasing position");   // :293-297
-
-		// genotypes of the included copies (:379-425)
-		std::size_t k(0);
-		while (k < included.size()) {
-			u32 const s(included[k].sample_vcf_index);
-			std::string_view const gt(gt_of(s));
-			// walk the alleles of this sample once
-			u32 copy(0);
-			std::size_t a(0);
-			while (a <= gt.size() && k < included.size() && included[k].sample_vcf_index == s) {
-				std::size_t b(a);
-				while (b < gt.size() && '|' != gt[b] && '/' != gt[b]) ++b;
-				if (included[k].copy_vcf_index == copy) {
-					std::string_view const tok(gt.substr(a, b - a));
-					if (tok.empty()) bad(lineno, "empty GT allele");
-					if (tok != ".") {                                                        // NULL_ALLELE: skipped (:396-397)
-						u32 allele(0);
-						for (char const c : tok) { if (c < '0' || '9' < c) bad(lineno, "bad GT allele"); allele = 10 * allele + u32(c - '0'); }
-						if (allele) {
-							if (allele > alts.size()) bad(lineno, "GT allele exceeds the ALT count");
-							cur_sample = s; cur_copy = copy;
-							builder.set_genotype(included[k].row, allele);
-						}
-					}
-					++k;
-				}
-				++copy;
-				a = b + 1;
-			}
-			if (k < included.size() && included[k].sample_vcf_index == s)
-				bad(lineno, "GT has fewer alleles than in the first record");              // libbio_assert_lt(chr_idx_input, gt.size()), :390
+			have_first = true;
 		}
 	}
-
-	if (is_first) {
+	if (!have_first) {
 		// No record on the requested chromosome: the reference leaves ploidy_csum empty and then reads it
-		// out of bounds (hard part 10).  Here: all samples, ploidy 0 rows, REF only.
+		// out of bounds (hard part 10).  Here: no samples, REF only.
 		builder.begin({}, {});
+		for (std::size_t pos(body_begin); pos < text.size();) {
+			std::size_t eol(text.find('\n', pos));
+			if (std::string_view::npos == eol) eol = text.size();
+			if (eol > pos && '#' != text[pos]) ++stats.chr_id_mismatches;
+			pos = eol + 1;
+		}
+		builder.finish(ref_seq.size());
+		return;
 	}
-	builder.finish(ref_seq.size());                                                          // :437-451
+
+	// ---- chunks of whole lines, parsed by worker threads, merged in file order -------------------------------------
+	if (0 == threads) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+	std::size_t const target_chunk(std::size_t(8) << 20);
+	std::vector<std::pair<std::size_t, std::size_t>> ranges;
+	for (std::size_t b(body_begin); b < text.size();) {
+		std::size_t e(std::min(text.size(), b + target_chunk));
+		if (e < text.size()) {
+			std::size_t const nl(text.find('\n', e));
+			e = (std::string_view::npos == nl) ? text.size() : nl + 1;
+		}
+		ranges.emplace_back(b, e);
+		b = e;
+	}
+
+	std::size_t const n_chunks(ranges.size());
+	std::vector<parsed_chunk> chunks(n_chunks);
+	std::vector<char> ready(n_chunks, 0);
+	std::mutex mutex;
+	std::condition_variable cv_ready, cv_window;
+	std::size_t next_chunk(0), consumed(0);
+	std::size_t const window(std::max<std::size_t>(2, 2 * threads));
+	bool abort_workers(false);
+
+	auto const worker([&] {
+		for (;;) {
+			std::size_t idx;
+			{
+				std::unique_lock<std::mutex> lock(mutex);
+				cv_window.wait(lock, [&] { return abort_workers || next_chunk >= n_chunks || next_chunk < consumed + window; });
+				if (abort_workers || next_chunk >= n_chunks) return;
+				idx = next_chunk++;
+			}
+			parse_chunk(text.substr(ranges[idx].first, ranges[idx].second - ranges[idx].first), ctx, chunks[idx]);
+			{
+				std::lock_guard<std::mutex> lock(mutex);
+				ready[idx] = 1;
+			}
+			cv_ready.notify_all();
+		}
+	});
+	std::vector<std::thread> pool;
+	if (threads > 1)
+		for (unsigned t(0); t < std::min<std::size_t>(threads, n_chunks); ++t) pool.emplace_back(worker);
+	struct joiner {
+		std::vector<std::thread> &pool; std::mutex &mutex; std::condition_variable &cv; bool &abort_flag;
+		~joiner()
+		{
+			{ std::lock_guard<std::mutex> lock(mutex); abort_flag = true; }
+			cv.notify_all();
+			for (auto &t : pool) t.join();
+		}
+	} const join_on_exit{pool, mutex, cv_window, abort_workers};
+
+	u64 lineno_base(header_lines), var_idx(0);
+	std::string_view cur_id;
+	u32 cur_sample(0), cur_copy(0);
+	u64 cur_lineno(0);
+	builder.on_overlap([&](overlap_info const &o) {
+		delegate.report_overlapping_alternative(cur_lineno, o.ref_pos, cur_id, vcf_sample_names[cur_sample], cur_copy, o.alt_number);
+	});
+
+	for (std::size_t ci(0); ci < n_chunks; ++ci) {
+		if (threads > 1) {
+			std::unique_lock<std::mutex> lock(mutex);
+			cv_ready.wait(lock, [&] { return 0 != ready[ci]; });
+		} else {
+			parse_chunk(text.substr(ranges[ci].first, ranges[ci].second - ranges[ci].first), ctx, chunks[ci]);
+		}
+		parsed_chunk &chunk(chunks[ci]);
+		// records parsed before an error are still merged first, so errors surface in file order
+		for (auto const &rec : chunk.records) {
+			++stats.handled_variants;
+			cur_lineno = lineno_base + rec.line_in_chunk;
+			cur_id = rec.id;
+			u64 const this_var(var_idx + rec.data_line_in_chunk);
+			{                                                                            // :307-314
+				std::string_view const expected(rec.ref_pos <= ref_sv.size() ? ref_sv.substr(rec.ref_pos, rec.ref.size()) : std::string_view{});
+				if (rec.ref != expected && !delegate.ref_column_mismatch(this_var, rec.ref_pos, rec.ref, expected))
+					return;
+			}
+			if (!builder.add_record(rec.ref_pos, rec.ref.size(), chunk.alts.data() + rec.alt_begin, rec.n_alts))
+				throw std::runtime_error("variant " + std::to_string(this_var) + " has non-increasing position");   // :293-297
+			for (u64 k(rec.geno_begin); k < rec.geno_end; ++k) {
+				auto const &gt(chunk.genos[k]);
+				cur_sample = gt.sample; cur_copy = gt.copy;
+				builder.set_genotype(gt.row, gt.alt_number);
+			}
+		}
+		if (!chunk.error.empty()) bad(lineno_base + chunk.error_line, chunk.error.c_str());
+		stats.chr_id_mismatches += chunk.chr_mismatches;
+		lineno_base += chunk.n_lines;
+		var_idx += chunk.n_data_lines;
+		parsed_chunk().records.swap(chunk.records);   // release the chunk's memory
+		std::vector<parsed_genotype>().swap(chunk.genos);
+		std::vector<alt_allele>().swap(chunk.alts);
+		if (threads > 1) {
+			{ std::lock_guard<std::mutex> lock(mutex); consumed = ci + 1; }
+			cv_window.notify_all();
+		}
+	}
+	builder.finish(ref_seq.size());                                                      // :437-451
 }
 
 } // namespace v2m::host

@@ -38,8 +38,13 @@ struct build_graph_statistics {
 // build_variant_graph (variant_graph.cc:108-454) up to, but not including, the final transpose at :453:
 // paths_by_edge_and_chrom_copy is filled, paths_by_chrom_copy_and_edge is left for the GPU
 // (gpu_path.hh: transpose_paths).  Throws std::runtime_error on malformed input.
+//
+// The reference parses and builds on one thread.  Here the genotype text -- 5 * 10^9 fields at config 3 -- is
+// parsed by `threads` workers over 8-MB chunks of whole lines into sparse (copy, allele) lists, and one thread
+// merges the chunks in file order through graph_builder, so the graph and the delegate calls are exactly those
+// of a sequential pass.  threads == 0: one per hardware thread, at most 16.
 void build_variant_graph(
 	sequence_type const &ref_seq, char const *variants_path, char const *chr_id,
-	variant_graph &graph, build_graph_statistics &stats, build_graph_delegate &delegate);
+	variant_graph &graph, build_graph_statistics &stats, build_graph_delegate &delegate, unsigned threads = 0);
 
 } // namespace v2m::host

@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 
 #include "../host/graph_builder.hh"
 
@@ -87,6 +88,7 @@ void generate(config const &cfg, dataset &out)
 	}
 
 	out.graph = host::variant_graph{};
+	out.records.clear();
 	out.edge_thresholds.clear();
 	host::graph_builder builder(out.graph, /* track_paths */ false);
 	std::string alt_a, alt_b;
@@ -121,9 +123,63 @@ void generate(config const &cfg, dataset &out)
 		}
 		alts[0] = {host::alt_kind::sequence, alt_a};
 		builder.add_record(pos, ref_len, alts, n_alts);
+		{
+			record r;
+			r.pos = pos; r.ref_length = u32(ref_len); r.n_alts = u32(n_alts); r.first_edge = builder.edge_for_alt(0);
+			r.alts[0] = alt_a;
+			if (n_alts > 1) r.alts[1] = alt_b;
+			out.records.push_back(std::move(r));
+		}
 		for (std::size_t a(0); a < n_alts; ++a) out.edge_thresholds.push_back(draw_threshold(rng));
 	}
 	builder.finish(R);
+}
+
+
+bool write_fasta_and_vcf(dataset const &ds, u64 seed, u32 samples, u32 ploidy, char const *chromosome, char const *fasta_path, char const *vcf_path)
+{
+	{
+		FILE *f(std::fopen(fasta_path, "wb"));
+		if (!f) return false;
+		std::fprintf(f, ">%s synthetic\n", chromosome);
+		for (u64 i(0); i < ds.reference.size(); i += 80) {
+			u64 const n(std::min<u64>(80, ds.reference.size() - i));
+			std::fwrite(ds.reference.data() + i, 1, n, f);
+			std::fputc('\n', f);
+		}
+		if (0 != std::fclose(f)) return false;
+	}
+	FILE *f(std::fopen(vcf_path, "wb"));
+	if (!f) return false;
+	std::vector<char> buf(1 << 22);
+	std::setvbuf(f, buf.data(), _IOFBF, buf.size());
+	std::fputs("##fileformat=VCFv4.2\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT", f);
+	for (u32 s(0); s < samples; ++s) std::fprintf(f, "\tS%u", s);
+	std::fputc('\n', f);
+	std::string line;
+	u64 idx(0);
+	for (auto const &r : ds.records) {
+		line.clear();
+		line += chromosome; line += '\t'; line += std::to_string(r.pos + 1); line += "\tv"; line += std::to_string(idx++); line += '\t';
+		line.append(ds.reference, r.pos, r.ref_length); line += '\t';
+		line += r.alts[0];
+		if (r.n_alts > 1) { line += ','; line += r.alts[1]; }
+		line += "\t.\tPASS\t.\tGT";
+		for (u32 s(0); s < samples; ++s) {
+			line += '\t';
+			for (u32 c(0); c < ploidy; ++c) {
+				if (c) line += '|';
+				u64 const copy(u64(s) * ploidy + c);
+				char allele('0');
+				for (u32 a(0); a < r.n_alts; ++a)
+					if (path_bit(seed, r.first_edge + a, copy, ds.edge_thresholds[r.first_edge + a])) { allele = char('1' + a); break; }
+				line += allele;
+			}
+		}
+		line += '\n';
+		std::fwrite(line.data(), 1, line.size(), f);
+	}
+	return 0 == std::fclose(f);
 }
 
 } // namespace v2m::synth

@@ -31,13 +31,27 @@ struct config {
 	u32 max_indel{32};
 };
 
+struct record {
+	u64 pos{};            // 0-based
+	u32 ref_length{};
+	u32 n_alts{};
+	u64 first_edge{};     // edge of ALT 1; ALT k is first_edge + k - 1
+	std::string alts[2];
+};
+
 struct dataset {
+	std::vector<record> records;
 	std::string reference;
 	host::variant_graph graph;            // nodes, edges, labels; no path matrices
 	std::vector<u32> edge_thresholds;     // P(copy carries edge) * 2^32, per edge
 };
 
 void generate(config const &cfg, dataset &out);
+
+// The same dataset as text: a single-sequence FASTA and a VCF with `samples` samples of the given ploidy whose
+// genotypes follow the genotype hash (per copy: the first ALT of the record whose edge bit is set, else 0), so
+// that the text pipeline can be run on exactly what the direct generator produces.  Returns false on I/O errors.
+bool write_fasta_and_vcf(dataset const &ds, u64 seed, u32 samples, u32 ploidy, char const *chromosome, char const *fasta_path, char const *vcf_path);
 
 // The genotype hash shared by the device kernel and the CPU check.
 inline u64 mix64(u64 z)

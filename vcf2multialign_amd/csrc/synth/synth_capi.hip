@@ -81,6 +81,11 @@ uint64_t const *v2ms_label_offsets(void *h) { return D(h).graph.alt_edge_label_o
 char const *v2ms_label_bytes(void *h) { return D(h).graph.alt_edge_label_bytes.data(); }
 uint32_t const *v2ms_edge_thresholds(void *h) { return D(h).edge_thresholds.data(); }
 
+int v2ms_write_fasta_and_vcf(void *h, uint64_t seed, uint32_t samples, uint32_t ploidy, char const *chromosome, char const *fasta_path, char const *vcf_path)
+{
+	return v2m::synth::write_fasta_and_vcf(D(h), seed, samples, ploidy, chromosome, fasta_path, vcf_path) ? 0 : 1;
+}
+
 // Fills a (n_rows x n_cols)-bit column-major matrix in HBM (rows = the chromosome copies
 // [copy_base, copy_base + n_rows) of n_copies in total, cols = edges) on `stream` (a hipStream_t).
 // Returns 0 on success, a hipError_t otherwise.

@@ -23,7 +23,7 @@ def _load():
 			pass
 		L = C.CDLL(_build.HOST_LIB_PATH)
 		L.v2mh_build_variant_graph.restype = C.c_void_p
-		L.v2mh_build_variant_graph.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]
+		L.v2mh_build_variant_graph.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint, C.c_char_p, C.c_size_t]
 		L.v2mh_free.argtypes = [C.c_void_p]
 		for n in ("node_count", "edge_count", "sample_count", "ref_length", "sample_blob_size", "ploidy_csum_size", "handled_variants", "chr_id_mismatches", "overlap_count"):
 			f = getattr(L, "v2mh_" + n)
@@ -55,11 +55,11 @@ def _arr(ptr, n, dtype):
 class HostGraph:
 	"""Result of the host's build_variant_graph (without the final transpose)."""
 
-	def __init__(self, fasta_path, vcf_path, chr_id, seq_id=None, exclude_sample=None, exclude_copy=-1):
+	def __init__(self, fasta_path, vcf_path, chr_id, seq_id=None, exclude_sample=None, exclude_copy=-1, threads=0):
 		L = _load()
 		err = C.create_string_buffer(512)
 		h = L.v2mh_build_variant_graph(str(fasta_path).encode(), seq_id.encode() if seq_id else None, str(vcf_path).encode(), chr_id.encode(),
-			exclude_sample.encode() if exclude_sample else None, exclude_copy, err, len(err))
+			exclude_sample.encode() if exclude_sample else None, exclude_copy, threads, err, len(err))
 		if not h:
 			raise ValueError(err.value.decode())
 		self._h = h

@@ -61,6 +61,8 @@ def _load():
 			f.argtypes = [C.c_void_p]
 		L.v2ms_fill_paths_device.restype = C.c_int
 		L.v2ms_fill_paths_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
+		L.v2ms_write_fasta_and_vcf.restype = C.c_int
+		L.v2ms_write_fasta_and_vcf.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_char_p, C.c_char_p, C.c_char_p]
 		L.v2ms_copy_column.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64]
 		_lib = L
 	return _lib
@@ -112,6 +114,12 @@ class Dataset:
 		rc = _load().v2ms_fill_paths_device(stream, d_words, n_rows, self.path_rows, copy_base, self.n_copies, self.graph.edge_count, d_thresholds, self.seed)
 		if rc != 0:
 			raise RuntimeError("fill_paths_kernel launch failed (%d)" % rc)
+
+	def write_fasta_and_vcf(self, fasta_path, vcf_path, chromosome="1"):
+		"""The same dataset as FASTA + VCF text (genotypes from the same hash), for the text pipeline."""
+		rc = _load().v2ms_write_fasta_and_vcf(self._h, self.seed, self.samples, self.ploidy, chromosome.encode(), str(fasta_path).encode(), str(vcf_path).encode())
+		if rc != 0:
+			raise OSError("could not write " + str(vcf_path))
 
 	def copy_column(self, copy):
 		"""CPU re-derivation of chromosome copy `copy`'s column of paths_by_chrom_copy_and_edge (Ep/64 words)."""
