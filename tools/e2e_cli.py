@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Config 2 through the whole text pipeline: synthetic FASTA + VCF (400 MB) -> bin/vcf2multialign --haplotypes -> A2M
+(20 GB) into /dev/null, wall-clock per stage from the driver's own log lines."""
+import os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vcf2multialign_amd import synth, build
+cfg = sys.argv[1] if len(sys.argv) > 1 else "config2"
+tmp = os.environ.get("TMPDIR", "/tmp")
+fa, vcf = os.path.join(tmp, cfg + ".fa"), os.path.join(tmp, cfg + ".vcf")
+t = time.time(); ds = synth.dataset(cfg); ds.write_fasta_and_vcf(fa, vcf)
+print("generated %s: VCF %.0f MB in %.1f s" % (cfg, os.path.getsize(vcf) / 1e6, time.time() - t), flush=True)
+t = time.time()
+p = subprocess.Popen([build.CLI_PATH, "-H", "-r", fa, "-a", vcf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+marks = []
+for line in p.stderr:
+	marks.append((time.time() - t, line.rstrip()))
+p.wait()
+total = time.time() - t
+for m in marks:
+	print("  %7.2f s  %s" % m)
+print(p.stdout.read().strip())
+rows, L = ds.n_copies + 1, ds.graph.aligned_length
+print("exit %d; total %.2f s for %d rows x %d bases = %.1f Gbases -> %.2f Gbases/s end to end incl. VCF parsing" % (p.returncode, total, rows, L, rows * L / 1e9, rows * L / total / 1e9))
+os.remove(vcf); os.remove(fa)
