@@ -430,13 +430,150 @@ struct tile_tables {
 	u32 const *cross_edges;    // edges with aln_begin < t*kTileBytes < aln_end, ascending
 };
 
+// Bytes [from, to) of an edge's aligned span: label bytes first, then padding.
+template <typename LabelPtr>
 __device__ __forceinline__ void fill_patch_bytes(
-	unsigned char *tile, u32 tile_base, edge_patch const p, char const *__restrict__ labels,
+	unsigned char *tile, u32 tile_base, u32 aln_begin, u32 label_len, LabelPtr label,
 	u32 from, u32 to, u32 start, u32 step, char gap)
 {
 	for (u32 pos = from + start; pos < to; pos += step) {
-		u32 const off = pos - p.aln_begin;
-		tile[pos - tile_base] = (off < p.label_len) ? (unsigned char) labels[p.label_begin + off] : (unsigned char) gap;
+		u32 const off = pos - aln_begin;
+		tile[pos - tile_base] = (off < label_len) ? (unsigned char) label[off] : (unsigned char) gap;
+	}
+}
+
+// Per-workgroup cache of everything the row loop needs about the tile's candidate edges, so that the loop itself
+// touches only LDS: the patch descriptors and label bytes of the edges that begin in the tile (a contiguous
+// edge range, hence a contiguous slice of `patches` and of the label pool) and the effective-edge words of every
+// row of the group for that range.  Without it each row pays three dependent L2 round trips (effective bits ->
+// descriptor -> label bytes) between its two barriers, which is what bounds the kernel on dense graphs
+// (config 5: one edge per 40 bp).  Edges that cross into the tile from the left, candidates beyond the cache
+// and spans longer than kLongPatch take the global-memory path.
+constexpr int kCandLds = 512;
+constexpr int kLabelLds = 2048;
+constexpr int kGroupRowsLds = 16;
+constexpr int kEffWordsLds = kCandLds / 64 + 2;
+constexpr int kLongQueueLds = 16;
+
+// 8-byte form of an edge_patch relative to the tile; 0xFFFF in span or label_rel means "not representable here,
+// read the full descriptor from global memory" (span >= 64 KiB, or label bytes outside the cached slice).
+struct cached_patch {
+	unsigned short begin_rel;   // aln_begin - tile_base (< kTileBytes: the edge begins in this tile)
+	unsigned short span;        // aln_end - aln_begin
+	unsigned short label_rel;   // label_begin - label_base
+	unsigned short label_len;
+};
+
+struct patch_cache {
+	cached_patch patch[kCandLds];
+	u64 eff[kGroupRowsLds][kEffWordsLds];
+	unsigned char labels[kLabelLds];
+	u32 long_queue[kLongQueueLds];
+	u32 long_count;
+};
+
+struct tile_job {
+	u32 tile_base, cross_begin, n_cross, range_begin, n_range;
+	u32 n_lds;          // candidates of the range cached in LDS
+	u32 w0;             // first effective-bit word cached
+};
+
+__device__ __forceinline__ void load_patch_cache(
+	patch_cache &pc, tile_job &job, tile_tables const &tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
+	u64 const *__restrict__ eff, u64 eff_words_per_row, u32 tile, u32 row_begin, u32 n_group_rows, int t)
+{
+	job.tile_base = tile * (u32) kTileBytes;
+	job.cross_begin = tt.cross_offsets[tile];
+	job.n_cross = tt.cross_offsets[tile + 1] - job.cross_begin;
+	job.range_begin = tt.edge_begin[tile];
+	job.n_range = tt.edge_begin[tile + 1] - job.range_begin;
+	job.n_lds = job.n_range < (u32) kCandLds ? job.n_range : (u32) kCandLds;
+	job.w0 = job.range_begin >> 6;
+	if (job.n_lds) {
+		u32 const label_base = patches[job.range_begin].label_begin;
+		for (u32 i = t; i < job.n_lds; i += kSpliceThreads) {
+			edge_patch const p = patches[job.range_begin + i];
+			u32 const span = p.aln_end - p.aln_begin, rel = p.label_begin - label_base;
+			cached_patch c;
+			c.begin_rel = (unsigned short) (p.aln_begin - job.tile_base);
+			c.span = span < 0xFFFFu ? (unsigned short) span : (unsigned short) 0xFFFF;
+			bool const label_ok = rel + p.label_len <= (u32) kLabelLds;
+			c.label_rel = label_ok ? (unsigned short) rel : (unsigned short) 0xFFFF;
+			c.label_len = label_ok ? (unsigned short) p.label_len : (unsigned short) 0;
+			pc.patch[i] = c;
+		}
+		edge_patch const last = patches[job.range_begin + job.n_lds - 1];
+		u32 const label_span = last.label_begin + last.label_len - label_base;
+		u32 const label_len = label_span < (u32) kLabelLds ? label_span : (u32) kLabelLds;
+		for (u32 i = t; i < label_len; i += kSpliceThreads)
+			pc.labels[i] = (unsigned char) labels[label_base + i];
+		u32 const nw = ((job.range_begin + job.n_lds - 1) >> 6) - job.w0 + 1;   // <= kEffWordsLds
+		u32 const rows = n_group_rows < (u32) kGroupRowsLds ? n_group_rows : (u32) kGroupRowsLds;
+		for (u32 i = t; i < rows * nw; i += kSpliceThreads)
+			pc.eff[i / nw][i % nw] = eff[(u64) (row_begin + i / nw) * eff_words_per_row + job.w0 + i % nw];
+	}
+	if (t == 0) pc.long_count = 0;
+	// visibility: the caller's next __syncthreads() (after it has dropped the pristine tile into LDS)
+}
+
+// Overwrites, in the LDS tile `buf`, the spans of the row's effective edges.  Contains the barriers that separate
+// it from the tile's readers; must be called by all threads of the workgroup.
+__device__ __forceinline__ void patch_row_tile(
+	unsigned char *buf, patch_cache &pc, tile_job const &job, tile_tables const &tt,
+	edge_patch const *__restrict__ patches, char const *__restrict__ labels,
+	u64 const *__restrict__ eff_row, u32 local_row, int t, char gap)
+{
+	u32 const n_cand = job.n_cross + job.n_range;
+	u32 const tile_end = job.tile_base + kTileBytes;
+	for (u32 i = t; i < n_cand; i += kSpliceThreads) {
+		bool cached = i >= job.n_cross && i - job.n_cross < job.n_lds && local_row < (u32) kGroupRowsLds;
+		u32 e;
+		bool set;
+		if (cached) {
+			e = job.range_begin + (i - job.n_cross);
+			set = (pc.eff[local_row][(e >> 6) - job.w0] >> (e & 63)) & 1;
+		} else {
+			e = (i < job.n_cross) ? tt.cross_edges[job.cross_begin + i] : job.range_begin + (i - job.n_cross);
+			set = (eff_row[e >> 6] >> (e & 63)) & 1;
+		}
+		if (!set) continue;
+		cached_patch c{};
+		if (cached) {
+			c = pc.patch[i - job.n_cross];
+			cached = c.span != 0xFFFF && c.label_rel != 0xFFFF;
+		}
+		if (cached) {
+			u32 const from = job.tile_base + c.begin_rel;
+			u32 const to = from + c.span < tile_end ? from + c.span : tile_end;
+			if (to - from > kLongPatch) {
+				u32 const slot = atomicAdd(&pc.long_count, 1u);
+				if (slot < (u32) kLongQueueLds) { pc.long_queue[slot] = e; continue; }
+			}
+			fill_patch_bytes(buf, job.tile_base, from, c.label_len, pc.labels + c.label_rel, from, to, 0, 1, gap);
+		} else {
+			edge_patch const p = patches[e];
+			u32 const from = p.aln_begin > job.tile_base ? p.aln_begin : job.tile_base;
+			u32 const to = p.aln_end < tile_end ? p.aln_end : tile_end;
+			if (to - from > kLongPatch) {
+				u32 const slot = atomicAdd(&pc.long_count, 1u);
+				if (slot < (u32) kLongQueueLds) { pc.long_queue[slot] = e; continue; }
+			}
+			fill_patch_bytes(buf, job.tile_base, p.aln_begin, p.label_len, labels + p.label_begin, from, to, 0, 1, gap);
+		}
+	}
+	__syncthreads();
+
+	u32 const n_long = pc.long_count < (u32) kLongQueueLds ? pc.long_count : (u32) kLongQueueLds;   // workgroup-uniform
+	if (n_long) {
+		// long spans (big deletions, long insertions): one wave per span, 64 bytes per step
+		for (u32 q = t >> 6; q < n_long; q += kSpliceThreads >> 6) {
+			edge_patch const p = patches[pc.long_queue[q]];
+			u32 const from = p.aln_begin > job.tile_base ? p.aln_begin : job.tile_base;
+			u32 const to = p.aln_end < tile_end ? p.aln_end : tile_end;
+			fill_patch_bytes(buf, job.tile_base, p.aln_begin, p.label_len, labels + p.label_begin, from, to, t & 63, 64, gap);
+		}
+		__syncthreads();
+		if (t == 0) pc.long_count = 0;   // next read is after the next row's first barrier
 	}
 }
 
@@ -463,25 +600,22 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_aligned_kernel(
 	u64 store_limit /* aligned length rounded up to 16 */, char gap)
 {
 	__shared__ vec4u lds[2][kTileChunks];
-	__shared__ u32 long_queue[kLongQueue];
-	__shared__ u32 long_count;
+	__shared__ patch_cache pc;
 
 	int const t = threadIdx.x;
 	u32 tile, group;
 	map_block(blockIdx.x, n_groups, n_tiles, tile_run, tile, group);
 	u32 const row_begin = group * rows_per_group;
 	u32 const row_end = (row_begin + rows_per_group < n_rows) ? row_begin + rows_per_group : n_rows;
-	u32 const tile_base = tile * (u32) kTileBytes;
 
 	vec4u pristine[kChunksPerThread];
 #pragma unroll
 	for (int k = 0; k < kChunksPerThread; ++k)
 		pristine[k] = tmpl[(u64) tile * kTileChunks + t + kSpliceThreads * k];
 
-	u32 const cross_begin = tt.cross_offsets[tile], n_cross = tt.cross_offsets[tile + 1] - cross_begin;
-	u32 const range_begin = tt.edge_begin[tile], n_range = tt.edge_begin[tile + 1] - range_begin;
-	u32 const n_cand = n_cross + n_range;
-	if (t == 0) long_count = 0;
+	tile_job job;
+	load_patch_cache(pc, job, tt, patches, labels, eff, eff_words_per_row, tile, row_begin, row_end - row_begin, t);
+	u32 const tile_base = job.tile_base;
 
 	for (u32 row = row_begin; row < row_end; ++row) {
 		vec4u *const buf = lds[(row - row_begin) & 1];
@@ -490,36 +624,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_aligned_kernel(
 			buf[t + kSpliceThreads * k] = pristine[k];
 		__syncthreads();
 
-		u64 const *const eff_row = eff + (u64) row * eff_words_per_row;
-		for (u32 i = t; i < n_cand; i += kSpliceThreads) {
-			u32 const e = (i < n_cross) ? tt.cross_edges[cross_begin + i] : range_begin + (i - n_cross);
-			if ((eff_row[e >> 6] >> (e & 63)) & 1) {
-				edge_patch const p = patches[e];
-				u32 const from = p.aln_begin > tile_base ? p.aln_begin : tile_base;
-				u32 const to = p.aln_end < tile_base + kTileBytes ? p.aln_end : tile_base + kTileBytes;
-				if (to - from > kLongPatch) {
-					u32 const slot = atomicAdd(&long_count, 1u);
-					if (slot < kLongQueue) long_queue[slot] = e;
-					else fill_patch_bytes((unsigned char *) buf, tile_base, p, labels, from, to, 0, 1, gap);
-				} else {
-					fill_patch_bytes((unsigned char *) buf, tile_base, p, labels, from, to, 0, 1, gap);
-				}
-			}
-		}
-		__syncthreads();
-
-		u32 const n_long = long_count < kLongQueue ? long_count : kLongQueue;   // block-uniform
-		if (n_long) {
-			// long spans (big deletions, long insertions): one wave per span, 64 bytes per step
-			for (u32 q = t >> 6; q < n_long; q += kSpliceThreads >> 6) {
-				edge_patch const p = patches[long_queue[q]];
-				u32 const from = p.aln_begin > tile_base ? p.aln_begin : tile_base;
-				u32 const to = p.aln_end < tile_base + kTileBytes ? p.aln_end : tile_base + kTileBytes;
-				fill_patch_bytes((unsigned char *) buf, tile_base, p, labels, from, to, t & 63, 64, gap);
-			}
-			__syncthreads();
-			if (t == 0) long_count = 0;   // next read is after the next row's first barrier
-		}
+		patch_row_tile((unsigned char *) buf, pc, job, tt, patches, labels, eff + (u64) row * eff_words_per_row, row - row_begin, t, gap);
 
 		char *const dst = out + (u64) row * row_pitch + (u64) tile * kTileBytes;
 #pragma unroll
@@ -565,8 +670,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 {
 	__shared__ vec4u lds[kTileChunks];
 	__shared__ vec4u comp[kTileChunks + 1];
-	__shared__ u32 long_queue[kLongQueue];
-	__shared__ u32 long_count;
+	__shared__ patch_cache pc;
 	__shared__ u32 wave_sums[kSpliceThreads / 64];
 
 	int const t = threadIdx.x;
@@ -575,17 +679,14 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	map_block(blockIdx.x, n_groups, n_tiles, tile_run, tile, group);
 	u32 const row_begin = group * rows_per_group;
 	u32 const row_end = (row_begin + rows_per_group < n_rows) ? row_begin + rows_per_group : n_rows;
-	u32 const tile_base = tile * (u32) kTileBytes;
 
 	vec4u pristine[kChunksPerThread];
 #pragma unroll
 	for (int k = 0; k < kChunksPerThread; ++k)
 		pristine[k] = tmpl0[(u64) tile * kTileChunks + t + kSpliceThreads * k];
 
-	u32 const cross_begin = tt.cross_offsets[tile], n_cross = tt.cross_offsets[tile + 1] - cross_begin;
-	u32 const range_begin = tt.edge_begin[tile], n_range = tt.edge_begin[tile + 1] - range_begin;
-	u32 const n_cand = n_cross + n_range;
-	if (t == 0) long_count = 0;
+	tile_job job;
+	load_patch_cache(pc, job, tt, patches, labels, eff, eff_words_per_row, tile, row_begin, row_end - row_begin, t);
 
 	for (u32 row = row_begin; row < row_end; ++row) {
 		__syncthreads();   // the previous row's readers of lds/comp are done
@@ -594,34 +695,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			lds[t + kSpliceThreads * k] = pristine[k];
 		__syncthreads();
 
-		u64 const *const eff_row = eff + (u64) row * eff_words_per_row;
-		for (u32 i = t; i < n_cand; i += kSpliceThreads) {
-			u32 const e = (i < n_cross) ? tt.cross_edges[cross_begin + i] : range_begin + (i - n_cross);
-			if ((eff_row[e >> 6] >> (e & 63)) & 1) {
-				edge_patch const p = patches[e];
-				u32 const from = p.aln_begin > tile_base ? p.aln_begin : tile_base;
-				u32 const to = p.aln_end < tile_base + kTileBytes ? p.aln_end : tile_base + kTileBytes;
-				if (to - from > kLongPatch) {
-					u32 const slot = atomicAdd(&long_count, 1u);
-					if (slot < kLongQueue) long_queue[slot] = e;
-					else fill_patch_bytes((unsigned char *) lds, tile_base, p, labels, from, to, 0, 1, 0);
-				} else {
-					fill_patch_bytes((unsigned char *) lds, tile_base, p, labels, from, to, 0, 1, 0);
-				}
-			}
-		}
-		__syncthreads();
-		u32 const n_long = long_count < kLongQueue ? long_count : kLongQueue;
-		if (n_long) {
-			for (u32 q = wave; q < n_long; q += kSpliceThreads >> 6) {
-				edge_patch const p = patches[long_queue[q]];
-				u32 const from = p.aln_begin > tile_base ? p.aln_begin : tile_base;
-				u32 const to = p.aln_end < tile_base + kTileBytes ? p.aln_end : tile_base + kTileBytes;
-				fill_patch_bytes((unsigned char *) lds, tile_base, p, labels, from, to, lane, 64, 0);
-			}
-			__syncthreads();
-			if (t == 0) long_count = 0;
-		}
+		patch_row_tile((unsigned char *) lds, pc, job, tt, patches, labels, eff + (u64) row * eff_words_per_row, row - row_begin, t, 0);
 
 		// each thread owns 64 contiguous tile bytes: count what survives
 		vec4u v[4];
