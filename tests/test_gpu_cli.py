@@ -126,6 +126,25 @@ def test_founders_on_a_larger_graph(tmp_path):
 		assert lines[3 + 2 * f] == g.output_sequence(g.ref, cuts=list(zip(cuts[:-1], col))), "founder %d" % (1 + f)
 
 
+def test_graph_checkpoint(tmp_path):
+	"""--output-graph then --input-graph: the second run skips the VCF and writes the same A2M (both modes)."""
+	g = synth.build_case(tmp_path, 64, 60000, 900, 12, long_every=200)
+	fa, vcf = str(tmp_path / "synth.fa"), str(tmp_path / "synth.vcf")
+	graph, a, b = tmp_path / "g.graph", tmp_path / "a.a2m", tmp_path / "b.a2m"
+	r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(a), "--output-graph=" + str(graph)])
+	assert r.returncode == 0, r.stderr.decode()
+	r = run(["-H", "-r", fa, "--input-graph=" + str(graph), "-s", str(b)])
+	assert r.returncode == 0, r.stderr.decode()
+	assert b"Building the variant graph" not in r.stderr
+	exp = tmp_path / "exp.a2m"
+	g.haplotype_output_a2m(g.ref, str(exp))
+	assert a.read_bytes() == exp.read_bytes() == b.read_bytes()
+	r1 = run(["-F", "5", "-r", fa, "-a", vcf, "-c", "1", "-s", str(a)])
+	r2 = run(["-F", "5", "-r", fa, "-g", str(graph), "-s", str(b)])
+	assert r1.returncode == 0 and r2.returncode == 0 and a.read_bytes() == b.read_bytes() and r1.stdout == r2.stdout
+	assert run(["-H", "-r", fa, "-g", str(graph), "-a", vcf, "-c", "1", "-s", str(b)]).returncode != 0
+
+
 def test_unsupported_and_bad_arguments():
 	assert run(["--founder-sequences=0", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
 	assert run(["-H", "--founder-sequences=2", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0

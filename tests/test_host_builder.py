@@ -160,3 +160,30 @@ def test_errors_surface_in_file_order(HostGraph, tmp_path):
 	with pytest.raises(ValueError) as e:
 		HostGraph(str(fa), str(vcf), "1", threads=3)
 	assert "line 4" in str(e.value) and "bad GT allele" in str(e.value)
+
+
+def test_graph_file_round_trip(HostGraph, tmp_path):
+	"""--output-graph / --input-graph (our flat format in place of the reference's cereal archive, main.cc:393-426)."""
+	g = synth.build_case(tmp_path, 130, 20000, 400, 70, multi_allelic=0.2)   # 140 copies
+	fa, vcf = str(tmp_path / "synth.fa"), str(tmp_path / "synth.vcf")
+	h = HostGraph(fa, vcf, "1")
+	path = tmp_path / "g.graph"
+	h.write(path)
+	r = HostGraph.read(path)
+	for k in ARRAYS:
+		assert np.array_equal(getattr(h, k), getattr(r, k)), k
+	assert h.label_bytes == r.label_bytes and h.sample_names == r.sample_names
+	assert h.paths_by_edge_and_chrom_copy_dims == r.paths_by_edge_and_chrom_copy_dims
+	assert g.edge_count == len(r.alt_edge_targets)
+	data = bytearray(path.read_bytes())
+	data[len(data) // 2] ^= 0x40
+	bad = tmp_path / "bad.graph"
+	bad.write_bytes(bytes(data))
+	with pytest.raises(ValueError, match="checksum"):
+		HostGraph.read(bad)
+	bad.write_bytes(bytes(data[:len(data) // 3]))
+	with pytest.raises(ValueError):
+		HostGraph.read(bad)
+	bad.write_bytes(b"not a graph file at all, just text\n" * 10)
+	with pytest.raises(ValueError, match="V2MGRAF1"):
+		HostGraph.read(bad)

@@ -41,8 +41,8 @@ def _stale(target, deps):
 # C++ host: graph builder, readers, output classes (libv2m_host.so) and the command-line driver
 HOST_LIB_PATH = os.path.join(PKG_DIR, "libv2m_host.so")
 HOST_DIR = os.path.join(CSRC, "host")
-HOST_SOURCES = [os.path.join(HOST_DIR, f) for f in ("graph_builder.cc", "readers.cc", "gpu_path.cc", "output.cc", "founder.cc", "host_capi.cc")]
-HOST_DEPS = HOST_SOURCES + [os.path.join(HOST_DIR, f) for f in ("graph_builder.hh", "readers.hh", "gpu_path.hh", "output.hh", "founder.hh", "variant_graph.hh")] + [os.path.join(ROOT, "include", "v2m_hip.h")]
+HOST_SOURCES = [os.path.join(HOST_DIR, f) for f in ("graph_builder.cc", "readers.cc", "gpu_path.cc", "output.cc", "founder.cc", "graph_file.cc", "host_capi.cc")]
+HOST_DEPS = HOST_SOURCES + [os.path.join(HOST_DIR, f) for f in ("graph_builder.hh", "readers.hh", "gpu_path.hh", "output.hh", "founder.hh", "graph_file.hh", "variant_graph.hh")] + [os.path.join(ROOT, "include", "v2m_hip.h")]
 CLI_PATH = os.path.join(PKG_DIR, "bin", "vcf2multialign")
 CLI_SOURCES = [os.path.join(HOST_DIR, "main.cc")]
 CXX_FLAGS = ["-O2", "-g", "-std=c++20", "-Wall", "-Wextra"]

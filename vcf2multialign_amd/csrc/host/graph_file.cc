@@ -1,0 +1,137 @@
+#include "graph_file.hh"
+
+#include <cstdio>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+
+namespace v2m::host {
+
+namespace {
+
+char const kMagic[8] = {'V', '2', 'M', 'G', 'R', 'A', 'F', '1'};
+
+u64 mix64(u64 z)
+{
+	z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+	z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+	z ^= z >> 31;
+	return z;
+}
+
+struct writer {
+	std::FILE *f;
+	u64 index{}, sum{};
+	void words(void const *p, u64 n_bytes)   // n_bytes is padded to 8 with zeros
+	{
+		auto const *b(static_cast<unsigned char const *>(p));
+		u64 const full(n_bytes / 8);
+		for (u64 i(0); i < full; ++i) { u64 w; std::memcpy(&w, b + 8 * i, 8); sum += mix64(index++ ^ w); }
+		if (full && 1 != std::fwrite(b, 8 * full, 1, f)) throw std::runtime_error("write error");
+		if (n_bytes % 8) {
+			u64 w(0);
+			std::memcpy(&w, b + 8 * full, n_bytes % 8);
+			sum += mix64(index++ ^ w);
+			if (1 != std::fwrite(&w, 8, 1, f)) throw std::runtime_error("write error");
+		}
+	}
+};
+
+struct reader {
+	std::FILE *f;
+	u64 index{}, sum{};
+	void words(void *p, u64 n_bytes)
+	{
+		u64 const padded((n_bytes + 7) & ~u64(7));
+		std::vector<unsigned char> tmp;
+		unsigned char *dst(static_cast<unsigned char *>(p));
+		if (padded != n_bytes) { tmp.resize(padded); dst = tmp.data(); }
+		if (padded && 1 != std::fread(dst, padded, 1, f)) throw std::runtime_error("unexpected end of graph file");
+		for (u64 i(0); i < padded / 8; ++i) { u64 w; std::memcpy(&w, dst + 8 * i, 8); sum += mix64(index++ ^ w); }
+		if (padded != n_bytes) std::memcpy(p, tmp.data(), n_bytes);
+	}
+};
+
+struct file_closer { std::FILE *f; ~file_closer() { if (f) std::fclose(f); } };
+
+} // namespace
+
+
+void write_graph(variant_graph const &g, char const *path)
+{
+	std::FILE *f(std::fopen(path, "wb"));
+	if (!f) throw std::runtime_error(std::string("unable to open ") + path + " for writing");
+	file_closer closer{f};
+	writer w{f};
+	std::string names;
+	for (auto const &s : g.sample_names) { names += s; names.push_back('\0'); }
+	u64 const counts[10] = {
+		g.node_count(), g.edge_count(), g.alt_edge_label_bytes.size(), g.sample_names.size(), names.size(), g.ploidy_csum.size(),
+		g.paths_by_chrom_copy_and_edge.rows, g.paths_by_chrom_copy_and_edge.cols, g.paths_by_edge_and_chrom_copy.rows, g.paths_by_edge_and_chrom_copy.cols};
+	w.words(kMagic, 8);
+	w.words(counts, sizeof(counts));
+	w.words(g.reference_positions.data(), 8 * g.reference_positions.size());
+	w.words(g.aligned_positions.data(), 8 * g.aligned_positions.size());
+	w.words(g.alt_edge_targets.data(), 8 * g.alt_edge_targets.size());
+	w.words(g.alt_edge_count_csum.data(), 8 * g.alt_edge_count_csum.size());
+	w.words(g.alt_edge_label_offsets.data(), 8 * g.alt_edge_label_offsets.size());
+	w.words(g.paths_by_chrom_copy_and_edge.words.data(), 8 * g.paths_by_chrom_copy_and_edge.words.size());
+	w.words(g.paths_by_edge_and_chrom_copy.words.data(), 8 * g.paths_by_edge_and_chrom_copy.words.size());
+	w.words(g.ploidy_csum.data(), 4 * g.ploidy_csum.size());
+	w.words(g.alt_edge_label_bytes.data(), g.alt_edge_label_bytes.size());
+	w.words(names.data(), names.size());
+	u64 const sum(w.sum);
+	if (1 != std::fwrite(&sum, 8, 1, f)) throw std::runtime_error("write error");
+	closer.f = nullptr;
+	if (0 != std::fclose(f)) throw std::runtime_error(std::string("error while closing ") + path);
+}
+
+
+void read_graph(char const *path, variant_graph &g)
+{
+	std::FILE *f(std::fopen(path, "rb"));
+	if (!f) throw std::runtime_error(std::string("unable to open ") + path);
+	file_closer closer{f};
+	reader r{f};
+	char magic[8];
+	r.words(magic, 8);
+	if (0 != std::memcmp(magic, kMagic, 8)) throw std::runtime_error(std::string(path) + " is not a V2MGRAF1 graph file");
+	u64 c[10];
+	r.words(c, sizeof(c));
+	u64 const limit(u64(1) << 40);
+	for (u64 const v : c) if (v > limit) throw std::runtime_error("implausible counts in graph file");
+	if (c[6] % 64 || c[7] % 64 || c[8] % 64 || c[9] % 64) throw std::runtime_error("path matrix dimensions must be multiples of 64");
+	g = variant_graph{};
+	g.reference_positions.resize(c[0]);
+	g.aligned_positions.resize(c[0]);
+	g.alt_edge_targets.resize(c[1]);
+	g.alt_edge_count_csum.resize(c[0] + 1);
+	g.alt_edge_label_offsets.resize(c[1] + 1);
+	g.paths_by_chrom_copy_and_edge = bit_matrix(c[6], c[7]);
+	g.paths_by_edge_and_chrom_copy = bit_matrix(c[8], c[9]);
+	g.ploidy_csum.resize(c[5]);
+	g.alt_edge_label_bytes.resize(c[2]);
+	std::string names(c[4], '\0');
+	r.words(g.reference_positions.data(), 8 * c[0]);
+	r.words(g.aligned_positions.data(), 8 * c[0]);
+	r.words(g.alt_edge_targets.data(), 8 * c[1]);
+	r.words(g.alt_edge_count_csum.data(), 8 * (c[0] + 1));
+	r.words(g.alt_edge_label_offsets.data(), 8 * (c[1] + 1));
+	r.words(g.paths_by_chrom_copy_and_edge.words.data(), 8 * g.paths_by_chrom_copy_and_edge.words.size());
+	r.words(g.paths_by_edge_and_chrom_copy.words.data(), 8 * g.paths_by_edge_and_chrom_copy.words.size());
+	r.words(g.ploidy_csum.data(), 4 * c[5]);
+	r.words(g.alt_edge_label_bytes.data(), c[2]);
+	r.words(names.data(), c[4]);
+	u64 stored(0);
+	if (1 != std::fread(&stored, 8, 1, f) || stored != r.sum) throw std::runtime_error(std::string(path) + ": checksum mismatch (truncated or corrupted graph file)");
+	for (std::size_t pos(0); pos < names.size();) {
+		std::size_t const end(names.find('\0', pos));
+		if (std::string::npos == end) break;
+		g.sample_names.emplace_back(names, pos, end - pos);
+		pos = end + 1;
+	}
+	if (g.sample_names.size() != c[3]) throw std::runtime_error("sample name block does not match the sample count");
+	if (g.alt_edge_label_offsets.back() != c[2]) throw std::runtime_error("label offsets do not match the label block");
+}
+
+} // namespace v2m::host

@@ -7,6 +7,7 @@
 #include <string>
 
 #include "founder.hh"
+#include "graph_file.hh"
 #include "readers.hh"
 
 namespace vh = v2m::host;
@@ -62,6 +63,26 @@ void *v2mh_build_variant_graph(char const *fasta, char const *seq_id, char const
 }
 
 void v2mh_free(void *h) { delete static_cast<host_graph *>(h); }
+
+int v2mh_write_graph(void *h, char const *path, char *err, size_t errlen)
+{
+	try { vh::write_graph(static_cast<host_graph *>(h)->graph, path); return 0; }
+	catch (std::exception const &e) { if (err && errlen) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; } return 1; }
+}
+
+void *v2mh_read_graph(char const *path, char *err, size_t errlen)
+{
+	auto *hg(new host_graph);
+	try {
+		vh::read_graph(path, hg->graph);
+		for (auto const &s : hg->graph.sample_names) { hg->sample_blob += s; hg->sample_blob.push_back('\0'); }
+		return hg;
+	} catch (std::exception const &e) {
+		if (err && errlen) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+		delete hg;
+		return nullptr;
+	}
+}
 
 #define HG(h) (*static_cast<host_graph *>(h))
 uint64_t v2mh_node_count(void *h) { return HG(h).graph.node_count(); }

@@ -17,6 +17,7 @@
 
 #include "founder.hh"
 #include "gpu_path.hh"
+#include "graph_file.hh"
 #include "output.hh"
 #include "readers.hh"
 
@@ -32,6 +33,7 @@ struct options {
 	char const *input_reference{}, *reference_sequence{}, *input_variants{}, *chromosome{};
 	char const *output_sequences_a2m{}, *dst_chromosome{}, *output_overlaps{};
 	char const *include_samples{}, *exclude_samples{};
+	char const *input_graph{}, *output_graph{};
 	bool output_sequences_separate{}, separate_plain{}, omit_reference{}, unaligned{}, verbose{}, graph_statistics{};
 	bool ref_mismatch_error{};
 	int device{0};
@@ -62,7 +64,9 @@ void usage()
 		"  -F, --founder-sequences=count      Produce founder sequences instead of haplotypes\n"
 		"  -d, --minimum-distance=distance    Minimum node distance (MSA co-ordinates) between cut positions\n"
 		"      --keep-ref-edges               Take the reference edges into account when matching\n"
-		"Not supported by this build: --input-graph, --output-graph, --output-graphviz, --pipe, --input/--output-cut-positions.\n";
+		"  -g, --input-graph=filename         Variant graph input (this build's flat V2MGRAF1 format)\n"
+		"  -f, --output-graph=filename        Output the variant graph\n"
+		"Not supported by this build: --output-graphviz, --pipe, --input/--output-cut-positions.\n";
 }
 
 typedef std::set<std::tuple<std::string, std::string, unsigned>> sample_set;
@@ -152,13 +156,13 @@ int main(int argc, char **argv)
 		{"output-overlaps", required_argument, nullptr, o_overlaps}, {"output-graph-statistics", no_argument, nullptr, o_stats},
 		{"ref-mismatch-handling", required_argument, nullptr, o_mismatch}, {"include-samples", required_argument, nullptr, o_include},
 		{"exclude-samples", required_argument, nullptr, 'x'}, {"device", required_argument, nullptr, o_device}, {"verbose", no_argument, nullptr, o_verbose},
-		{"input-graph", required_argument, nullptr, o_unsupported}, {"output-graph", required_argument, nullptr, o_unsupported},
+		{"input-graph", required_argument, nullptr, 'g'}, {"output-graph", required_argument, nullptr, 'f'},
 		{"output-graphviz", required_argument, nullptr, o_unsupported}, {"pipe", required_argument, nullptr, o_unsupported},
 		{"minimum-distance", required_argument, nullptr, 'd'}, {"input-cut-positions", required_argument, nullptr, o_unsupported},
 		{"output-cut-positions", required_argument, nullptr, o_unsupported}, {"keep-ref-edges", no_argument, nullptr, o_keep_ref},
 		{"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
 	int c;
-	while (-1 != (c = getopt_long(argc, argv, "HF:d:r:e:a:c:s:m:x:h", longopts, nullptr))) {
+	while (-1 != (c = getopt_long(argc, argv, "HF:d:r:e:a:c:s:m:x:g:f:h", longopts, nullptr))) {
 		switch (c) {
 			case 'H': opt.haplotypes = true; break;
 			case 'F': opt.founder_mode = true; opt.founder_sequences = std::atol(optarg); break;
@@ -171,6 +175,8 @@ int main(int argc, char **argv)
 			case 's': opt.output_sequences_a2m = optarg; break;
 			case 'm': opt.dst_chromosome = optarg; break;
 			case 'x': opt.exclude_samples = optarg; break;
+			case 'g': opt.input_graph = optarg; break;
+			case 'f': opt.output_graph = optarg; break;
 			case o_separate: opt.output_sequences_separate = true; break;
 			case o_sep_format:
 				if (0 == std::strcmp(optarg, "plain")) opt.separate_plain = true;
@@ -197,7 +203,11 @@ int main(int argc, char **argv)
 	if (opt.haplotypes == opt.founder_mode) { std::cerr << "ERROR: exactly one of --haplotypes and --founder-sequences is required.\n"; return EXIT_FAILURE; }
 	if (opt.founder_mode && opt.founder_sequences <= 0) { std::cerr << "ERROR: --founder-sequences must be positive.\n"; return EXIT_FAILURE; }   // main.cc:595-599
 	if (opt.minimum_distance < 0) { std::cerr << "ERROR: --minimum-distance must be non-negative.\n"; return EXIT_FAILURE; }                    // main.cc:607-611
-	if (!opt.input_reference || !opt.input_variants || !opt.chromosome) { std::cerr << "ERROR: --input-reference, --input-variants and --chromosome are required.\n"; return EXIT_FAILURE; }
+	if (!opt.input_reference) { std::cerr << "ERROR: --input-reference is required.\n"; return EXIT_FAILURE; }
+	if (opt.input_variants && opt.input_graph) { std::cerr << "ERROR: Only one of --input-variants and --input-graph can be specified.\n"; return EXIT_FAILURE; }   // main.cc:577-581
+	if (!opt.input_variants && !opt.input_graph) { std::cerr << "ERROR: One of --input-variants and --input-graph must be specified.\n"; return EXIT_FAILURE; }  // main.cc:583-587
+	if (opt.input_variants && !opt.chromosome) { std::cerr << "ERROR: --chromosome must be specified with --input-variants.\n"; return EXIT_FAILURE; }          // main.cc:589-593
+	if (opt.output_graph && !opt.input_variants) { std::cerr << "ERROR: --output-graph requires --input-variants.\n"; return EXIT_FAILURE; }                     // cmdline.ggo:40 (dependon)
 	if (opt.include_samples && opt.exclude_samples) { std::cerr << "ERROR: --include-samples and --exclude-samples are mutually exclusive.\n"; return EXIT_FAILURE; }
 
 	try {
@@ -212,7 +222,11 @@ int main(int argc, char **argv)
 		std::cerr << " Done. Reference length is " << ref_seq.size() << ".\n";
 
 		vh::variant_graph graph;
-		{
+		if (opt.input_graph) {                                  // main.cc:392-401
+			std::cerr << "Loading the variant graph from " << opt.input_graph << "..." << std::flush;
+			vh::read_graph(opt.input_graph, graph);
+			std::cerr << " Done.\n";
+		} else {
 			sample_set included, excluded;
 			build_delegate delegate;
 			delegate.chromosome = opt.chromosome;
@@ -231,6 +245,12 @@ int main(int argc, char **argv)
 			vh::transpose_paths(gpu, graph);   // variant_graph.cc:453, on the GPU
 			std::cerr << "Done. Handled variants: " << stats.handled_variants << " Chromosome ID mismatches: " << stats.chr_id_mismatches << '\n';
 			if (0 == stats.handled_variants) std::cerr << "WARNING: no variants matched the chromosome identifier \"" << opt.chromosome << "\".\n";
+		}
+
+		if (opt.output_graph) {                                 // main.cc:418-426
+			std::cerr << "Outputting the variant graph..." << std::flush;
+			vh::write_graph(graph, opt.output_graph);
+			std::cerr << " Done.\n";
 		}
 
 		if (opt.graph_statistics) {   // main.cc:428-435

@@ -25,6 +25,10 @@ def _load():
 		L.v2mh_build_variant_graph.restype = C.c_void_p
 		L.v2mh_build_variant_graph.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint, C.c_char_p, C.c_size_t]
 		L.v2mh_free.argtypes = [C.c_void_p]
+		L.v2mh_write_graph.restype = C.c_int
+		L.v2mh_write_graph.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
+		L.v2mh_read_graph.restype = C.c_void_p
+		L.v2mh_read_graph.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
 		for n in ("node_count", "edge_count", "sample_count", "ref_length", "sample_blob_size", "ploidy_csum_size", "handled_variants", "chr_id_mismatches", "overlap_count"):
 			f = getattr(L, "v2mh_" + n)
 			f.restype = C.c_uint64
@@ -55,11 +59,14 @@ def _arr(ptr, n, dtype):
 class HostGraph:
 	"""Result of the host's build_variant_graph (without the final transpose)."""
 
-	def __init__(self, fasta_path, vcf_path, chr_id, seq_id=None, exclude_sample=None, exclude_copy=-1, threads=0):
+	def __init__(self, fasta_path, vcf_path, chr_id, seq_id=None, exclude_sample=None, exclude_copy=-1, threads=0, _graph_file=None):
 		L = _load()
 		err = C.create_string_buffer(512)
-		h = L.v2mh_build_variant_graph(str(fasta_path).encode(), seq_id.encode() if seq_id else None, str(vcf_path).encode(), chr_id.encode(),
-			exclude_sample.encode() if exclude_sample else None, exclude_copy, threads, err, len(err))
+		if _graph_file is not None:
+			h = L.v2mh_read_graph(str(_graph_file).encode(), err, len(err))
+		else:
+			h = L.v2mh_build_variant_graph(str(fasta_path).encode(), seq_id.encode() if seq_id else None, str(vcf_path).encode(), chr_id.encode(),
+				exclude_sample.encode() if exclude_sample else None, exclude_copy, threads, err, len(err))
 		if not h:
 			raise ValueError(err.value.decode())
 		self._h = h
@@ -95,6 +102,16 @@ class HostGraph:
 				self._h = None
 		except Exception:
 			pass
+
+	@classmethod
+	def read(cls, path):
+		"""read_graph(): a graph from this build's flat V2MGRAF1 file (no reference sequence)."""
+		return cls(None, None, None, _graph_file=path)
+
+	def write(self, path):
+		err = C.create_string_buffer(512)
+		if 0 != _load().v2mh_write_graph(self._h, str(path).encode(), err, len(err)):
+			raise OSError(err.value.decode())
 
 	def find_founders(self, founder_count, min_distance=0, keep_ref_edges=False):
 		"""find_cut_positions + find_matchings (host algorithms).  Returns (cut_positions, assigned_samples column-major, score)
