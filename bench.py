@@ -86,6 +86,9 @@ def main():
 	import torch
 	import torch.distributed as dist
 
+	from vcf2multialign_amd import build as _build
+	if local_rank == 0:
+		_build.build_native()   # no-op when the in-tree libraries are newer than their sources (hipcc cross-compiles gfx950)
 	import vcf2multialign_amd as v2m
 	from vcf2multialign_amd import _native as N
 	from vcf2multialign_amd import synth
@@ -122,7 +125,9 @@ def main():
 	n_rows = len(rows)
 	total_rows = H + 1
 
-	batch_rows = max(1, min(args.batch_rows, n_rows))
+	# equal-sized batches of at most --batch-rows rows (5009 rows -> 10 x 501 rather than 9 x 512 + 401)
+	n_batches = max(1, -(-n_rows // max(1, args.batch_rows)))
+	batch_rows = max(1, -(-n_rows // n_batches))
 	# Output buffer: placement matters on this hardware, so the library picks it by measurement.
 	out_bytes = batch_rows * pitch
 	out_ptr = ctx.alloc_output(out_bytes, candidates=args.output_candidates)
@@ -191,7 +196,7 @@ def main():
 	try:
 		with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
 			rec = json.load(f).get(args.config)
-		if rec and rec["batch_rows"] == batch_rows and rec["n_gpus"] == world:
+		if rec and rec["batch_rows"] == args.batch_rows and rec["n_gpus"] == world:
 			traffic, traffic_source = rec["hbm_bytes_per_launch"], rec["source"]
 	except (OSError, ValueError, KeyError):
 		pass

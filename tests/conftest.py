@@ -17,6 +17,14 @@ def pytest_configure(config):
 	config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+	# the in-tree native libraries (HIP product, C++ host, synthetic-input helper) and the CPU oracle; no-ops when fresh
+	from vcf2multialign_amd import build
+	build.build_native()
+	import oracle
+	oracle.build_oracle()
+
+
 @pytest.fixture(scope="session")
 def goldens():
 	import json

@@ -179,6 +179,38 @@ def test_both_store_flavours(v2m, ctx, tmp_path, monkeypatch, nt):
 	assert ctx.splice_rows(rows) == _oracle_rows(g, rows)
 
 
+def test_extreme_spans_and_cache_limits(v2m, ctx, tmp_path, monkeypatch):
+	"""Spans and labels beyond what the workgroup's LDS cache can describe (>= 64 KiB spans, labels past the cached
+	2 KiB slice), more long patches in one tile-row than the long-span queue holds, and row groups larger than the
+	cached effective-bit rows: all must fall back to the global-memory path without changing a byte."""
+	rng = np.random.default_rng(77)
+	ref = synth.random_reference(rng, 400000)
+	recs = []
+	def rec(pos, ref_len, alts, gts):
+		recs.append((pos, ref[pos:pos + ref_len], alts, np.array(gts)))
+	n = 3   # samples, diploid
+	rec(1000, 150000, [ref[1000:1001]], [[1, 0], [0, 0], [1, 1]])                        # 150 kb deletion (span >= 64 KiB)
+	for k in range(30):                                                                 # variants under it: skipped by copies 0, 4, 5
+		rec(2000 + 500 * k, 1, [synth._alt_base(rng, ref[2000 + 500 * k])], [[1, 1], [1, 0], [0, 1]])
+	rec(160000, 1, [ref[160000:160001] + synth.random_reference(rng, 70000)], [[0, 1], [1, 0], [0, 0]])   # 70 kb insertion
+	for k in range(40):                                                                 # 40 insertions of 200 bp inside one 16-KiB tile, all carried by copy 1
+		p = 250000 + 150 * k
+		rec(p, 1, [ref[p:p + 1] + synth.random_reference(rng, 200)], [[0, 1], [0, 0], [1, 0]])
+	rec(300000, 5, [ref[300000:300001], ref[300000:300001] + b"ACGTACGTACGT"], [[1, 2], [2, 1], [0, 2]])
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, n)
+	g = oracle.build_variant_graph(fa, vcf, "1")
+	assert g.aligned_length > 470000
+	_upload(v2m, ctx, g)
+	rows = [v2m.PLOIDY_MAX] + list(range(6)) + [[(0, 0), (g.node_count - 3, 3)]]
+	exp = _oracle_rows(g, rows)
+	assert ctx.splice_rows(rows) == exp
+	assert ctx.splice_rows(rows, unaligned=True) == _oracle_rows(g, rows, unaligned=True)
+	many = rows * 6                                                                    # 48 rows in one group of 40: rows 16.. use the uncached path
+	monkeypatch.setenv("V2M_ROWS_PER_GROUP", "40")
+	assert ctx.splice_rows(many) == exp * 6
+	assert ctx.splice_rows(many, unaligned=True) == _oracle_rows(g, rows, unaligned=True) * 6
+
+
 def test_founder_rows_synthetic(v2m, ctx, tmp_path):
 	"""Copy switching at cut nodes that no edge spans (founder_sequence_greedy_output.cc:106-114)."""
 	g = synth.build_case(tmp_path, 21, 80000, 1200, 10)
@@ -263,6 +295,19 @@ def test_unaligned_keeps_dashes_and_case_of_the_reference(v2m, ctx, tmp_path):
 	assert ctx.splice_rows(rows, unaligned=True) == _oracle_rows(g, rows, unaligned=True)
 	assert ctx.splice_rows(rows) == _oracle_rows(g, rows)
 	assert ctx.splice_rows([v2m.PLOIDY_MAX], unaligned=True) == [ref]
+
+
+def test_alloc_output(v2m, ctx):
+	"""v2m_alloc_output: plain allocation for small sizes, measured choice among candidates for large ones."""
+	p = ctx.alloc_output(1 << 20, candidates=3)
+	assert p and p % 256 == 0
+	ctx.free_output(p)
+	before = ctx.info
+	p = ctx.alloc_output(3 << 30, candidates=3)          # 3 x 3 GiB candidates, probed
+	assert p and "output buffer chosen among" in ctx.info[len(before):]
+	ctx.free_output(p)
+	with pytest.raises(v2m.V2MError):
+		ctx.alloc_output(0)
 
 
 # ---- edge cases and error behaviour --------------------------------------------------------
