@@ -52,13 +52,11 @@ struct __attribute__((aligned(8))) edge_span {
 // Bit-matrix transpose.  src: n_rows x n_cols bits, column-major, SW = n_rows/64 words per column.
 // dst: n_cols x n_rows bits, DW = n_cols/64 words per column.
 //
-// One workgroup moves a 512 x 512-bit panel (8 row-words x 8 column groups = 32 KiB) through
-// LDS: every source column contributes 64 contiguous bytes and every destination column
-// receives 64 contiguous bytes, so both HBM sides move whole 64-B segments instead of the
-// 8-B strided words a tile-per-wave scheme would touch.  Each wave transposes 64 x 64-bit
-// tiles in registers with the six-stage butterfly (lane = source column, bit = source row).
+// One workgroup moves a panel of kR row-words x kC column groups through LDS, so that both HBM
+// sides move contiguous 8*kR- and 8*kC-byte segments instead of the 8-B words, a whole column
+// apart, that a tile-per-wave scheme would touch.  Each wave transposes 64 x 64-bit tiles in
+// registers with the six-stage butterfly (lane = source column, bit = source row).
 // ---------------------------------------------------------------------------------------------
-constexpr int kTrPanel = 8;         // row-words and column groups per workgroup panel
 constexpr int kTrThreads = 256;
 
 __device__ __forceinline__ u64 shfl_xor_u64(u64 v, int mask)
@@ -87,55 +85,61 @@ __device__ __forceinline__ u64 wave_transpose_64x64(u64 x, int lane)
 	return x;
 }
 
+// Panel of kR source row-words x kC source column groups (64*kR x 64*kC bits).  Every source column contributes
+// 8*kR contiguous bytes, every destination column receives 8*kC contiguous bytes.
+template <int kR, int kC>
 __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW)
 {
-	// [source column within panel][row-word], padded to 9 words: the per-lane stride of the
-	// transposing read is 72 B, conflict-free for ds_read_b64 ((18*lane) mod 64 distinct over 32 lanes).
-	__shared__ u64 panel[64 * kTrPanel][kTrPanel + 1];
+	static_assert(kR % 4 == 0, "each of the 4 waves owns kR / 4 row-words");
+	// phase 1 view: [source column within panel = 64*kC][kR + 1]; phase 2 view: [destination column = 64*kR][kC + 1].
+	// The one-word pad makes the per-lane stride of the strided accesses odd in 8-byte units: conflict-free ds_read/write_b64.
+	constexpr int kWords1 = 64 * kC * (kR + 1), kWords2 = 64 * kR * (kC + 1);
+	__shared__ u64 panel[kWords1 > kWords2 ? kWords1 : kWords2];
 
 	int const t = threadIdx.x;
 	int const lane = t & 63;
 	int const wave = t >> 6;
-	u64 const rw0 = (u64) blockIdx.x * kTrPanel;    // first source row-word
-	u64 const cg0 = (u64) blockIdx.y * kTrPanel;    // first source column group
+	u64 const rw0 = (u64) blockIdx.x * kR;    // first source row-word
+	u64 const cg0 = (u64) blockIdx.y * kC;    // first source column group
 	u64 const n_cols = DW * 64;
 
-	// load: 8 consecutive lanes fetch one column's 64 contiguous bytes
-	for (int k = 0; k < (64 * kTrPanel * kTrPanel) / kTrThreads; ++k) {
+	// load: kR consecutive lanes fetch one column's 8*kR contiguous bytes
+	for (int k = 0; k < (64 * kR * kC) / kTrThreads; ++k) {
 		int const idx = t + kTrThreads * k;
-		int const col = idx >> 3, w = idx & 7;
+		int const col = idx / kR, w = idx % kR;
 		u64 const gcol = cg0 * 64 + col;
 		u64 v = 0;
 		if (gcol < n_cols && rw0 + w < SW)
 			v = src[gcol * SW + rw0 + w];
-		panel[col][w] = v;
+		panel[col * (kR + 1) + w] = v;
 	}
 	__syncthreads();
 
-	// each wave owns two row-words; pull their 2 x 8 tiles into registers
-	u64 x[2][kTrPanel];
+	// each wave owns kR / 4 row-words; pull their tiles into registers
+	constexpr int kA = kR / 4;
+	u64 x[kA][kC];
 #pragma unroll
-	for (int a = 0; a < 2; ++a)
+	for (int a = 0; a < kA; ++a)
 #pragma unroll
-		for (int cg = 0; cg < kTrPanel; ++cg)
-			x[a][cg] = panel[64 * cg + lane][2 * wave + a];
+		for (int cg = 0; cg < kC; ++cg)
+			x[a][cg] = panel[(64 * cg + lane) * (kR + 1) + kA * wave + a];
 	__syncthreads();
 
 #pragma unroll
-	for (int a = 0; a < 2; ++a)
+	for (int a = 0; a < kA; ++a)
 #pragma unroll
-		for (int cg = 0; cg < kTrPanel; ++cg)
-			panel[64 * (2 * wave + a) + lane][cg] = wave_transpose_64x64(x[a][cg], lane);   // now [dst column within panel][column group]
+		for (int cg = 0; cg < kC; ++cg)
+			panel[(64 * (kA * wave + a) + lane) * (kC + 1) + cg] = wave_transpose_64x64(x[a][cg], lane);
 	__syncthreads();
 
-	// store: 8 consecutive lanes write one destination column's 64 contiguous bytes
-	for (int k = 0; k < (64 * kTrPanel * kTrPanel) / kTrThreads; ++k) {
+	// store: kC consecutive lanes write one destination column's 8*kC contiguous bytes
+	for (int k = 0; k < (64 * kR * kC) / kTrThreads; ++k) {
 		int const idx = t + kTrThreads * k;
-		int const dcol = idx >> 3, cw = idx & 7;
+		int const dcol = idx / kC, cw = idx % kC;
 		u64 const grow = rw0 * 64 + dcol;          // destination column = source row
 		if (grow < SW * 64 && cg0 + cw < DW)
-			dst[grow * DW + cg0 + cw] = panel[dcol][cw];
+			dst[grow * DW + cg0 + cw] = panel[dcol * (kC + 1) + cw];
 	}
 }
 

@@ -163,18 +163,32 @@ int upload_vec(v2m_ctx *ctx, dev_buf &dst, std::vector<T> const &src, size_t min
 }
 
 
-int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst)
+template <int kR, int kC>
+int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
 {
-	u64 const SW(n_rows / 64), DW(n_cols / 64);
-	u64 const gx((SW + v2m::kTrPanel - 1) / v2m::kTrPanel), gy((DW + v2m::kTrPanel - 1) / v2m::kTrPanel);
+	u64 const gx((SW + kR - 1) / kR), gy((DW + kC - 1) / kC);
 	if (gy > 65535 || gx > 0x7FFFFFFFu)
-		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch (%llu x %llu bits)", (unsigned long long) n_rows, (unsigned long long) n_cols);
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch (%llu x %llu bits)", (unsigned long long) (SW * 64), (unsigned long long) (DW * 64));
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL(v2m::transpose_bits_kernel, dim3((unsigned) gx, (unsigned) gy), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW);
+		hipLaunchKernelGGL((v2m::transpose_bits_kernel<kR, kC>), dim3((unsigned) gx, (unsigned) gy), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW);
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
+}
+
+int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst)
+{
+	u64 const SW(n_rows / 64), DW(n_cols / 64);
+	char const *e(std::getenv("V2M_TRANSPOSE_PANEL"));   // tuning knob: "8x8", "8x16", "16x8", "4x16", "16x4"
+	std::string const shape((e && *e) ? e : "4x16");   // tools/tune_transpose.py: 4x16 2.1 TB/s, 8x8 2.0, 16x4 1.8, 8x16 / 16x8 1.4 (config-3 matrix)
+	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, d_dst);
+	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, d_dst);
+	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, d_dst);
+	if (shape == "4x8") return launch_transpose_shape<4, 8>(ctx, d_src, SW, DW, d_dst);
+	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, d_dst);
+	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, d_dst);
+	return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, d_dst);
 }
 
 
