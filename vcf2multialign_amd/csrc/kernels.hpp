@@ -520,12 +520,21 @@ __device__ __forceinline__ void load_patch_cache(
 	// visibility: the caller's next __syncthreads() (after it has dropped the pristine tile into LDS)
 }
 
-// Overwrites, in the LDS tile `buf`, the spans of the row's effective edges.  Contains the barriers that separate
-// it from the tile's readers; must be called by all threads of the workgroup.
-__device__ __forceinline__ void patch_row_tile(
-	unsigned char *buf, patch_cache &pc, tile_job const &job, tile_tables const &tt,
-	edge_patch const *__restrict__ patches, char const *__restrict__ labels,
-	u64 const *__restrict__ eff_row, u32 local_row, int t, char gap)
+// What an effective candidate edge contributes to the tile: its clipped aligned span and where its label bytes are.
+struct tile_patch {
+	u32 edge;
+	u32 aln_begin;     // unclipped start of the span
+	u32 from, to;      // span clipped to the tile
+	u32 label_len;
+	u32 label_begin;   // offset into the cached label slice (in_lds) or into the global label pool
+	bool in_lds;
+};
+
+// Calls f(tile_patch) for every candidate edge of the tile that is effective in the row, each candidate on one thread.
+template <typename F>
+__device__ __forceinline__ void for_each_effective_candidate(
+	patch_cache const &pc, tile_job const &job, tile_tables const &tt, edge_patch const *__restrict__ patches,
+	u64 const *__restrict__ eff_row, u32 local_row, int t, F &&f)
 {
 	u32 const n_cand = job.n_cross + job.n_range;
 	u32 const tile_end = job.tile_base + kTileBytes;
@@ -546,25 +555,45 @@ __device__ __forceinline__ void patch_row_tile(
 			c = pc.patch[i - job.n_cross];
 			cached = c.span != 0xFFFF && c.label_rel != 0xFFFF;
 		}
+		tile_patch tp;
+		tp.edge = e;
 		if (cached) {
-			u32 const from = job.tile_base + c.begin_rel;
-			u32 const to = from + c.span < tile_end ? from + c.span : tile_end;
-			if (to - from > kLongPatch) {
-				u32 const slot = atomicAdd(&pc.long_count, 1u);
-				if (slot < (u32) kLongQueueLds) { pc.long_queue[slot] = e; continue; }
-			}
-			fill_patch_bytes(buf, job.tile_base, from, c.label_len, pc.labels + c.label_rel, from, to, 0, 1, gap);
+			tp.aln_begin = tp.from = job.tile_base + c.begin_rel;
+			tp.to = tp.from + c.span < tile_end ? tp.from + c.span : tile_end;
+			tp.label_len = c.label_len;
+			tp.label_begin = c.label_rel;
+			tp.in_lds = true;
 		} else {
 			edge_patch const p = patches[e];
-			u32 const from = p.aln_begin > job.tile_base ? p.aln_begin : job.tile_base;
-			u32 const to = p.aln_end < tile_end ? p.aln_end : tile_end;
-			if (to - from > kLongPatch) {
-				u32 const slot = atomicAdd(&pc.long_count, 1u);
-				if (slot < (u32) kLongQueueLds) { pc.long_queue[slot] = e; continue; }
-			}
-			fill_patch_bytes(buf, job.tile_base, p.aln_begin, p.label_len, labels + p.label_begin, from, to, 0, 1, gap);
+			tp.aln_begin = p.aln_begin;
+			tp.from = p.aln_begin > job.tile_base ? p.aln_begin : job.tile_base;
+			tp.to = p.aln_end < tile_end ? p.aln_end : tile_end;
+			tp.label_len = p.label_len;
+			tp.label_begin = p.label_begin;
+			tp.in_lds = false;
 		}
+		f(tp);
 	}
+}
+
+// Overwrites, in the LDS tile `buf`, the spans of the row's effective edges.  Contains the barriers that separate
+// it from the tile's readers; must be called by all threads of the workgroup.
+__device__ __forceinline__ void patch_row_tile(
+	unsigned char *buf, patch_cache &pc, tile_job const &job, tile_tables const &tt,
+	edge_patch const *__restrict__ patches, char const *__restrict__ labels,
+	u64 const *__restrict__ eff_row, u32 local_row, int t, char gap)
+{
+	u32 const tile_end = job.tile_base + kTileBytes;
+	for_each_effective_candidate(pc, job, tt, patches, eff_row, local_row, t, [&](tile_patch const &tp) {
+		if (tp.to - tp.from > kLongPatch) {
+			u32 const slot = atomicAdd(&pc.long_count, 1u);
+			if (slot < (u32) kLongQueueLds) { pc.long_queue[slot] = tp.edge; return; }
+		}
+		if (tp.in_lds)
+			fill_patch_bytes(buf, job.tile_base, tp.aln_begin, tp.label_len, pc.labels + tp.label_begin, tp.from, tp.to, 0, 1, gap);
+		else
+			fill_patch_bytes(buf, job.tile_base, tp.aln_begin, tp.label_len, labels + tp.label_begin, tp.from, tp.to, 0, 1, gap);
+	});
 	__syncthreads();
 
 	u32 const n_long = pc.long_count < (u32) kLongQueueLds ? pc.long_count : (u32) kLongQueueLds;   // workgroup-uniform
@@ -653,11 +682,13 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_aligned_kernel(
 // -- from a second template whose padding byte is 0 instead of '-' (a byte neither FASTA text nor
 // VCF alleles can contain), patched with 0 as padding -- and then compacted.  Where a tile's bytes
 // land in the row needs the number of non-padding bytes of all tiles before it:
-//   pass 1  splice_unaligned_kernel<true>   counts the non-padding bytes of every (row, tile)
-//           scan_tile_counts_kernel         exclusive prefix sum per row -> tile offsets, row lengths
-//   pass 2  splice_unaligned_kernel<false>  rebuilds each tile, compacts it in LDS at the destination's
-//                                           16-B phase and streams it out (16-B stores inside, byte
-//                                           stores on the ragged first/last chunk, which neighbours share).
+//   pass 1  count_unaligned_kernel     non-padding bytes of every (row, tile), WITHOUT building the rows: the
+//                                      template tile's own count plus, per effective edge, the label bytes it
+//                                      puts into the tile minus the template bytes its span removes
+//           scan_tile_counts_kernel    exclusive prefix sum per row -> tile offsets, row lengths
+//   pass 2  splice_unaligned_kernel    builds each tile, compacts it in LDS at the destination's 16-B phase and
+//                                      streams it out (16-B stores inside, byte stores on the ragged first/last
+//                                      chunk, which neighbouring tiles share).
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 zero_bytes_mask(u32 x)
 {
@@ -665,11 +696,76 @@ __device__ __forceinline__ u32 zero_bytes_mask(u32 x)
 	return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
 }
 
-template <bool kCountOnly>
+// Non-zero bytes of tile[lo, hi).
+__device__ __forceinline__ u32 count_nonzero_bytes(unsigned char const *tile, u32 lo, u32 hi)
+{
+	u32 n = 0;
+	while (lo < hi && (lo & 3)) n += tile[lo++] != 0;
+	for (; lo + 4 <= hi; lo += 4)
+		n += 4 - __builtin_popcount(zero_bytes_mask(*(u32 const *) (tile + lo)));
+	while (lo < hi) n += tile[lo++] != 0;
+	return n;
+}
+
+constexpr int kCountRowsMax = 256;   // rows per group the count kernel can hold (host clamps rows_per_group)
+
+__global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
+	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
+	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
+	u32 *__restrict__ tile_counts /* [n_rows][n_tiles] */, u32 n_tiles,
+	u32 n_rows, u32 rows_per_group, u32 n_groups, u32 tile_run)
+{
+	__shared__ vec4u lds[kTileChunks];        // the pristine template tile, shared by all rows of the group
+	__shared__ patch_cache pc;
+	__shared__ int row_delta[kCountRowsMax];
+	__shared__ u32 wave_sums[kSpliceThreads / 64];
+
+	int const t = threadIdx.x;
+	u32 tile, group;
+	map_block(blockIdx.x, n_groups, n_tiles, tile_run, tile, group);
+	u32 const row_begin = group * rows_per_group;
+	u32 const row_end = (row_begin + rows_per_group < n_rows) ? row_begin + rows_per_group : n_rows;
+
+	u32 mine = 0;
+#pragma unroll
+	for (int k = 0; k < kChunksPerThread; ++k) {
+		vec4u const v = tmpl0[(u64) tile * kTileChunks + t + kSpliceThreads * k];
+		lds[t + kSpliceThreads * k] = v;
+#pragma unroll
+		for (int d = 0; d < 4; ++d)
+			mine += 4 - __builtin_popcount(zero_bytes_mask(v[d]));
+	}
+#pragma unroll
+	for (int d = 32; d >= 1; d >>= 1) mine += __shfl_down(mine, d, kWave);
+	if ((t & 63) == 0) wave_sums[t >> 6] = mine;
+	for (u32 r = t; r < (u32) kCountRowsMax; r += kSpliceThreads) row_delta[r] = 0;
+
+	tile_job job;
+	load_patch_cache(pc, job, tt, patches, labels, eff, eff_words_per_row, tile, row_begin, row_end - row_begin, t);
+	__syncthreads();
+	u32 tile_count = 0;
+#pragma unroll
+	for (int wv = 0; wv < kSpliceThreads / 64; ++wv) tile_count += wave_sums[wv];
+
+	unsigned char const *const tile_bytes = (unsigned char const *) lds;
+	for (u32 row = row_begin; row < row_end; ++row) {
+		int delta = 0;
+		for_each_effective_candidate(pc, job, tt, patches, eff + (u64) row * eff_words_per_row, row - row_begin, t, [&](tile_patch const &tp) {
+			u32 const label_end = tp.aln_begin + tp.label_len;
+			int const label_in_tile = label_end > tp.from ? (int) ((label_end < tp.to ? label_end : tp.to) - tp.from) : 0;
+			delta += label_in_tile - (int) count_nonzero_bytes(tile_bytes, tp.from - job.tile_base, tp.to - job.tile_base);
+		});
+		if (delta) atomicAdd(&row_delta[row - row_begin], delta);
+	}
+	__syncthreads();
+	for (u32 r = t; r < row_end - row_begin; r += kSpliceThreads)
+		tile_counts[(u64) (row_begin + r) * n_tiles + tile] = (u32) ((int) tile_count + row_delta[r]);
+}
+
 __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
 	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
-	u32 *__restrict__ tile_counts /* [n_rows][n_tiles]: counts (pass 1) / exclusive offsets (pass 2) */, u32 n_tiles,
+	u32 const *__restrict__ tile_offsets /* [n_rows][n_tiles]: where each tile's bytes start in its row */, u32 n_tiles,
 	char *__restrict__ out, u64 row_pitch, u32 n_rows, u32 rows_per_group, u32 n_groups, u32 tile_run)
 {
 	__shared__ vec4u lds[kTileChunks];
@@ -727,27 +823,49 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			if (wv < wave) before += ws;
 			total += ws;
 		}
-		u32 *const slot = tile_counts + (u64) row * n_tiles + tile;
-		if (kCountOnly) {
-			if (t == 0) *slot = total;
-			continue;
-		}
 
-		u32 const row_off = *slot;             // where this tile's bytes start in the unaligned row
+		u32 const row_off = tile_offsets[(u64) row * n_tiles + tile];   // where this tile's bytes start in the unaligned row
 		u32 const phase = row_off & 15;
 		unsigned char *const c8 = (unsigned char *) comp;
-		u32 pos = phase + before + (incl - mine);
+		u32 *const c32 = (u32 *) comp;
+		// Append the surviving bytes to the compacted image through a 64-bit window that is flushed one aligned dword
+		// at a time; the first dword of the thread's run may be shared with its left neighbour (bytes below `pos`), the
+		// last with its right neighbour: those are written byte-wise, everything between as whole dwords.
+		u32 const pos = phase + before + (incl - mine);
+		u32 out_dword = pos >> 2;
+		u32 fill = pos & 3;              // bytes of the current dword that belong to the left neighbour
+		u32 skip = fill;
+		u64 win = 0;
 #pragma unroll
 		for (int k = 0; k < 4; ++k)
 #pragma unroll
 			for (int d = 0; d < 4; ++d) {
 				u32 const x = v[k][d];
+				u32 const zm = zero_bytes_mask(x);
+				if (0 == zm) {
+					win |= (u64) x << (8 * fill);
+					fill += 4;
+				} else {
 #pragma unroll
-				for (int b = 0; b < 4; ++b) {
-					unsigned char const ch = (unsigned char) (x >> (8 * b));
-					if (ch) c8[pos++] = ch;
+					for (int b = 0; b < 4; ++b) {
+						u32 const ch = (x >> (8 * b)) & 0xFF;
+						if (ch) { win |= (u64) ch << (8 * fill); ++fill; }
+					}
+				}
+				if (fill >= 4) {
+					u32 const w = (u32) win;
+					if (skip) {
+						for (u32 b = skip; b < 4; ++b) c8[4 * out_dword + b] = (unsigned char) (w >> (8 * b));
+						skip = 0;
+					} else {
+						c32[out_dword] = w;
+					}
+					++out_dword;
+					win >>= 32;
+					fill -= 4;
 				}
 			}
+		for (u32 b = skip; b < fill; ++b) c8[4 * out_dword + b] = (unsigned char) ((u32) win >> (8 * b));
 		__syncthreads();
 
 		char *const dst = out + (u64) row * row_pitch + (row_off - phase);   // 16-B aligned

@@ -254,7 +254,7 @@ u32 rows_per_group_for(u64 n_rows)
 {
 	char const *e = std::getenv("V2M_ROWS_PER_GROUP");
 	int const v((e && *e) ? std::atoi(e) : 0);
-	if (v > 0) return u32(v);
+	if (v > 0) return u32(std::min(v, 256));   // count_unaligned_kernel holds at most 256 rows per group
 	return u32(std::min<u64>(16, std::max<u64>(1, n_rows)));
 }
 
@@ -417,12 +417,12 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 	v2m::tile_tables tt{ctx->d_tile_edge_begin.as<u32>(), ctx->d_cross_offsets.as<u32>(), ctx->d_cross_edges.as<u32>()};
 	{
 		timed_launch tl(ctx, V2M_KERNEL_SPLICE_UNALIGNED);
-		hipLaunchKernelGGL(v2m::splice_unaligned_kernel<true>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
+		hipLaunchKernelGGL(v2m::count_unaligned_kernel, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 			ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
-			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
+			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
 		hipLaunchKernelGGL(v2m::scan_tile_counts_kernel, dim3(unsigned(n_rows)), dim3(256), 0, ctx->stream,
 			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, ctx->d_row_lengths.as<u64>());
-		hipLaunchKernelGGL(v2m::splice_unaligned_kernel<false>, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
+		hipLaunchKernelGGL(v2m::splice_unaligned_kernel, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 			ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
 			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
 	}
