@@ -52,15 +52,20 @@ public:
 			u64 const d(m_prev_divergence[i]);
 			if (less(p, d)) p = d;
 			if (less(q, d)) q = d;
-			auto const it(value_counts.find(d));
-			if (0 == --it->second) value_counts.erase(it);
 			bool const uses_edge((column[copy >> 6] >> (copy & 63)) & 1);
+			u64 const nd(uses_edge ? q : p);
+			// The reference decrements the old value's count and increments the new one's for every copy
+			// (pbwt.hh:110-131); when the value does not change -- the common case, a copy whose predecessor in
+			// the order used the same allele -- the two cancel, so the map is only touched on a change.
+			if (nd != d) {
+				auto const it(value_counts.find(d));
+				if (0 == --it->second) value_counts.erase(it);
+				++value_counts[nd];
+			}
 			if (!uses_edge) {
-				++value_counts[p];
 				order[zero_at] = copy; divergence[zero_at] = p; ++zero_at;
 				p = 0;
 			} else {
-				++value_counts[q];
 				order[one_at] = copy; divergence[one_at] = q; ++one_at;
 				q = 0;
 			}

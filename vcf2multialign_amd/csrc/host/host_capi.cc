@@ -62,6 +62,30 @@ void *v2mh_build_variant_graph(char const *fasta, char const *seq_id, char const
 	}
 }
 
+// A host graph from flat arrays (e.g. a synthetic dataset whose genotype matrix was generated on the GPU):
+// paths_by_edge_and_chrom_copy words are column-major, rows = path_rows copies (multiple of 64), cols = path_cols edges.
+void *v2mh_graph_from_arrays(
+	uint64_t n_nodes, uint64_t n_edges, uint64_t const *ref_pos, uint64_t const *aln_pos, uint64_t const *targets, uint64_t const *csum,
+	uint64_t const *label_offsets, char const *label_bytes, uint64_t const *paths_by_edge_and_chrom_copy, uint64_t path_rows, uint64_t path_cols,
+	uint32_t n_samples, uint32_t ploidy)
+{
+	auto *hg(new host_graph);
+	auto &g(hg->graph);
+	g.reference_positions.assign(ref_pos, ref_pos + n_nodes);
+	g.aligned_positions.assign(aln_pos, aln_pos + n_nodes);
+	g.alt_edge_targets.assign(targets, targets + n_edges);
+	g.alt_edge_count_csum.assign(csum, csum + n_nodes + 1);
+	g.alt_edge_label_offsets.assign(label_offsets, label_offsets + n_edges + 1);
+	g.alt_edge_label_bytes.assign(label_bytes, label_bytes + label_offsets[n_edges]);
+	g.paths_by_edge_and_chrom_copy = vh::bit_matrix(path_rows, path_cols);
+	if (paths_by_edge_and_chrom_copy)
+		std::copy(paths_by_edge_and_chrom_copy, paths_by_edge_and_chrom_copy + path_rows / 64 * path_cols, g.paths_by_edge_and_chrom_copy.words.begin());
+	g.ploidy_csum.assign(1, 0);
+	for (uint32_t s(0); s < n_samples; ++s) { g.sample_names.push_back("S" + std::to_string(s)); g.ploidy_csum.push_back(g.ploidy_csum.back() + ploidy); }
+	for (auto const &s : g.sample_names) { hg->sample_blob += s; hg->sample_blob.push_back('\0'); }
+	return hg;
+}
+
 void v2mh_free(void *h) { delete static_cast<host_graph *>(h); }
 
 int v2mh_write_graph(void *h, char const *path, char *err, size_t errlen)

@@ -860,6 +860,7 @@ int v2m_alloc_output(v2m_ctx *ctx, uint64_t bytes, int candidates, void **d_out)
 		best = std::size_t(std::min_element(ms.begin(), ms.end()) - ms.begin());
 		std::string note("output buffer chosen among " + std::to_string(bufs.size()) + " candidates by probe write rate (GB/s):");
 		for (float const t : ms) { char b2[32]; std::snprintf(b2, sizeof(b2), " %.0f", double(pitch) * n_groups * 16 / (t * 1e6)); note += b2; }
+		if (ctx->info.size() > 2000) ctx->info.clear();   // keep the note bounded over many allocations
 		if (!ctx->info.empty()) ctx->info += "; ";
 		ctx->info += note;
 	}

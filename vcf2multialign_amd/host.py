@@ -25,6 +25,8 @@ def _load():
 		L.v2mh_build_variant_graph.restype = C.c_void_p
 		L.v2mh_build_variant_graph.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint, C.c_char_p, C.c_size_t]
 		L.v2mh_free.argtypes = [C.c_void_p]
+		L.v2mh_graph_from_arrays.restype = C.c_void_p
+		L.v2mh_graph_from_arrays.argtypes = [C.c_uint64, C.c_uint64] + [C.c_void_p] * 5 + [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32]
 		L.v2mh_write_graph.restype = C.c_int
 		L.v2mh_write_graph.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]
 		L.v2mh_read_graph.restype = C.c_void_p
@@ -59,10 +61,12 @@ def _arr(ptr, n, dtype):
 class HostGraph:
 	"""Result of the host's build_variant_graph (without the final transpose)."""
 
-	def __init__(self, fasta_path, vcf_path, chr_id, seq_id=None, exclude_sample=None, exclude_copy=-1, threads=0, _graph_file=None):
+	def __init__(self, fasta_path, vcf_path, chr_id, seq_id=None, exclude_sample=None, exclude_copy=-1, threads=0, _graph_file=None, _handle=None):
 		L = _load()
 		err = C.create_string_buffer(512)
-		if _graph_file is not None:
+		if _handle is not None:
+			h = _handle
+		elif _graph_file is not None:
 			h = L.v2mh_read_graph(str(_graph_file).encode(), err, len(err))
 		else:
 			h = L.v2mh_build_variant_graph(str(fasta_path).encode(), seq_id.encode() if seq_id else None, str(vcf_path).encode(), chr_id.encode(),
@@ -102,6 +106,16 @@ class HostGraph:
 				self._h = None
 		except Exception:
 			pass
+
+	@classmethod
+	def from_arrays(cls, graph, paths_by_edge_and_chrom_copy, path_rows, path_cols, n_samples, ploidy):
+		"""A host graph from a VariantGraph-like object plus the (copies x edges) path matrix words."""
+		u64 = lambda x: np.ascontiguousarray(x, dtype=np.uint64)
+		a = [u64(graph.reference_positions), u64(graph.aligned_positions), u64(graph.alt_edge_targets), u64(graph.alt_edge_count_csum), u64(graph.label_offsets)]
+		pw = u64(paths_by_edge_and_chrom_copy)
+		h = _load().v2mh_graph_from_arrays(len(a[0]), len(a[2]), a[0].ctypes.data, a[1].ctypes.data, a[2].ctypes.data, a[3].ctypes.data, a[4].ctypes.data,
+			bytes(graph.label_bytes) + b"\0", pw.ctypes.data if pw.size else None, path_rows, path_cols, n_samples, ploidy)
+		return cls(None, None, None, _handle=h)
 
 	@classmethod
 	def read(cls, path):
