@@ -67,7 +67,7 @@ def main():
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
 	ap.add_argument("--config", default="config3", help="synthetic workload (vcf2multialign_amd/synth.py CONFIGS)")
-	ap.add_argument("--batch-rows", type=int, default=512, help="rows per splice launch (one device output buffer of this many rows is reused)")
+	ap.add_argument("--batch-rows", type=int, default=640, help="rows per splice launch (one device output buffer of this many rows is reused)")
 	ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal of N > 1)")
 	ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this HIP device")
 	ap.add_argument("--output-candidates", type=int, default=3, help="device buffers v2m_alloc_output may try for the output (1 = plain allocation)")
