@@ -17,7 +17,8 @@ ds.fill_paths_device(ctx.stream, src.data_ptr(), thr.data_ptr(), 0, hp)
 ctx.transpose_bits_device(src.data_ptr(), hp, ds.path_rows, dst.data_ptr())
 ctx.set_paths_device(dst.data_ptr(), ds.path_rows, hp)
 pitch = ctx.min_row_pitch
-out = ctx.alloc_output(640 * pitch, 3)
+BIG = int(os.environ.get('SWEEP_ROWS_CAP', '640'))
+out = ctx.alloc_output(BIG * pitch, 1 if BIG > 700 else 3)
 ctx.synchronize(); ctx.profile_enable(True)
 L = g.aligned_length
 for rows in (640, 512, 314, 256, 157, 128, 64, 640):
@@ -30,7 +31,7 @@ for rows in (640, 512, 314, 256, 157, 128, 64, 640):
 	t, r = min(x for x, _ in ts[1:]), min(y for _, y in ts[1:])
 	print("%4d rows: splice %.3f ms = %.0f GB/s   resolve %.3f ms" % (rows, t, rows * L / t / 1e6, r))
 # same row counts, rows spread over the whole 64-GB buffer (larger pitch): is it the address footprint?
-for rows, mult in ((314, 2), (157, 4), (64, 10), (314, 1), (32, 20), (16, 40)):
+for rows, mult in ((314, 2), (157, 4), (64, 10), (314, 1), (32, 20), (16, 40)) + (((640, 2), (640, 3), (320, 4), (320, 6), (640, 1), (960, 2), (1280, 1), (1920, 1)) if BIG >= 1920 else ()):
 	b = v2m.RowBatch(list(range(rows)))
 	ts = []
 	for rep in range(4):
