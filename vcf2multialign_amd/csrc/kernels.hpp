@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void expand_reference_row_kernel(
 // overlappable (set or not: every earlier target is <= its source).  Both the mask and hence the
 // restart points are properties of the uploaded graph, computed once.
 //
-// resolve_effective_edges_kernel: one thread per (row, 64-edge word), fully coalesced.  A word
+// resolve_effective_edges_kernel: one thread per (row, 64-edge word), fully coalesced (grid.y = row).  A word
 // with no set overlappable bit is copied through.  Otherwise the thread finds its restart
 // point in the static mask and replays the row's set bits from there to the end of its own
 // word.  A restart point more than kMaxBackWords away
@@ -270,11 +270,13 @@ constexpr u32 kMaxBackWords = 2048;   // default max_back_words: restart points 
 __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
 	row_segments rs, edge_span const *__restrict__ spans, u64 const *__restrict__ overlappable,
-	u64 *__restrict__ eff, u32 n_words, u32 n_rows, u32 *__restrict__ needs_serial, u32 max_back_words)
+	u64 *__restrict__ eff, u32 n_words, u32 row_base, u32 *__restrict__ needs_serial, u32 max_back_words)
 {
-	u64 const idx = (u64) blockIdx.x * blockDim.x + threadIdx.x;
-	if (idx >= (u64) n_rows * n_words) return;
-	u32 const row = (u32) (idx / n_words), wi = (u32) (idx % n_words);
+	// grid: x over the row's words, y over rows -- the row (and with it the segment table lookups below) is uniform
+	// per workgroup, so those loads are scalar and leave the per-lane path with the one coalesced word load
+	u32 const row = blockIdx.y + row_base;
+	u32 const wi = blockIdx.x * blockDim.x + threadIdx.x;
+	if (wi >= n_words) return;
 	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
 	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;   // padding bits are zero by contract; do not trust them
 

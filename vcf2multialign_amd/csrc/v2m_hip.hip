@@ -181,14 +181,16 @@ int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64
 {
 	u64 const SW(n_rows / 64), DW(n_cols / 64);
 	char const *e(std::getenv("V2M_TRANSPOSE_PANEL"));   // tuning knob: "8x8", "8x16", "16x8", "4x16", "16x4"
-	std::string const shape((e && *e) ? e : "4x16");   // tools/tune_transpose.py: 4x16 2.1 TB/s, 8x8 2.0, 16x4 1.8, 8x16 / 16x8 1.4 (config-3 matrix)
-	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, d_dst);
+	// tools/tune_transpose.py (config-3 matrix, 5056 x 1M bits): 4x16 2.1 TB/s, 8x8 2.0, 16x4 1.8, 8x16 / 16x8 1.4;
+	// config-5 matrix (20032 x 6.2M bits): 8x8 11.3 ms, 4x16 20.7 ms -> 8x8 is the robust choice
+	std::string const shape((e && *e) ? e : "8x8");
+	if (shape == "4x16") return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, d_dst);
 	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, d_dst);
 	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, d_dst);
 	if (shape == "4x8") return launch_transpose_shape<4, 8>(ctx, d_src, SW, DW, d_dst);
 	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, d_dst);
 	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, d_dst);
-	return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, d_dst);
+	return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, d_dst);
 }
 
 
@@ -278,16 +280,16 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 	V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_needs_serial.p, 0, n_rows * sizeof(u32), ctx->stream));
 
 	v2m::row_segments rs{ctx->d_seg_offsets.as<u32>(), ctx->d_seg_edge_begin.as<u32>(), ctx->d_seg_copy.as<u32>()};
-	u64 const n_threads(n_rows * eff_words);
 	char const *const back_env(std::getenv("V2M_MAX_BACK_WORDS"));   // test knob: 0 forces the serial kernel for every cross-word restart
 	u32 const max_back_words((back_env && *back_env) ? u32(std::strtoul(back_env, nullptr, 10)) : v2m::kMaxBackWords);
-	if ((n_threads + 255) / 256 > 0x7FFFFFFFull)
-		return fail(ctx, V2M_ERR_UNSUPPORTED, "resolve grid too large; use smaller batches");
 	{
 		timed_launch tl(ctx, V2M_KERNEL_RESOLVE);
-		hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_threads + 255) / 256)), dim3(256), 0, ctx->stream,
-			ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
-			ctx->d_eff.as<u64>(), u32(eff_words), u32(n_rows), ctx->d_needs_serial.as<u32>(), max_back_words);
+		for (u64 r0(0); r0 < n_rows; r0 += 65535) {   // grid.y limit
+			u64 const nr(std::min<u64>(65535, n_rows - r0));
+			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((eff_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
+				ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
+				ctx->d_eff.as<u64>(), u32(eff_words), u32(r0), ctx->d_needs_serial.as<u32>(), max_back_words);
+		}
 		// rows whose restart point is too far back for the per-word kernel (chromosome-scale deletions)
 		hipLaunchKernelGGL(v2m::resolve_rows_serial_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
 			ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(),
