@@ -70,8 +70,10 @@ def test_transpose_fixed(ctx, case):   # tests/transpose_matrix.cc:188-251
 	assert np.array_equal(ctx.transpose_matrix(src, case["rows"], case["cols"]), exp)
 
 
-@pytest.mark.parametrize("h,w", [(1, 1), (1, 2), (2, 1), (3, 5), (8, 8), (9, 7), (16, 17), (79, 33), (5, 130), (64, 64)])
-def test_transpose_random(ctx, h, w):  # tests/transpose_matrix.cc:254-279 (1/3 of the bits set), plus ragged panels
+@pytest.mark.parametrize("kernel", ["8x8", "stream16", "4x16"])
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 2), (2, 1), (3, 5), (8, 8), (9, 7), (16, 17), (79, 33), (5, 130), (64, 64), (17, 15), (33, 31)])
+def test_transpose_random(ctx, monkeypatch, kernel, h, w):  # tests/transpose_matrix.cc:254-279 (1/3 of the bits set), plus ragged panels
+	monkeypatch.setenv("V2M_TRANSPOSE_PANEL", kernel)   # both transpose kernels (the library picks per shape by measurement)
 	rng = np.random.default_rng(1000 * h + w)
 	rows, cols = 64 * h, 64 * w
 	src = rng.integers(0, 2 ** 63, size=rows * cols // 64, dtype=np.uint64) & rng.integers(0, 2 ** 63, size=rows * cols // 64, dtype=np.uint64)

@@ -12,7 +12,7 @@ n = hp // 64 * ep
 src = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device="cuda")
 dst = torch.empty_like(src); back = torch.empty_like(src)
 torch.cuda.synchronize(); ctx.profile_enable(True)
-for shape in ("8x8", "8x16", "16x8", "4x16", "16x4", "4x8", "8x4", "8x8", "8x16"):
+for shape in ("8x8", "stream16", "4x16", "8x8", "stream16"):
 	os.environ["V2M_TRANSPOSE_PANEL"] = shape
 	ts = []
 	for rep in range(4):

@@ -144,6 +144,83 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 }
 
 
+// Streaming variant: a workgroup owns kR = 16 source row-words (a full 128-B line of every source column) and
+// kC = 16 column groups (a full 128-B line of every destination column), but only one 64-column group of the
+// source is in LDS at a time (double-buffered, one barrier per group).  Each wave keeps the transposed tiles of
+// its 4 row-words in registers across the 16 groups (lane = destination column, 16 words = 128 contiguous
+// bytes of it) and writes them out through a wave-private LDS slab, so that 16 consecutive lanes store one
+// destination column's 128 bytes.  Both HBM sides move whole 128-B runs.
+constexpr int kTsR = 16, kTsC = 16;
+
+__global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW)
+{
+	constexpr int kA = kTsR / 4;                         // row-words per wave
+	__shared__ u64 in[2][64][kTsR + 1];
+	__shared__ u64 slab[kTrThreads / 64][64][kTsC + 1];
+
+	int const t = threadIdx.x;
+	int const lane = t & 63;
+	int const wave = t >> 6;
+	u64 const rw0 = (u64) blockIdx.x * kTsR;
+	u64 const cg0 = (u64) blockIdx.y * kTsC;
+	u64 const n_cols = DW * 64;
+
+	// one sub-panel = 64 columns x 16 row-words; 16 consecutive lanes fetch one column's 128 contiguous bytes.
+	// Two sub-panels are kept in flight in registers (the kernel is bound by bytes in flight, not by the shuffles).
+	constexpr int kPer = (64 * kTsR) / kTrThreads;
+	u64 stage[2][kPer];
+	auto fetch = [&](int cg, u64 (&st)[kPer]) {
+#pragma unroll
+		for (int k = 0; k < kPer; ++k) {
+			int const idx = t + kTrThreads * k;
+			int const col = idx / kTsR, w = idx % kTsR;
+			u64 const gcol = (cg0 + cg) * 64 + col;
+			st[k] = (gcol < n_cols && rw0 + w < SW) ? src[gcol * SW + rw0 + w] : 0;
+		}
+	};
+	auto stash = [&](int buf, u64 const (&st)[kPer]) {
+#pragma unroll
+		for (int k = 0; k < kPer; ++k) {
+			int const idx = t + kTrThreads * k;
+			in[buf][idx / kTsR][idx % kTsR] = st[k];
+		}
+	};
+
+	u64 y[kA][kTsC];
+	fetch(0, stage[0]);
+	fetch(1, stage[1]);
+	stash(0, stage[0]);
+#pragma unroll
+	for (int cg = 0; cg < kTsC; ++cg) {
+		__syncthreads();                                 // in[cg & 1] is complete; everyone is done with in[(cg + 1) & 1]
+		if (cg + 2 < kTsC) fetch(cg + 2, stage[cg & 1]); // stage[cg & 1] was stashed for this group already
+#pragma unroll
+		for (int a = 0; a < kA; ++a)
+			y[a][cg] = wave_transpose_64x64(in[cg & 1][lane][kA * wave + a], lane);
+		if (cg + 1 < kTsC) stash((cg + 1) & 1, stage[(cg + 1) & 1]);
+	}
+
+	// write-out, one row-word at a time through the wave's own slab (LDS operations of one wave execute in order)
+#pragma unroll
+	for (int a = 0; a < kA; ++a) {
+		u64 const rw = rw0 + kA * wave + a;
+#pragma unroll
+		for (int cg = 0; cg < kTsC; ++cg)
+			slab[wave][lane][cg] = y[a][cg];
+		if (rw < SW) {
+#pragma unroll
+			for (int k = 0; k < kTsC; ++k) {
+				int const idx = lane + 64 * k;
+				int const dcol = idx / kTsC, cw = idx % kTsC;
+				if (cg0 + cw < DW)
+					dst[(rw * 64 + dcol) * DW + cg0 + cw] = slab[wave][dcol][cw];
+			}
+		}
+	}
+}
+
+
 // ---------------------------------------------------------------------------------------------
 // The gap-aligned REF row ("template"): what output_sequence() emits for
 // chromosome_copy_index == PLOIDY_MAX (sequence_writer.cc:49,70-81): for every node its reference

@@ -94,6 +94,9 @@ struct v2m_ctx {
 	dev_buf owned_paths;
 	u64 path_rows{}, path_cols{};
 
+	struct transpose_pick { u64 rows, cols; bool stream; };
+	std::vector<transpose_pick> transpose_choice;   // per matrix shape: which transpose kernel measured faster
+
 	// store flavour of the aligned splice: -1 = not calibrated yet, 0 = plain, 1 = nontemporal
 	int store_mode{-1};
 	std::string info;
@@ -177,13 +180,21 @@ int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *
 	return V2M_OK;
 }
 
-int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst)
+int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
 {
-	u64 const SW(n_rows / 64), DW(n_cols / 64);
-	char const *e(std::getenv("V2M_TRANSPOSE_PANEL"));   // tuning knob: "8x8", "8x16", "16x8", "4x16", "16x4"
-	// tools/tune_transpose.py (config-3 matrix, 5056 x 1M bits): 4x16 2.1 TB/s, 8x8 2.0, 16x4 1.8, 8x16 / 16x8 1.4;
-	// config-5 matrix (20032 x 6.2M bits): 8x8 11.3 ms, 4x16 20.7 ms -> 8x8 is the robust choice
-	std::string const shape((e && *e) ? e : "8x8");
+	u64 const gx((SW + v2m::kTsR - 1) / v2m::kTsR), gy((DW + v2m::kTsC - 1) / v2m::kTsC);
+	if (gy > 65535 || gx > 0x7FFFFFFFu) return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
+	{
+		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
+		hipLaunchKernelGGL(v2m::transpose_bits_stream_kernel, dim3((unsigned) gx, (unsigned) gy), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW);
+	}
+	V2M_HIP_TRY(ctx, hipGetLastError());
+	return V2M_OK;
+}
+
+int launch_transpose_named(v2m_ctx *ctx, std::string const &shape, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
+{
+	if (shape == "stream16") return launch_transpose_stream(ctx, d_src, SW, DW, d_dst);
 	if (shape == "4x16") return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, d_dst);
 	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, d_dst);
 	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, d_dst);
@@ -191,6 +202,51 @@ int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64
 	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, d_dst);
 	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, d_dst);
 	return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, d_dst);
+}
+
+// Two kernels implement the transpose: the 8x8 LDS panel and the streaming 16x16 one.  Which is faster depends on
+// the matrix shape (tools/tune_transpose.py: 5056 x 1M bits -> streaming 0.45 ms vs panel 0.60 ms; 20032 x 6.2M bits
+// -> panel 11.3 ms vs streaming 13.2 ms), so matrices of at least 32 MiB are timed once per shape and context with both
+// (the result is the same either way) and the faster kernel is remembered.  V2M_TRANSPOSE_PANEL forces one.
+int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst)
+{
+	u64 const SW(n_rows / 64), DW(n_cols / 64);
+	char const *e(std::getenv("V2M_TRANSPOSE_PANEL"));
+	if (e && *e) return launch_transpose_named(ctx, e, d_src, SW, DW, d_dst);
+	if (SW * DW * 512 < (u64(32) << 20)) return launch_transpose_named(ctx, "8x8", d_src, SW, DW, d_dst);
+	for (auto const &c : ctx->transpose_choice)
+		if (c.rows == n_rows && c.cols == n_cols) return launch_transpose_named(ctx, c.stream ? "stream16" : "8x8", d_src, SW, DW, d_dst);
+
+	hipEvent_t ev[3];
+	for (auto &x : ev) V2M_HIP_TRY(ctx, hipEventCreate(&x));
+	float t[2] = {0, 0};
+	bool const was_profiling(ctx->profiling);
+	ctx->profiling = false;   // the calibration launches are not the caller's
+	int rc(V2M_OK);
+	for (int rep(0); rep < 2 && V2M_OK == rc; ++rep) {   // second round's times count (first touches the pages)
+		V2M_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+		rc = launch_transpose_named(ctx, "8x8", d_src, SW, DW, d_dst);
+		V2M_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+		if (V2M_OK == rc) rc = launch_transpose_named(ctx, "stream16", d_src, SW, DW, d_dst);
+		V2M_HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
+		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		V2M_HIP_TRY(ctx, hipEventElapsedTime(&t[0], ev[0], ev[1]));
+		V2M_HIP_TRY(ctx, hipEventElapsedTime(&t[1], ev[1], ev[2]));
+	}
+	ctx->profiling = was_profiling;
+	for (auto &x : ev) (void) hipEventDestroy(x);
+	if (V2M_OK != rc) return rc;
+	bool const stream(t[1] < t[0]);
+	ctx->transpose_choice.push_back({n_rows, n_cols, stream});
+	char buf[160];
+	std::snprintf(buf, sizeof(buf), "transpose %llux%llu bits: %s kernel (panel 8x8 %.3f ms, streaming 16x16 %.3f ms)",
+		(unsigned long long) n_rows, (unsigned long long) n_cols, stream ? "streaming" : "panel", t[0], t[1]);
+	if (ctx->info.size() > 2000) ctx->info.clear();
+	if (!ctx->info.empty()) ctx->info += "; ";
+	ctx->info += buf;
+	// the calibration already produced the result; run the chosen kernel once more under the caller's profiling so
+	// that its launch is accounted for like any other
+	return launch_transpose_named(ctx, stream ? "stream16" : "8x8", d_src, SW, DW, d_dst);
 }
 
 
