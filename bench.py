@@ -67,7 +67,8 @@ def main():
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
 	ap.add_argument("--config", default="config3", help="synthetic workload (vcf2multialign_amd/synth.py CONFIGS)")
-	ap.add_argument("--batch-rows", type=int, default=640, help="rows per splice launch (one device output buffer of this many rows is reused)")
+	ap.add_argument("--batch-rows", type=int, default=0, help="rows per splice launch (one device output buffer of this many rows is reused); 0 = as many as fit --batch-gb")
+	ap.add_argument("--batch-gb", type=float, default=64.0, help="size of the reused device output buffer when --batch-rows is 0: launches that write a ~64-GB address range reach the full HBM write rate (DESIGN.md section 4)")
 	ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal of N > 1)")
 	ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this HIP device")
 	ap.add_argument("--output-candidates", type=int, default=3, help="device buffers v2m_alloc_output may try for the output (1 = plain allocation)")
@@ -126,7 +127,8 @@ def main():
 	total_rows = H + 1
 
 	# equal-sized batches of at most --batch-rows rows (5009 rows -> 10 x 501 rather than 9 x 512 + 401)
-	n_batches = max(1, -(-n_rows // max(1, args.batch_rows)))
+	max_batch_rows = args.batch_rows if args.batch_rows > 0 else max(1, int(args.batch_gb * 1e9) // pitch)
+	n_batches = max(1, -(-n_rows // max(1, max_batch_rows)))
 	batch_rows = max(1, -(-n_rows // n_batches))
 	# Output buffer: placement matters on this hardware, so the library picks it by measurement.
 	out_bytes = batch_rows * pitch
@@ -196,7 +198,7 @@ def main():
 	try:
 		with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
 			rec = json.load(f).get(args.config)
-		if rec and rec["batch_rows"] == args.batch_rows and rec["n_gpus"] == world:
+		if rec and rec["batch_rows"] == batch_rows and rec["n_gpus"] == world:
 			traffic, traffic_source = rec["hbm_bytes_per_launch"], rec["source"]
 	except (OSError, ValueError, KeyError):
 		pass
