@@ -7,7 +7,8 @@ import numpy as np, torch
 import vcf2multialign_amd as v2m
 from vcf2multialign_amd import _native as N
 ctx = v2m.Context(0)
-hp, ep = 5056, 1000000
+hp, ep = (int(x) for x in (sys.argv[1:3] if len(sys.argv) > 2 else (5056, 1000000)))
+print("matrix %d x %d bits" % (hp, ep))
 n = hp // 64 * ep
 src = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device="cuda")
 dst = torch.empty_like(src); back = torch.empty_like(src)

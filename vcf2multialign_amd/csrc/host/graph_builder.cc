@@ -21,7 +21,7 @@ alt_kind classify_alt(std::string_view alt)
 }
 
 
-graph_builder::graph_builder(variant_graph &graph, bool track_paths) : m_graph(graph), m_track_paths(track_paths)
+graph_builder::graph_builder(variant_graph &graph, bool track_paths, u64 path_alignment) : m_graph(graph), m_track_paths(track_paths), m_path_alignment(path_alignment < 64 ? 64 : (path_alignment + 63) / 64 * 64)
 {
 	m_graph.alt_edge_count_csum.assign(1, 0);   // variant_graph.cc:147
 	add_node(0, 0);                             // variant_graph.cc:148
@@ -35,7 +35,7 @@ void graph_builder::begin(std::vector<std::string> sample_names, std::vector<u32
 	for (u32 const p : ploidies) m_graph.ploidy_csum.push_back(m_graph.ploidy_csum.back() + p);
 	u64 const copies(m_graph.ploidy_csum.back());
 	if (m_track_paths) {
-		u64 const rows(64 * ((copies + 63) / 64));                    // variant_graph.cc:277
+		u64 const rows(m_path_alignment * ((copies + m_path_alignment - 1) / m_path_alignment));   // variant_graph.cc:277
 		m_graph.paths_by_edge_and_chrom_copy = bit_matrix(rows, rows ? 512 : 0);
 		m_target_ref_pos_by_copy.assign(copies, 0);
 	}
@@ -143,7 +143,7 @@ void graph_builder::finish(u64 ref_length)
 	flush_targets(ref_length);                                        // :437-443
 	add_or_update_node(ref_length, m_aln_pos + (ref_length - m_prev_ref_pos));
 	if (m_track_paths)
-		m_graph.paths_by_edge_and_chrom_copy.set_column_count(64 * ((m_graph.edge_count() + 63) / 64));   // :445-451
+		m_graph.paths_by_edge_and_chrom_copy.set_column_count(m_path_alignment * ((m_graph.edge_count() + m_path_alignment - 1) / m_path_alignment));   // :445-451
 	// variant_graph.cc:453 (paths_by_chrom_copy_and_edge = transpose_matrix(...)) is the caller's next
 	// step and runs on the GPU: see transpose_paths() in gpu_path.cc.  There is no CPU transpose here.
 }

@@ -37,7 +37,10 @@ public:
 
 	// track_paths == false builds nodes/edges only (the path matrix is then produced elsewhere,
 	// e.g. directly in HBM by the synthetic generator).
-	graph_builder(variant_graph &graph, bool track_paths = true);
+	// path_alignment: both dimensions of paths_by_edge_and_chrom_copy are padded to a multiple of it.  64 is what the
+	// reference does (variant_graph.cc:277,449); 1024 makes every matrix column start on a 128-B line, which the GPU
+	// transpose rewards.  Padding rows and columns are zero either way.
+	graph_builder(variant_graph &graph, bool track_paths = true, u64 path_alignment = 64);
 
 	// Must be called once before the first record, with the ploidy of every (included) sample
 	// (variant_graph.cc:215-288: taken from the first matching record).
@@ -75,6 +78,7 @@ private:
 
 	variant_graph &m_graph;
 	bool m_track_paths;
+	u64 m_path_alignment;
 	std::priority_queue<pending_target, std::vector<pending_target>, std::greater<pending_target>> m_pending;
 	u64 m_seq{};
 	u64 m_aln_pos{};

@@ -241,7 +241,7 @@ int main(int argc, char **argv)
 			}
 			std::cerr << "Building the variant graph...\n";
 			vh::build_graph_statistics stats;
-			vh::build_variant_graph(ref_seq, opt.input_variants, opt.chromosome, graph, stats, delegate);
+			vh::build_variant_graph(ref_seq, opt.input_variants, opt.chromosome, graph, stats, delegate, 0, 1024);   // 1024-bit matrix padding: whole 128-B lines for the GPU transpose
 			vh::transpose_paths(gpu, graph);   // variant_graph.cc:453, on the GPU
 			std::cerr << "Done. Handled variants: " << stats.handled_variants << " Chromosome ID mismatches: " << stats.chr_id_mismatches << '\n';
 			if (0 == stats.handled_variants) std::cerr << "WARNING: no variants matched the chromosome identifier \"" << opt.chromosome << "\".\n";

@@ -224,14 +224,14 @@ void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &
 
 void build_variant_graph(
 	sequence_type const &ref_seq, char const *variants_path, char const *chr_id,
-	variant_graph &graph, build_graph_statistics &stats, build_graph_delegate &delegate, unsigned threads)
+	variant_graph &graph, build_graph_statistics &stats, build_graph_delegate &delegate, unsigned threads, u64 path_alignment)
 {
 	mapped_file const file(variants_path);
 	std::string_view const text(file.data, file.size);
 	std::string_view const ref_sv(ref_seq.data(), ref_seq.size());
 
 	graph = variant_graph{};
-	graph_builder builder(graph, /* track_paths */ true);
+	graph_builder builder(graph, /* track_paths */ true, path_alignment);
 
 	// ---- header, then the first record on the requested chromosome: it fixes ploidy and inclusion (:215-288) ----
 	parse_context ctx;

@@ -42,9 +42,9 @@ struct build_graph_statistics {
 // The reference parses and builds on one thread.  Here the genotype text -- 5 * 10^9 fields at config 3 -- is
 // parsed by `threads` workers over 8-MB chunks of whole lines into sparse (copy, allele) lists, and one thread
 // merges the chunks in file order through graph_builder, so the graph and the delegate calls are exactly those
-// of a sequential pass.  threads == 0: one per hardware thread, at most 16.
+// of a sequential pass.  threads == 0: one per hardware thread, at most 16.  path_alignment: see graph_builder.
 void build_variant_graph(
 	sequence_type const &ref_seq, char const *variants_path, char const *chr_id,
-	variant_graph &graph, build_graph_statistics &stats, build_graph_delegate &delegate, unsigned threads = 0);
+	variant_graph &graph, build_graph_statistics &stats, build_graph_delegate &delegate, unsigned threads = 0, u64 path_alignment = 64);
 
 } // namespace v2m::host
