@@ -347,7 +347,7 @@ constexpr u32 kMaxBackWords = 2048;   // default max_back_words: restart points 
 __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
 	row_segments rs, edge_span const *__restrict__ spans, u64 const *__restrict__ overlappable,
-	u64 *__restrict__ eff, u32 n_words, u32 row_base, u32 *__restrict__ needs_serial, u32 max_back_words)
+	u64 *__restrict__ eff, u32 n_words, u32 eff_words_per_row, u32 row_base, u32 *__restrict__ needs_serial, u32 max_back_words)
 {
 	// grid: x over the row's words, y over rows -- the row (and with it the segment table lookups below) is uniform
 	// per workgroup, so those loads are scalar and leave the per-lane path with the one coalesced word load
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 			}
 		}
 	}
-	eff[(u64) row * n_words + wi] = out;
+	eff[(u64) row * eff_words_per_row + wi] = out;
 }
 
 

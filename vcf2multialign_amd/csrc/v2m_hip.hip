@@ -317,11 +317,15 @@ u32 rows_per_group_for(u64 n_rows)
 }
 
 
+// Words per row of the effective-edge scratch: the edge count in 64-bit words, rounded up to a whole 128-B line so
+// that every row starts line-aligned.
+u64 eff_row_words(v2m_ctx const *ctx) { return (((ctx->n_edges + 63) / 64) + 15) & ~u64(15); }
+
 // Effective-edge bits of rows [row_begin, row_end) of the batch into ctx->d_eff.
 int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row_end)
 {
 	u64 const n_rows(row_end - row_begin);
-	u64 const eff_words((ctx->n_edges + 63) / 64);
+	u64 const eff_words(eff_row_words(ctx)), n_words((ctx->n_edges + 63) / 64);
 	if (0 == ctx->n_edges) return V2M_OK;
 
 	prepared_rows pr;
@@ -342,9 +346,9 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 		timed_launch tl(ctx, V2M_KERNEL_RESOLVE);
 		for (u64 r0(0); r0 < n_rows; r0 += 65535) {   // grid.y limit
 			u64 const nr(std::min<u64>(65535, n_rows - r0));
-			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((eff_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
+			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
 				ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
-				ctx->d_eff.as<u64>(), u32(eff_words), u32(r0), ctx->d_needs_serial.as<u32>(), max_back_words);
+				ctx->d_eff.as<u64>(), u32(n_words), u32(eff_words), u32(r0), ctx->d_needs_serial.as<u32>(), max_back_words);
 		}
 		// rows whose restart point is too far back for the per-word kernel (chromosome-scale deletions)
 		hipLaunchKernelGGL(v2m::resolve_rows_serial_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
@@ -388,7 +392,7 @@ int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin,
 	if (0 == n_rows || 0 == ctx->aligned_len) return V2M_OK;
 	if (int const rc = resolve_slice(ctx, rows, row_begin, row_end)) return rc;
 
-	u64 const eff_words((ctx->n_edges + 63) / 64);
+	u64 const eff_words(eff_row_words(ctx));
 	splice_grid g;
 	if (int const rc = make_grid(ctx, n_rows, g)) return rc;
 	v2m::tile_tables tt{ctx->d_tile_edge_begin.as<u32>(), ctx->d_cross_offsets.as<u32>(), ctx->d_cross_edges.as<u32>()};
@@ -468,7 +472,7 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 	}
 	if (int const rc = resolve_slice(ctx, rows, row_begin, row_end)) return rc;
 
-	u64 const eff_words((ctx->n_edges + 63) / 64);
+	u64 const eff_words(eff_row_words(ctx));
 	splice_grid g;
 	if (int const rc = make_grid(ctx, n_rows, g)) return rc;
 	V2M_HIP_TRY(ctx, ctx->d_tile_counts.ensure(n_rows * ctx->n_tiles * sizeof(u32)));
