@@ -31,7 +31,6 @@ constexpr int kSpliceThreads = 256;
 constexpr int kTileChunks = kTileBytes / 16;          // 16-B chunks per tile (1024)
 constexpr int kChunksPerThread = kTileChunks / kSpliceThreads;   // 4
 constexpr int kLongPatch = 96;                        // patches longer than this are filled by a whole wave
-constexpr int kLongQueue = 64;
 
 // Per-edge patch descriptor: where the edge's label + padding lands in aligned co-ordinates.
 struct __attribute__((aligned(16))) edge_patch {
