@@ -532,7 +532,7 @@ __device__ __forceinline__ void fill_patch_bytes(
 // (config 5: one edge per 40 bp).  Edges that cross into the tile from the left, candidates beyond the cache
 // and spans longer than kLongPatch take the global-memory path.
 constexpr int kCandLds = 512;
-constexpr int kLabelLds = 2048;
+constexpr int kLabelLds = 1024;
 constexpr int kGroupRowsLds = 16;
 constexpr int kEffWordsLds = kCandLds / 64 + 2;
 constexpr int kLongQueueLds = 16;
@@ -764,9 +764,9 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_aligned_kernel(
 //                                      template tile's own count plus, per effective edge, the label bytes it
 //                                      puts into the tile minus the template bytes its span removes
 //           scan_tile_counts_kernel    exclusive prefix sum per row -> tile offsets, row lengths
-//   pass 2  splice_unaligned_kernel    builds each tile, compacts it in LDS at the destination's 16-B phase and
-//                                      streams it out (16-B stores inside, byte stores on the ragged first/last
-//                                      chunk, which neighbouring tiles share).
+//   pass 2  splice_unaligned_kernel    builds each tile and streams it out chunk by chunk: a 16-B chunk without padding
+//                                      goes out as one 16-B store at its (byte-granular) destination, a chunk that
+//                                      contains padding as single bytes.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ u32 zero_bytes_mask(u32 x)
 {
@@ -840,6 +840,8 @@ __global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
 		tile_counts[(u64) (row_begin + r) * n_tiles + tile] = (u32) ((int) tile_count + row_delta[r]);
 }
 
+typedef vec4u vec4u_unaligned __attribute__((aligned(1)));   // 16-B access at any byte address (gfx950 / HSA unaligned access mode; tools/unaligned_store_test.hip)
+
 __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
 	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
@@ -847,9 +849,8 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	char *__restrict__ out, u64 row_pitch, u32 n_rows, u32 rows_per_group, u32 n_groups, u32 tile_run)
 {
 	__shared__ vec4u lds[kTileChunks];
-	__shared__ vec4u comp[kTileChunks + 1];
 	__shared__ patch_cache pc;
-	__shared__ u32 wave_sums[kSpliceThreads / 64];
+	__shared__ u32 wave_sums[kChunksPerThread][kSpliceThreads / 64];
 
 	int const t = threadIdx.x;
 	int const lane = t & 63, wave = t >> 6;
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	load_patch_cache(pc, job, tt, patches, labels, eff, eff_words_per_row, tile, row_begin, row_end - row_begin, t);
 
 	for (u32 row = row_begin; row < row_end; ++row) {
-		__syncthreads();   // the previous row's readers of lds/comp are done
+		// (everybody read the previous row's tile before the barrier that follows its scan, so no barrier is needed here)
 #pragma unroll
 		for (int k = 0; k < kChunksPerThread; ++k)
 			lds[t + kSpliceThreads * k] = pristine[k];
@@ -875,88 +876,55 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 
 		patch_row_tile((unsigned char *) lds, pc, job, tt, patches, labels, eff + (u64) row * eff_words_per_row, row - row_begin, t, 0);
 
-		// each thread owns 64 contiguous tile bytes: count what survives
-		vec4u v[4];
-		u32 mine = 0;
+		// Thread t owns the 16-B chunks t, t + 256, ... (lane-contiguous, like the aligned kernel).  Where a chunk's
+		// surviving bytes go = the number of surviving bytes in all chunks before it, in chunk order.
+		vec4u v[kChunksPerThread];
+		u32 cnt[kChunksPerThread], incl[kChunksPerThread];
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			v[k] = lds[4 * t + k];
+		for (int k = 0; k < kChunksPerThread; ++k) {
+			v[k] = lds[t + kSpliceThreads * k];
+			u32 zeros = 0;
 #pragma unroll
-			for (int d = 0; d < 4; ++d)
-				mine += 4 - __builtin_popcount(zero_bytes_mask(v[k][d]));
-		}
-		// block-wide exclusive scan of `mine`
-		u32 incl = mine;
+			for (int d = 0; d < 4; ++d) zeros += __builtin_popcount(zero_bytes_mask(v[k][d]));
+			cnt[k] = 16 - zeros;
+			u32 s = cnt[k];
 #pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			u32 const o = __shfl_up(incl, d, kWave);
-			if (lane >= d) incl += o;
-		}
-		if (lane == 63) wave_sums[wave] = incl;
-		__syncthreads();
-		u32 before = 0, total = 0;
-#pragma unroll
-		for (int wv = 0; wv < kSpliceThreads / 64; ++wv) {
-			u32 const ws = wave_sums[wv];
-			if (wv < wave) before += ws;
-			total += ws;
-		}
-
-		u32 const row_off = tile_offsets[(u64) row * n_tiles + tile];   // where this tile's bytes start in the unaligned row
-		u32 const phase = row_off & 15;
-		unsigned char *const c8 = (unsigned char *) comp;
-		u32 *const c32 = (u32 *) comp;
-		// Append the surviving bytes to the compacted image through a 64-bit window that is flushed one aligned dword
-		// at a time; the first dword of the thread's run may be shared with its left neighbour (bytes below `pos`), the
-		// last with its right neighbour: those are written byte-wise, everything between as whole dwords.
-		u32 const pos = phase + before + (incl - mine);
-		u32 out_dword = pos >> 2;
-		u32 fill = pos & 3;              // bytes of the current dword that belong to the left neighbour
-		u32 skip = fill;
-		u64 win = 0;
-#pragma unroll
-		for (int k = 0; k < 4; ++k)
-#pragma unroll
-			for (int d = 0; d < 4; ++d) {
-				u32 const x = v[k][d];
-				u32 const zm = zero_bytes_mask(x);
-				if (0 == zm) {
-					win |= (u64) x << (8 * fill);
-					fill += 4;
-				} else {
-#pragma unroll
-					for (int b = 0; b < 4; ++b) {
-						u32 const ch = (x >> (8 * b)) & 0xFF;
-						if (ch) { win |= (u64) ch << (8 * fill); ++fill; }
-					}
-				}
-				if (fill >= 4) {
-					u32 const w = (u32) win;
-					if (skip) {
-						for (u32 b = skip; b < 4; ++b) c8[4 * out_dword + b] = (unsigned char) (w >> (8 * b));
-						skip = 0;
-					} else {
-						c32[out_dword] = w;
-					}
-					++out_dword;
-					win >>= 32;
-					fill -= 4;
-				}
+			for (int d = 1; d < 64; d <<= 1) {
+				u32 const o = __shfl_up(s, d, kWave);
+				if (lane >= d) s += o;
 			}
-		for (u32 b = skip; b < fill; ++b) c8[4 * out_dword + b] = (unsigned char) ((u32) win >> (8 * b));
+			incl[k] = s;
+			if (lane == 63) wave_sums[k][wave] = s;
+		}
 		__syncthreads();
 
-		char *const dst = out + (u64) row * row_pitch + (row_off - phase);   // 16-B aligned
-		u32 const end = phase + total;
-		for (u32 c = t; c * 16 < end; c += kSpliceThreads) {
-			u32 const lo = c * 16, hi = lo + 16;
-			if (lo >= phase && hi <= end) {
-				*(vec4u *) (dst + lo) = comp[c];
-			} else {
-				for (u32 p = (lo > phase ? lo : phase); p < (hi < end ? hi : end); ++p)
-					dst[p] = (char) c8[p];
+		char *const dst = out + (u64) row * row_pitch + tile_offsets[(u64) row * n_tiles + tile];
+		u32 running = 0;
+#pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k) {
+			u32 before = 0, total = 0;
+#pragma unroll
+			for (int wv = 0; wv < kSpliceThreads / 64; ++wv) {
+				u32 const ws = wave_sums[k][wv];
+				if (wv < wave) before += ws;
+				total += ws;
+			}
+			u32 const off = running + before + incl[k] - cnt[k];
+			running += total;
+			if (16 == cnt[k]) {
+				*(vec4u_unaligned *) (dst + off) = v[k];   // a wave's 64 such stores cover one contiguous KiB at whatever byte phase the row is in
+			} else if (cnt[k]) {
+				u32 p = off;
+#pragma unroll
+				for (int d = 0; d < 4; ++d)
+#pragma unroll
+					for (int bb = 0; bb < 4; ++bb) {
+						unsigned char const ch = (unsigned char) (v[k][d] >> (8 * bb));
+						if (ch) dst[p++] = (char) ch;
+					}
 			}
 		}
+		// wave_sums is rewritten only after the next row's barriers
 	}
 }
 
