@@ -912,7 +912,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			u32 const off = running + before + incl[k] - cnt[k];
 			running += total;
 			if (16 == cnt[k]) {
-				*(vec4u_unaligned *) (dst + off) = v[k];   // a wave's 64 such stores cover one contiguous KiB at whatever byte phase the row is in
+				__builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));   // a wave's 64 such stores cover one contiguous KiB at whatever byte phase the row is in
 			} else if (cnt[k]) {
 				u32 p = off;
 #pragma unroll
