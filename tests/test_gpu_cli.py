@@ -126,6 +126,28 @@ def test_founders_on_a_larger_graph(tmp_path):
 		assert lines[3 + 2 * f] == g.output_sequence(g.ref, cuts=list(zip(cuts[:-1], col))), "founder %d" % (1 + f)
 
 
+def test_sharded_output_over_several_contexts(tmp_path):
+	"""--device=0,0,0: three contexts (here on the same GPU), rows sharded over them, every thread writing its rows at
+	their final file offsets: the file must equal the single-context one, for haplotypes and for founders."""
+	g = synth.build_case(tmp_path, 65, 120000, 1800, 25, long_every=300)
+	fa, vcf = str(tmp_path / "synth.fa"), str(tmp_path / "synth.vcf")
+	one, three = tmp_path / "one.a2m", tmp_path / "three.a2m"
+	assert run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(one)]).returncode == 0
+	r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(three), "--device=0,0,0"])
+	assert r.returncode == 0, r.stderr.decode()
+	exp = tmp_path / "exp.a2m"
+	g.haplotype_output_a2m(g.ref, str(exp))
+	assert one.read_bytes() == exp.read_bytes() == three.read_bytes()
+	assert run(["-F", "7", "-r", fa, "-a", vcf, "-c", "1", "-s", str(one), "--dst-chromosome=chrQ"]).returncode == 0
+	r = run(["-F", "7", "-r", fa, "-a", vcf, "-c", "1", "-s", str(three), "--dst-chromosome=chrQ", "--device=0,0"])
+	assert r.returncode == 0, r.stderr.decode()
+	assert one.read_bytes() == three.read_bytes() and one.read_bytes().count(b">chrQ\t") == 8
+	# unaligned output falls back to the first context
+	assert run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(three), "--unaligned", "--device=0,0"]).returncode == 0
+	g.haplotype_output_a2m(g.ref, str(exp), unaligned=True)
+	assert three.read_bytes() == exp.read_bytes()
+
+
 def test_graph_checkpoint(tmp_path):
 	"""--output-graph then --input-graph: the second run skips the VCF and writes the same A2M (both modes)."""
 	g = synth.build_case(tmp_path, 64, 60000, 900, 12, long_every=200)

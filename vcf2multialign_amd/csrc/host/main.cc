@@ -10,10 +10,12 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <set>
 #include <sstream>
 #include <string>
 #include <tuple>
+#include <vector>
 
 #include "founder.hh"
 #include "gpu_path.hh"
@@ -36,7 +38,7 @@ struct options {
 	char const *input_graph{}, *output_graph{};
 	bool output_sequences_separate{}, separate_plain{}, omit_reference{}, unaligned{}, verbose{}, graph_statistics{};
 	bool ref_mismatch_error{};
-	int device{0};
+	std::vector<int> devices{0};
 };
 
 void usage()
@@ -59,7 +61,8 @@ void usage()
 		"      --ref-mismatch-handling=how    warning (default) or error\n"
 		"      --include-samples=file         TSV (chrom, sample, copy_idx) of the only copies to include\n"
 		"  -x, --exclude-samples=file         TSV (chrom, sample, copy_idx) of copies to exclude\n"
-		"      --device=n                     HIP device to run on (default 0)\n"
+		"      --device=n[,m...]              HIP device(s) to run on (default 0); with several, the rows of an aligned\n"
+		"                                     A2M file are sharded over them (graph replicated, no collective)\n"
 		"      --verbose\n"
 		"  -F, --founder-sequences=count      Produce founder sequences instead of haplotypes\n"
 		"  -d, --minimum-distance=distance    Minimum node distance (MSA co-ordinates) between cut positions\n"
@@ -191,7 +194,13 @@ int main(int argc, char **argv)
 				else if (0 != std::strcmp(optarg, "warning")) { std::cerr << "ERROR: --ref-mismatch-handling must be warning or error.\n"; return EXIT_FAILURE; }
 				break;
 			case o_include: opt.include_samples = optarg; break;
-			case o_device: opt.device = std::atoi(optarg); break;
+			case o_device: {
+				opt.devices.clear();
+				std::istringstream ds(optarg);
+				for (std::string tok; std::getline(ds, tok, ',');) if (!tok.empty()) opt.devices.push_back(std::atoi(tok.c_str()));
+				if (opt.devices.empty()) { std::cerr << "ERROR: --device needs at least one device.\n"; return EXIT_FAILURE; }
+				break;
+			}
 			case o_verbose: opt.verbose = true; break;
 			case 'h': usage(); return EXIT_SUCCESS;
 			case o_unsupported: std::cerr << "ERROR: option " << argv[optind - 1] << " is not supported by this build.\n"; return EXIT_FAILURE;
@@ -211,7 +220,9 @@ int main(int argc, char **argv)
 	if (opt.include_samples && opt.exclude_samples) { std::cerr << "ERROR: --include-samples and --exclude-samples are mutually exclusive.\n"; return EXIT_FAILURE; }
 
 	try {
-		vh::gpu_context gpu(opt.device);   // fails here, loudly, without a usable MI355X
+		vh::gpu_context gpu(opt.devices.front());   // fails here, loudly, without a usable MI355X
+		std::vector<std::unique_ptr<vh::gpu_context>> more_gpus;
+		for (std::size_t k(1); k < opt.devices.size(); ++k) more_gpus.emplace_back(new vh::gpu_context(opt.devices[k]));
 
 		vh::sequence_type ref_seq;
 		std::cerr << "Reading the reference sequence..." << std::flush;
@@ -260,6 +271,7 @@ int main(int argc, char **argv)
 		}
 
 		vh::upload_graph(gpu, ref_seq, graph);
+		for (auto &g : more_gpus) vh::upload_graph(*g, ref_seq, graph);   // graph and reference replicated on every GPU
 		progress_delegate delegate;
 		delegate.verbose = opt.verbose;
 		auto const do_output([&](vh::output &output) {   // main.cc:456-473
@@ -277,9 +289,11 @@ int main(int argc, char **argv)
 
 		if (opt.haplotypes) {
 			vh::haplotype_output output(gpu, nullptr, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
+			for (auto &g : more_gpus) output.add_gpu(*g);
 			do_output(output);
 		} else {                                            // main.cc:487-550
 			vh::founder_sequence_greedy_output output(gpu, nullptr, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
+			for (auto &g : more_gpus) output.add_gpu(*g);
 			std::cerr << "Optimising cut positions...\n";
 			std::vector<vh::u64> cuts;
 			vh::u32 const score(vh::find_cut_positions(graph, vh::u64(opt.minimum_distance), cuts));

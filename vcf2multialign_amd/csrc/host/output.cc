@@ -1,7 +1,13 @@
 #include "output.hh"
 
+#include <fcntl.h>
+#include <sys/uio.h>
+#include <unistd.h>
+
+#include <exception>
 #include <fstream>
 #include <stdexcept>
+#include <thread>
 
 namespace v2m::host {
 
@@ -76,8 +82,89 @@ void output::write_separate(row_set const &rows)
 }
 
 
+namespace {
+	// One shard of an aligned A2M file: rows [first, first + n) of the batch, written at precomputed file offsets.
+	struct shard_state {
+		int fd;
+		std::vector<std::string> const *ids;
+		std::uint64_t const *offsets;      // file offset of each row of the whole batch
+		std::uint64_t first;               // batch index of the shard's row 0
+	};
+
+	int shard_sink(void *user, uint64_t row, char const *bytes, uint64_t length)
+	{
+		auto const &st(*static_cast<shard_state *>(user));
+		std::uint64_t const i(st.first + row);
+		std::string const header(">" + (*st.ids)[i] + "\n");
+		char newline('\n');
+		struct iovec iov[3] = {{const_cast<char *>(header.data()), header.size()}, {const_cast<char *>(bytes), length}, {&newline, 1}};
+		std::uint64_t off(st.offsets[i]);
+		int k(0);
+		while (k < 3) {   // pwritev may write less than asked
+			ssize_t const w(::pwritev(st.fd, iov + k, 3 - k, off_t(off)));
+			if (w <= 0) return 1;
+			off += std::uint64_t(w);
+			std::size_t left = std::size_t(w);
+			while (k < 3 && left >= iov[k].iov_len) { left -= iov[k].iov_len; ++k; }
+			if (k < 3) { iov[k].iov_base = static_cast<char *>(iov[k].iov_base) + left; iov[k].iov_len -= left; }
+		}
+		return 0;
+	}
+}
+
+
+void output::write_a2m_sharded(row_set const &rows, char const *dst_name)
+{
+	std::vector<gpu_context *> gpus{&m_gpu};
+	gpus.insert(gpus.end(), m_more_gpus.begin(), m_more_gpus.end());
+	std::uint64_t const n(rows.copy_index.size()), L(v2m_aligned_length(m_gpu.get()));
+	std::vector<std::uint64_t> offsets(n + 1, 0);
+	for (std::uint64_t i(0); i < n; ++i) offsets[i + 1] = offsets[i] + 1 + rows.ids[i].size() + 1 + L + 1;   // '>' id '\n' body '\n'
+
+	int const fd(::open(dst_name, O_WRONLY | O_CREAT | O_TRUNC, 0644));
+	if (fd < 0) throw std::runtime_error(std::string("unable to open ") + dst_name + " for writing");
+	struct closer { int fd; ~closer() { ::close(fd); } } const close_on_exit{fd};
+	if (0 != ::ftruncate(fd, off_t(offsets[n]))) { /* not all targets can be sized (e.g. /dev/null); pwrite extends regular files anyway */ }
+
+	std::size_t const g(gpus.size());
+	std::vector<std::exception_ptr> errors(g);
+	std::vector<std::thread> threads;
+	for (std::size_t k(0); k < g; ++k) {
+		std::uint64_t const first(n * k / g), last(n * (k + 1) / g);
+		threads.emplace_back([&, k, first, last] {
+			try {
+				if (first == last) return;
+				v2m_row_batch batch{};
+				batch.n_rows = last - first;
+				batch.copy_index = rows.copy_index.data() + first;
+				std::vector<std::uint64_t> cut_offsets;
+				if (rows.any_cuts) {   // re-base the CSR offsets of the shard
+					cut_offsets.assign(rows.cut_offsets.begin() + first, rows.cut_offsets.begin() + last + 1);
+					std::uint64_t const base(cut_offsets.front());
+					for (auto &o : cut_offsets) o -= base;
+					batch.cut_offsets = cut_offsets.data();
+					batch.cut_nodes = rows.cut_nodes.data() + base;
+					batch.cut_copies = rows.cut_copies.data() + base;
+				}
+				shard_state st{fd, &rows.ids, offsets.data(), first};
+				gpus[k]->check(v2m_splice_rows(gpus[k]->get(), &batch, 0u, shard_sink, &st));
+			} catch (...) {
+				errors[k] = std::current_exception();
+			}
+		});
+	}
+	for (auto &t : threads) t.join();
+	for (auto const &e : errors) if (e) std::rethrow_exception(e);
+	for (std::uint64_t i(0); i < n; ++i) m_delegate->handled_sequences(u32(1 + i));
+}
+
+
 void output::output_a2m(variant_graph const &graph, char const *dst_name)          // output.cc:47-76 without the pipe branch
 {
+	if (!m_more_gpus.empty() && !m_should_output_unaligned) {
+		write_a2m_sharded(a2m_rows(graph), dst_name);
+		return;
+	}
 	std::ofstream stream(dst_name, std::ios::binary | std::ios::trunc);
 	if (!stream) throw std::runtime_error(std::string("unable to open ") + dst_name + " for writing");
 	output_a2m(graph, stream);

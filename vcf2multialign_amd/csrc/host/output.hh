@@ -36,6 +36,13 @@ public:
 	// The graph must be the one uploaded to the context (upload_graph()).
 	virtual void output_separate(variant_graph const &graph, bool should_include_fasta_header) = 0;
 	void output_a2m(variant_graph const &graph, char const *dst_name);
+
+	// More GPUs for the same output (each must hold the same uploaded graph): the rows of an aligned A2M file are
+	// then sharded in contiguous blocks over all contexts, one host thread per context, and every thread writes its
+	// rows straight to their final place in the file (every aligned row has the same length, so offsets are known
+	// up front; there is no collective and no reordering buffer -- SURVEY.md section 8e).  Unaligned output and
+	// std::ostream targets use the first context only.
+	void add_gpu(gpu_context &gpu) { m_more_gpus.push_back(&gpu); }
 	virtual void output_a2m(variant_graph const &graph, std::ostream &stream) = 0;
 
 protected:
@@ -48,10 +55,13 @@ protected:
 	};
 	void splice(row_set const &rows, v2m_sink_fn sink, void *user);
 	void write_a2m(row_set const &rows, std::ostream &stream);
+	void write_a2m_sharded(row_set const &rows, char const *dst_name);
+	virtual row_set a2m_rows(variant_graph const &graph) = 0;
 	void write_separate(row_set const &rows);
 	std::string prefixed(std::string const &name, char sep) const;
 
 	gpu_context &m_gpu;
+	std::vector<gpu_context *> m_more_gpus;
 	char const *m_chromosome_id{};
 	output_delegate *m_delegate{};
 	bool m_should_output_reference{};
@@ -66,6 +76,7 @@ public:
 	void output_a2m(variant_graph const &graph, std::ostream &stream) override;
 private:
 	row_set rows_for(variant_graph const &graph, char sep, char const *suffix);
+	row_set a2m_rows(variant_graph const &graph) override { return rows_for(graph, '\t', ""); }
 };
 
 class founder_sequence_greedy_output final : public output {
@@ -80,6 +91,7 @@ public:
 	void output_a2m(variant_graph const &graph, std::ostream &stream) override;
 private:
 	row_set rows_for(char sep, char const *suffix);
+	row_set a2m_rows(variant_graph const &) override { return rows_for('\t', ""); }
 	std::vector<u64> m_cut_positions;
 	std::vector<u32> m_assigned_samples;
 	u32 m_founder_count{};
