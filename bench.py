@@ -87,14 +87,6 @@ def main():
 	import torch
 	import torch.distributed as dist
 
-	from vcf2multialign_amd import build as _build
-	if local_rank == 0:
-		_build.build_native()   # no-op when the in-tree libraries are newer than their sources (hipcc cross-compiles gfx950)
-	import vcf2multialign_amd as v2m
-	from vcf2multialign_amd import _native as N
-	from vcf2multialign_amd import synth
-	from vcf2multialign_amd.sharding import max_over_ranks, shard_copies
-
 	dev_index = local_rank if args.force_device is None else args.force_device
 	torch.cuda.set_device(dev_index)
 	dev = torch.device("cuda", dev_index)
@@ -105,6 +97,16 @@ def main():
 			dist.init_process_group("nccl", device_id=dev)
 		else:
 			dist.init_process_group(args.dist_backend)
+
+	from vcf2multialign_amd import build as _build
+	if local_rank == 0:
+		_build.build_native()   # no-op when the in-tree libraries are newer than their sources (hipcc cross-compiles gfx950)
+	if world > 1:
+		dist.barrier()          # nobody loads the libraries before the (possible) rebuild is over
+	import vcf2multialign_amd as v2m
+	from vcf2multialign_amd import _native as N
+	from vcf2multialign_amd import synth
+	from vcf2multialign_amd.sharding import max_over_ranks, shard_copies
 
 	# ---- workload: generated on every rank (deterministic), resident in HBM before timing ----------
 	t0 = time.time()

@@ -427,6 +427,363 @@ bool read_single_fasta_sequence(char const *path, std::string &seq, char const *
 }
 
 
+// ---------------------------------------------------------------------------
+// Founder search: pBWT over the ALT edges, cut positions, greedy matching.
+// Literal restatement -- every divergence-count update the reference makes is
+// made here too; the product's host version (csrc/host/founder.cc) takes
+// shortcuts and is tested against this one.
+// ---------------------------------------------------------------------------
+
+// pbwt.hh:32-49: divergence values order with DIVERGENCE_MAX first.
+struct divergence_value {
+	std::uint64_t value{};
+	divergence_value() = default;
+	divergence_value(std::uint64_t v) : value(v) {}
+	bool operator<(divergence_value const other) const { return 1 + value < 1 + other.value; }
+	operator std::uint64_t() const { return value; }
+};
+
+// pbwt.hh:22-145
+struct pbwt_context {
+	std::vector<std::uint32_t> permutation, prev_permutation;
+	std::vector<divergence_value> divergence, prev_divergence;
+	std::map<divergence_value, std::uint32_t> divergence_value_counts;
+
+	explicit pbwt_context(std::uint32_t count) : permutation(count), divergence(count, divergence_value(UINT64_MAX))   // :62-73
+	{
+		if (count) {
+			divergence[0] = 0;
+			divergence_value_counts[0] = 1;
+			if (1 < count) divergence_value_counts[UINT64_MAX] = count - 1;
+		}
+		for (std::uint32_t i(0); i < count; ++i) permutation[i] = i;
+	}
+
+	void swap_vectors()                                                       // :137-145
+	{
+		std::swap(permutation, prev_permutation);
+		std::swap(divergence, prev_divergence);
+		permutation.clear();
+		divergence.clear();
+	}
+
+	// :76-134; `column` is one column of paths_by_edge_and_chrom_copy
+	void update_divergence(bit_matrix const &m, std::uint64_t column, divergence_value const kk)
+	{
+		std::uint32_t zero_idx(0);
+		std::uint32_t one_idx(std::uint32_t(prev_permutation.size()));
+		for (std::uint64_t r(0); r < m.rows; ++r) one_idx -= m.get(r, column) ? 1 : 0;
+		permutation.resize(prev_permutation.size());
+		divergence.resize(prev_divergence.size());
+		divergence_value pp(kk + 1), qq(kk + 1);
+		for (std::size_t ii(0); ii < prev_permutation.size(); ++ii) {
+			auto const val_idx(prev_permutation[ii]);
+			auto const pd(prev_divergence[ii]);
+			if (pp < pd) pp = pd;
+			if (qq < pd) qq = pd;
+			{
+				auto const it(divergence_value_counts.find(pd));
+				--it->second;
+				if (0 == it->second) divergence_value_counts.erase(it);
+			}
+			if (!m.get(val_idx, column)) {
+				++divergence_value_counts[pp];
+				permutation[zero_idx] = val_idx;
+				divergence[zero_idx] = pp;
+				++zero_idx;
+				pp = 0;
+			} else {
+				++divergence_value_counts[qq];
+				permutation[one_idx] = val_idx;
+				divergence[one_idx] = qq;
+				++one_idx;
+				qq = 0;
+			}
+		}
+	}
+};
+
+constexpr std::uint32_t kCutPositionScoreMax = UINT32_MAX;   // find_cut_positions.hh (CUT_POSITION_SCORE_MAX)
+
+// find_cut_positions.cc:29-63
+struct cut_position {
+	std::uint64_t edge{};
+	std::uint64_t prev_edge{kEdgeMax};
+	std::uint64_t node{};
+	std::uint32_t score{};
+
+	void update_if_needed(std::uint32_t eq_class_count, cut_position const &prev_cut)
+	{
+		auto const candidate_score(std::max(eq_class_count, prev_cut.score));
+		if (candidate_score < score) {
+			score = candidate_score;
+			prev_edge = prev_cut.edge;
+		}
+	}
+};
+
+std::uint32_t total_chromosome_copies(graph const &g) { return g.ploidy_csum.empty() ? 0 : g.ploidy_csum.back(); }
+
+// find_cut_positions.cc:93-211
+std::uint32_t find_initial_cut_positions_lambda_min(graph const &g, std::uint64_t min_distance, std::vector<std::uint64_t> &out_cut_positions)
+{
+	out_cut_positions.clear();
+	auto const path_count(total_chromosome_copies(g));
+	std::uint64_t rightmost_seen_alt_edge_target(0), edge_idx(0), prev_cut_pos_id(kEdgeMax);
+	pbwt_context pbwt_ctx(path_count);
+	std::vector<cut_position> cut_positions;
+	cut_positions.push_back({0, kEdgeMax, 0, 0});
+	auto const by_edge([](cut_position const &lhs, std::uint64_t rhs) { return lhs.edge < rhs; });
+
+	for (std::uint64_t node(0); node < g.node_count(); ++node) {               // variant_graph_walker
+		if (rightmost_seen_alt_edge_target <= node && prev_cut_pos_id != edge_idx) {   // :126-129
+			cut_positions.push_back({edge_idx, kEdgeMax, node, path_count});
+			auto &current_cut(cut_positions.back());
+			prev_cut_pos_id = edge_idx;
+
+			auto const cut_pos_begin(cut_positions.begin());
+			auto cut_pos_rb(cut_positions.end());
+			auto const &dvc(pbwt_ctx.divergence_value_counts);
+			auto eq_class_count(dvc.rbegin()->second);                          // :137
+			// every entry but the last (largest), from the largest down (:115-121, :138)
+			auto last(dvc.end()); --last;
+			for (auto it(last); it != dvc.begin();) {
+				--it;
+				std::uint64_t const div_edge_idx(it->first);
+				auto const pos(std::lower_bound(cut_pos_begin, cut_pos_rb, div_edge_idx, by_edge));
+				if (pos != cut_pos_rb) {
+					cut_pos_rb = pos;
+					if (min_distance <= g.aligned_positions[node] - g.aligned_positions[pos->node])
+						current_cut.update_if_needed(eq_class_count, *pos);
+				}
+				eq_class_count += it->second;
+			}
+			if (cut_pos_begin != cut_pos_rb) {                                  // :160-164
+				--cut_pos_rb;
+				current_cut.update_if_needed(eq_class_count, *cut_pos_rb);
+			}
+		}
+
+		for (auto e(g.alt_edge_count_csum[node]); e < g.alt_edge_count_csum[node + 1]; ++e) {   // :169-176
+			pbwt_ctx.swap_vectors();
+			pbwt_ctx.update_divergence(g.paths_by_edge_and_chrom_copy, edge_idx, edge_idx);
+			++edge_idx;
+			rightmost_seen_alt_edge_target = std::max(rightmost_seen_alt_edge_target, g.alt_edge_targets[e]);
+		}
+	}
+
+	if (cut_positions.size() <= 1) return kCutPositionScoreMax;               // :182-183
+
+	auto it(cut_positions.cend() - 1);
+	auto const retval(it->score);
+	for (;;) {                                                                // :188-198
+		out_cut_positions.push_back(it->node);
+		auto const prev_edge(it->prev_edge);
+		if (kEdgeMax == prev_edge) break;
+		it = std::lower_bound(cut_positions.cbegin(), it, prev_edge, by_edge);
+	}
+	if (0 != out_cut_positions.back()) out_cut_positions.push_back(0);
+	std::reverse(out_cut_positions.begin(), out_cut_positions.end());
+	if (out_cut_positions.back() != g.node_count() - 1) out_cut_positions.back() = g.node_count() - 1;   // :205-207
+	return retval;
+}
+
+
+// founder_sequence_greedy_output.cc:47-69
+struct joined_path_eq_class {
+	std::uint32_t lhs_rep{}, rhs_rep{}, size{};
+	joined_path_eq_class(std::uint32_t l, std::uint32_t r) : lhs_rep(l), rhs_rep(r) {}
+	explicit joined_path_eq_class(std::uint32_t r) : lhs_rep(kPloidyMax), rhs_rep(r) {}
+	bool operator<(joined_path_eq_class const &other) const { return size < other.size; }
+};
+
+// founder_sequence_greedy_output.cc:154-512.  assigned_samples: (cuts - 1) rows x founder_count columns, column-major.
+bool find_matchings(
+	graph const &g, std::vector<std::uint64_t> const &cuts, std::uint32_t founder_count, bool should_keep_ref_edges,
+	std::vector<std::uint32_t> &assigned_samples)
+{
+	if (cuts.size() < 2) return false;                                        // :162-166
+	auto const copies(total_chromosome_copies(g));
+	if (0 == copies) return false;
+
+	std::size_t const n_rows(cuts.size() - 1);
+	assigned_samples.assign(n_rows * founder_count, kPloidyMax);               // :170-172
+	auto const assigned([&](std::size_t row, std::uint32_t col) -> std::uint32_t & { return assigned_samples[col * n_rows + row]; });
+
+	std::multimap<std::uint32_t, std::uint32_t> assignments_by_eq_class;
+	std::vector<char> reserved_assignments(copies, 0);
+	std::vector<std::uint32_t> arbitrarily_connected_rhs;
+	std::uint64_t edge_idx(0), prev_cut_edge_idx(0), cut_pair_edge_idx(0);
+	std::vector<std::uint32_t> lhs_eq_classes(copies, kPloidyMax), rhs_eq_classes(copies, kPloidyMax);
+	std::uint32_t lhs_distinct_eq_classes(0), rhs_distinct_eq_classes(0);
+	std::vector<joined_path_eq_class> joined_path_eq_classes;
+	bool lhs_first_path_is_ref(true), rhs_first_path_is_ref(true);
+	std::uint32_t lhs_first_path_eq_class(0), rhs_first_path_eq_class(0);
+	auto cut_pos_it(cuts.begin());
+	++cut_pos_it;
+	pbwt_context pbwt_ctx(copies);
+	std::uint64_t cut_pos_idx(0);
+
+	for (std::uint64_t node(0); node < g.node_count(); ++node) {
+		if (cut_pos_it != cuts.end() && node == *cut_pos_it) {                  // :208
+			std::swap(lhs_eq_classes, rhs_eq_classes);                          // :213-222
+			std::fill(rhs_eq_classes.begin(), rhs_eq_classes.end(), kPloidyMax);
+			lhs_distinct_eq_classes = rhs_distinct_eq_classes;
+			lhs_first_path_eq_class = rhs_first_path_eq_class;
+			rhs_distinct_eq_classes = 0;
+			rhs_first_path_eq_class = pbwt_ctx.permutation.front();
+
+			{
+				std::uint32_t rep(kPloidyMax);                                  // :229-252
+				joined_path_eq_classes.clear();
+				for (std::size_t i(0); i < pbwt_ctx.permutation.size(); ++i) {
+					auto const aa(pbwt_ctx.permutation[i]);
+					std::uint64_t const dd(pbwt_ctx.divergence[i]);             // compared as a plain integer (:233)
+					if (prev_cut_edge_idx < dd) { rep = aa; ++rhs_distinct_eq_classes; }
+					rhs_eq_classes[aa] = rep;
+					if (0 < cut_pos_idx) {
+						if (cut_pair_edge_idx < dd) joined_path_eq_classes.emplace_back(lhs_eq_classes[aa], rep);
+						++joined_path_eq_classes.back().size;
+					}
+				}
+			}
+
+			if (0 < cut_pos_idx) {
+				std::sort(joined_path_eq_classes.begin(), joined_path_eq_classes.end());   // :256
+				if (!should_keep_ref_edges && lhs_first_path_is_ref && rhs_first_path_is_ref)   // :259-264
+					std::erase_if(joined_path_eq_classes, [&](auto const &c) { return lhs_first_path_eq_class == c.lhs_rep && rhs_first_path_eq_class == c.rhs_rep; });
+
+				if (1 == cut_pos_idx) {                                         // :266-311
+					auto remaining_founders(founder_count);
+					auto remaining_reserved(std::min(remaining_founders, lhs_distinct_eq_classes));
+					remaining_founders -= remaining_reserved;
+					std::uint32_t founder_idx(0);
+					auto const do_assign([&](joined_path_eq_class const &c) {
+						assignments_by_eq_class.emplace(c.lhs_rep, founder_idx);
+						assigned(0, founder_idx) = c.lhs_rep;
+						++founder_idx;
+					});
+					for (auto c(joined_path_eq_classes.rbegin()); c != joined_path_eq_classes.rend(); ++c) {
+						if (reserved_assignments[c->lhs_rep]) {
+							if (remaining_founders) { --remaining_founders; do_assign(*c); }
+						} else if (remaining_reserved) {
+							--remaining_reserved;
+							reserved_assignments[c->lhs_rep] = 1;
+							do_assign(*c);
+						}
+					}
+					// the reference spins here when there is no class at all; the oracle stops instead
+					while (remaining_founders && !joined_path_eq_classes.empty())
+						for (auto c(joined_path_eq_classes.rbegin()); c != joined_path_eq_classes.rend() && remaining_founders; ++c) {
+							--remaining_founders;
+							do_assign(*c);
+						}
+				}
+
+				{                                                               // :321-437
+					std::fill(reserved_assignments.begin(), reserved_assignments.end(), 0);
+					arbitrarily_connected_rhs.clear();
+					auto remaining_founders(founder_count);
+					auto remaining_reserved(std::min(remaining_founders, rhs_distinct_eq_classes));
+					remaining_founders -= remaining_reserved;
+
+					auto const try_assign([&](joined_path_eq_class const &c) -> bool {
+						auto const it(assignments_by_eq_class.find(c.lhs_rep));
+						if (assignments_by_eq_class.end() == it) return false;
+						auto const founder_idx(it->second);
+						assignments_by_eq_class.erase(it);
+						assigned(cut_pos_idx, founder_idx) = c.rhs_rep;
+						return true;
+					});
+					auto const assign_arbitrary([&](std::uint32_t rhs_rep) {
+						if (assignments_by_eq_class.empty()) return;            // asserted non-empty at :355
+						auto const it(assignments_by_eq_class.begin());
+						auto const founder_idx(it->second);
+						assignments_by_eq_class.erase(it);
+						assigned(cut_pos_idx, founder_idx) = rhs_rep;
+					});
+
+					bool is_first(true), leave(false);                          // steps 1-3 (:363-413)
+					while (!leave) {
+						bool did_assign(false);
+						for (auto c(joined_path_eq_classes.rbegin()); c != joined_path_eq_classes.rend(); ++c) {
+							if (reserved_assignments[c->rhs_rep]) {
+								if (remaining_founders) {
+									if (try_assign(*c)) { did_assign = true; --remaining_founders; }
+								} else if (!is_first) {
+									leave = true;                               // goto continue_subsequent_assignment
+									break;
+								}
+							} else if (remaining_reserved) {
+								--remaining_reserved;
+								if (try_assign(*c)) reserved_assignments[c->rhs_rep] = 1;
+								else arbitrarily_connected_rhs.push_back(c->rhs_rep);
+							}
+						}
+						if (leave) break;
+						if (!remaining_founders) break;
+						if (is_first) { is_first = false; continue; }
+						if (!did_assign) break;
+					}
+
+					for (auto const rhs_rep : arbitrarily_connected_rhs) {       // step 4 (:417-426)
+						if (!reserved_assignments[rhs_rep]) {
+							assign_arbitrary(rhs_rep);
+							reserved_assignments[rhs_rep] = 1;
+						}
+					}
+
+					while (!assignments_by_eq_class.empty() && !joined_path_eq_classes.empty())   // step 5 (:429-438)
+						for (auto c(joined_path_eq_classes.rbegin()); c != joined_path_eq_classes.rend() && !assignments_by_eq_class.empty(); ++c)
+							assign_arbitrary(c->rhs_rep);
+
+					assignments_by_eq_class.clear();                            // :441-447
+					for (std::uint32_t idx(0); idx < founder_count; ++idx)
+						assignments_by_eq_class.insert({assigned(cut_pos_idx, idx), idx});
+				}
+			}
+
+			++cut_pos_idx;                                                      // :451-457
+			++cut_pos_it;
+			cut_pair_edge_idx = prev_cut_edge_idx;
+			prev_cut_edge_idx = edge_idx;
+			lhs_first_path_is_ref = rhs_first_path_is_ref;
+			rhs_first_path_is_ref = true;
+		}
+
+		for (auto e(g.alt_edge_count_csum[node]); e < g.alt_edge_count_csum[node + 1]; ++e) {   // :461-469
+			pbwt_ctx.swap_vectors();
+			pbwt_ctx.update_divergence(g.paths_by_edge_and_chrom_copy, edge_idx, edge_idx);
+			rhs_first_path_is_ref = rhs_first_path_is_ref && !g.paths_by_edge_and_chrom_copy.get(pbwt_ctx.permutation.front(), edge_idx);
+			++edge_idx;
+		}
+	}
+
+	if (1 == cut_pos_idx) {                                                   // :475-508
+		std::uint32_t rep(kPloidyMax);
+		joined_path_eq_classes.clear();
+		for (std::size_t i(0); i < pbwt_ctx.permutation.size(); ++i) {
+			auto const aa(pbwt_ctx.permutation[i]);
+			std::uint64_t const dd(pbwt_ctx.divergence[i]);
+			if (0 < dd) {
+				rep = aa;
+				++rhs_distinct_eq_classes;
+				joined_path_eq_classes.emplace_back(rep);
+			}
+			rhs_eq_classes[aa] = rep;
+			++joined_path_eq_classes.back().size;
+		}
+		std::sort(joined_path_eq_classes.begin(), joined_path_eq_classes.end());
+		if (!should_keep_ref_edges && rhs_first_path_is_ref)
+			std::erase_if(joined_path_eq_classes, [&](auto const &c) { return rhs_first_path_eq_class == c.rhs_rep; });
+		std::uint32_t founder_idx(0);
+		for (auto c(joined_path_eq_classes.rbegin()); c != joined_path_eq_classes.rend() && founder_idx < founder_count; ++c, ++founder_idx)
+			assigned(0, founder_idx) = c->rhs_rep;
+	}
+	return true;
+}
+
+
 std::vector<std::string_view> split(std::string_view s, char delim)
 {
 	std::vector<std::string_view> out;
@@ -899,6 +1256,29 @@ std::int64_t v2mo_founder_output_a2m(
 	auto const s(std::move(os).str());
 	if (s.size() <= out_cap) std::memcpy(out, s.data(), s.size());
 	return std::int64_t(s.size());
+}
+
+// find_cut_positions + find_matchings (founder_sequence_greedy_output.cc:139-152, 154-512).  cuts_out: node_count
+// entries; assigned_out: (cuts - 1) * founder_count entries, column-major.  Returns the number of cut positions,
+// 0 when there is no solution.  A graph made by v2mo_graph_from_arrays gets its copies-by-edge matrix here.
+std::uint64_t v2mo_find_founders(
+	v2mo_graph *h, std::uint64_t min_distance, std::uint32_t founder_count, int keep_ref_edges,
+	std::uint64_t *cuts_out, std::uint32_t *assigned_out, std::uint64_t assigned_capacity, std::uint32_t *score_out
+)
+{
+	auto &g(G(h));
+	if (g.paths_by_edge_and_chrom_copy.words.empty() && !g.paths_by_chrom_copy_and_edge.words.empty())
+		g.paths_by_edge_and_chrom_copy = transpose_matrix(g.paths_by_chrom_copy_and_edge);
+	std::vector<std::uint64_t> cuts;
+	auto const score(find_initial_cut_positions_lambda_min(g, min_distance, cuts));
+	if (score_out) *score_out = score;
+	if (kCutPositionScoreMax == score) return 0;
+	std::vector<std::uint32_t> assigned;
+	if (!find_matchings(g, cuts, founder_count, 0 != keep_ref_edges, assigned)) return 0;
+	if (assigned.size() > assigned_capacity) return 0;
+	std::copy(cuts.begin(), cuts.end(), cuts_out);
+	std::copy(assigned.begin(), assigned.end(), assigned_out);
+	return cuts.size();
 }
 
 } // extern "C"

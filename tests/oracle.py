@@ -71,6 +71,8 @@ def lib():
 	L.v2mo_haplotype_output_a2m.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_double)]
 	L.v2mo_founder_output_a2m.restype = C.c_int64
 	L.v2mo_founder_output_a2m.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+	L.v2mo_find_founders.restype = C.c_uint64
+	L.v2mo_find_founders.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, _u32p]
 	_lib = L
 	return L
 
@@ -189,6 +191,19 @@ class OracleGraph:
 			cuts.ctypes.data, len(cuts), asg.ctypes.data, n_founders, buf, cap)
 		assert 0 <= n <= cap
 		return buf.raw[:n]
+
+	# -- find_cut_positions + find_matchings (find_cut_positions.cc:93-211, founder_sequence_greedy_output.cc:154-512) ---
+	def find_founders(self, founder_count, min_distance=0, keep_ref_edges=False):
+		"""Literal restatement (every pBWT divergence-count update made).  Returns (cut_positions,
+		assigned_samples column-major, score) or None when there is no solution."""
+		n = self.node_count
+		cuts = np.zeros(max(1, n), dtype=np.uint64)
+		assigned = np.zeros(max(1, n * founder_count), dtype=np.uint32)
+		score = C.c_uint32()
+		k = lib().v2mo_find_founders(self._h, min_distance, founder_count, int(keep_ref_edges), cuts.ctypes.data, assigned.ctypes.data, assigned.size, C.byref(score))
+		if k == 0:
+			return None
+		return cuts[:k].tolist(), assigned[:(k - 1) * founder_count].tolist(), score.value
 
 
 def build_variant_graph(fasta_path, vcf_path, chr_id, seq_id=None, exclude_sample=None, exclude_copy=-1):

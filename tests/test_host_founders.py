@@ -43,3 +43,30 @@ def test_minimum_distance_and_founder_count_are_honoured(HostGraph, fixtures_dir
 	for k in (1, 2, 5, 14):
 		cuts, assigned, _ = h.find_founders(k, 0)
 		assert cuts == cuts0 and len(assigned) == (len(cuts) - 1) * k
+
+
+# The host's pBWT skips work the reference does literally (divergence counts touched only on a change, 32-bit biased
+# divergence values, a flat count table); the oracle's restatement makes every update.  Same answers on random inputs.
+@pytest.mark.parametrize("seed,ref_len,n_variants,n_samples,kw", [
+	(1, 3000, 120, 6, dict()),
+	(2, 5000, 400, 9, dict(multi_allelic=0.3)),
+	(3, 20000, 900, 40, dict(mix=(0.6, 0.2, 0.2))),
+	(4, 8000, 300, 3, dict(density=0.5)),
+	(5, 8000, 300, 70, dict(density=0.02)),
+	(6, 60000, 500, 12, dict(long_every=50)),
+	(7, 2000, 60, 1, dict(ploidy=1)),
+	(8, 30000, 2500, 33, dict(multi_allelic=0.1, mix=(0.7, 0.15, 0.15))),
+], ids=lambda v: str(v) if isinstance(v, int) else None)
+def test_random_inputs_against_the_literal_restatement(HostGraph, tmp_path, seed, ref_len, n_variants, n_samples, kw):
+	import numpy as np
+	import oracle
+	import synth
+	rng = np.random.default_rng(1000 + seed)
+	ref = synth.random_reference(rng, ref_len)
+	recs = synth.random_records(rng, ref, n_variants, n_samples, **kw)
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, n_samples)
+	og = oracle.build_variant_graph(fa, vcf, "1")
+	hg = HostGraph(fa, vcf, "1")
+	assert og.edge_count > 0
+	for founders, min_distance, keep in ((1, 0, False), (2, 0, False), (3, 10, True), (7, 50, False), (25, 50, False), (4, 1000, True), (5, 10 * ref_len, False)):
+		assert hg.find_founders(founders, min_distance, keep_ref_edges=keep) == og.find_founders(founders, min_distance, keep_ref_edges=keep), (founders, min_distance, keep)

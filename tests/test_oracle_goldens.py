@@ -64,6 +64,17 @@ def test_founder_a2m(case, fixtures_dir):
 		assert g.output_sequence(g.ref, cuts=cuts).decode() == expected_rows[3 + 2 * f]
 
 
+# REQUIRE(expected_cut_positions == output.cut_positions()), REQUIRE(expected_matchings == output.assigned_samples())
+# (tests/founder_sequences.cc:126-128): the oracle's literal pBWT / cut search / greedy matching
+@pytest.mark.parametrize("case", _load("founder_sequences"), ids=_case_id)
+def test_founder_search(case, fixtures_dir):
+	d = os.path.join(fixtures_dir, "founder-sequences")
+	g = oracle.build_variant_graph(os.path.join(d, case["fasta"]), os.path.join(d, case["vcf"]), case["chromosome"])
+	cuts, assigned, _ = g.find_founders(case["founder_count"], case["minimum_distance"], keep_ref_edges=False)
+	assert cuts == case["cut_positions"]
+	assert assigned == case["assigned_samples_column_major"]
+
+
 # --- tests/transpose_matrix.cc:188-251 ------------------------------------------------------
 def _set_bit(words, nrows, r, c):
 	idx = c * nrows + r

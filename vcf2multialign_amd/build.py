@@ -5,6 +5,8 @@
 hipcc cross-compiles for gfx950 without a GPU present.
 """
 
+import contextlib
+import fcntl
 import os
 import shutil
 import subprocess
@@ -48,21 +50,41 @@ CLI_SOURCES = [os.path.join(HOST_DIR, "main.cc")]
 CXX_FLAGS = ["-O2", "-g", "-std=c++20", "-Wall", "-Wextra"]
 
 
+def _link(cmd_prefix, target, cmd_suffix, verbose):
+	"""Runs a compile-and-link command into a temporary name and renames it over the target, so that a process that
+	loads the library while another one rebuilds it never sees a half-written file."""
+	tmp = "%s.tmp%d" % (target, os.getpid())
+	cmd = cmd_prefix + ["-o", tmp] + cmd_suffix
+	if verbose:
+		print(" ".join(cmd))
+	try:
+		subprocess.check_call(cmd, cwd=ROOT)
+		os.replace(tmp, target)
+	finally:
+		with contextlib.suppress(OSError):
+			os.unlink(tmp)
+
+
+@contextlib.contextmanager
+def _build_lock():
+	"""One builder at a time per checkout (several ranks or pytest workers may start together)."""
+	with open(os.path.join(PKG_DIR, ".build.lock"), "w") as f:
+		fcntl.flock(f, fcntl.LOCK_EX)
+		try:
+			yield
+		finally:
+			fcntl.flock(f, fcntl.LOCK_UN)
+
+
 def _build_host(force, verbose):
 	cxx = os.environ.get("CXX") or shutil.which("g++")
 	if cxx is None:
 		raise RuntimeError("g++ not found")
 	if force or _stale(HOST_LIB_PATH, HOST_DEPS + [LIB_PATH]):
-		cmd = [cxx] + CXX_FLAGS + ["-fPIC", "-shared", "-o", HOST_LIB_PATH] + HOST_SOURCES + ["-L" + PKG_DIR, "-lv2m_hip", "-Wl,-rpath,$ORIGIN"]
-		if verbose:
-			print(" ".join(cmd))
-		subprocess.check_call(cmd, cwd=ROOT)
+		_link([cxx] + CXX_FLAGS + ["-fPIC", "-shared"], HOST_LIB_PATH, HOST_SOURCES + ["-L" + PKG_DIR, "-lv2m_hip", "-Wl,-rpath,$ORIGIN"], verbose)
 	if force or _stale(CLI_PATH, CLI_SOURCES + HOST_DEPS + [HOST_LIB_PATH]):
 		os.makedirs(os.path.dirname(CLI_PATH), exist_ok=True)
-		cmd = [cxx] + CXX_FLAGS + ["-o", CLI_PATH] + CLI_SOURCES + ["-L" + PKG_DIR, "-lv2m_host", "-lv2m_hip", "-Wl,-rpath,$ORIGIN/.."]
-		if verbose:
-			print(" ".join(cmd))
-		subprocess.check_call(cmd, cwd=ROOT)
+		_link([cxx] + CXX_FLAGS, CLI_PATH, CLI_SOURCES + ["-L" + PKG_DIR, "-lv2m_host", "-lv2m_hip", "-Wl,-rpath,$ORIGIN/.."], verbose)
 
 
 def _build(target, sources, deps, force, verbose):
@@ -71,16 +93,14 @@ def _build(target, sources, deps, force, verbose):
 	hipcc = find_hipcc()
 	if hipcc is None:
 		raise RuntimeError("hipcc not found: cannot build " + target)
-	cmd = [hipcc] + HIPCC_FLAGS + ["-o", target] + sources
-	if verbose:
-		print(" ".join(cmd))
-	subprocess.check_call(cmd, cwd=ROOT)
+	_link([hipcc] + HIPCC_FLAGS, target, sources, verbose)
 	return target
 
 
 def build_native(force=False, verbose=False):
 	"""Compiles libv2m_hip.so (and the synthetic-input helper) for gfx950 if missing or older than the sources."""
-	_build(SYNTH_LIB_PATH, SYNTH_SOURCES, SYNTH_DEPS, force, verbose)
-	_build(LIB_PATH, HIP_SOURCES, HIP_DEPS, force, verbose)
-	_build_host(force, verbose)
+	with _build_lock():
+		_build(SYNTH_LIB_PATH, SYNTH_SOURCES, SYNTH_DEPS, force, verbose)
+		_build(LIB_PATH, HIP_SOURCES, HIP_DEPS, force, verbose)
+		_build_host(force, verbose)
 	return LIB_PATH
