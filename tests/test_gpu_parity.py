@@ -242,6 +242,47 @@ def test_founder_rows_synthetic(v2m, ctx, tmp_path):
 		assert a == b, "unaligned row %d differs" % i
 
 
+@pytest.mark.parametrize("max_back", [None, "0"])
+def test_founder_rows_many_segments(v2m, ctx, tmp_path, monkeypatch, max_back):
+	"""Rows that switch copy at (nearly) every bridge node: dozens of segments per 64-edge word, put together by
+	assemble_row_bits_kernel over several waves and workgroups; next to rows with a handful of long segments and plain rows."""
+	if max_back is not None:
+		monkeypatch.setenv("V2M_MAX_BACK_WORDS", max_back)          # every cross-word restart goes through the serial kernel
+	g = synth.with_random_paths(synth.build_case(tmp_path, 77, 1_500_000, 30000, 12, multi_allelic=0.1), 5, 0.3)
+	_upload(v2m, ctx, g)
+	assert g.edge_count > 64 * 64 * 4 + 100                          # more than one workgroup of four 64-word waves
+	reach, bridges = 0, []
+	for n in range(g.node_count - 1):
+		if n >= reach and n > 0:
+			bridges.append(n)
+		for e in range(int(g.alt_edge_count_csum[n]), int(g.alt_edge_count_csum[n + 1])):
+			reach = max(reach, int(g.alt_edge_targets[e]))
+	rng = np.random.default_rng(9)
+	H = g.total_chromosome_copies
+
+	def row(cut_nodes):
+		copies = rng.integers(0, H, size=len(cut_nodes)).tolist()
+		for k in rng.choice(len(cut_nodes), size=max(1, len(cut_nodes) // 50), replace=False):
+			copies[int(k)] = v2m.PLOIDY_MAX                            # unassigned slots
+		return list(zip(cut_nodes, copies))
+
+	rows = [
+		row([0] + bridges),                                            # every bridge node
+		row(bridges[1::2]),                                            # first cut not at node 0
+		3,
+		row([0] + sorted(int(x) for x in rng.choice(bridges, size=len(bridges) // 3, replace=False))),
+		row([0, bridges[len(bridges) // 2]]),                          # two segments, thousands of words each
+		v2m.PLOIDY_MAX,
+		row([0] + sorted(int(x) for x in rng.choice(bridges, size=7, replace=False))),
+		row([0] + bridges[:200]),                                      # dense at the start, one long tail
+	]
+	exp = _oracle_rows(g, rows)
+	got = ctx.splice_rows(rows)
+	for i, (a, b) in enumerate(zip(got, exp)):
+		assert a == b, "row %d differs" % i
+	assert ctx.splice_rows(rows[:2], unaligned=True) == _oracle_rows(g, rows[:2], unaligned=True)
+
+
 def test_device_rows_checksums(v2m, ctx, tmp_path):
 	"""Device-resident output + on-device checksums == host checksums of the oracle rows; and the
 	sink path cut into several ring slices gives the same bytes."""

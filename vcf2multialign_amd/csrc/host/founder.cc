@@ -3,34 +3,118 @@
 #include <algorithm>
 #include <map>
 #include <numeric>
+#include <stdexcept>
 
 namespace v2m::host {
 
 namespace {
 
-constexpr u64 kDivergenceMax = UINT64_MAX;
+// Divergence values are kept BIASED by one in 32 bits: b = d + 1, so that "no match yet" (the reference's
+// DIVERGENCE_MAX) is 0 and the order the reference defines -- DIVERGENCE_MAX first (pbwt.hh:25-42) -- is the plain
+// integer order.  Edge indices stay below 2^32 - 3 (checked by the callers); the device side narrows them the same way.
+constexpr u32 kNoValue = UINT32_MAX;
 
-// Divergence values order with "no match yet" (kDivergenceMax) FIRST (pbwt.hh:25-42).
-struct divergence_less {
-	bool operator()(u64 a, u64 b) const { return a + 1 < b + 1; }
+inline u64 unbiased(u32 b) { return b ? u64(b) - 1 : UINT64_MAX; }
+
+// How often each divergence value occurs (the reference's std::map, pbwt.hh:46): a flat table over the biased values
+// plus a bitset hierarchy of the non-zero entries, so that a change costs a few word operations and the values can be
+// listed from the largest down.
+class divergence_counts {
+public:
+	explicit divergence_counts(u64 n_values) : m_count(n_values, 0)
+	{
+		for (u64 n(n_values);;) {
+			n = (n + 63) / 64;
+			m_level.emplace_back(n, 0);
+			if (n <= 1) break;
+		}
+	}
+
+	u32 operator[](u32 v) const { return m_count[v]; }
+
+	void add(u32 v, u32 n)
+	{
+		if (0 == m_count[v]) mark(v);
+		m_count[v] += n;
+	}
+
+	void move(u32 from, u32 to)                             // one copy's value changes
+	{
+		if (0 == --m_count[from]) unmark(from);
+		if (0 == m_count[to]++) mark(to);
+	}
+
+	// largest value present below `bound` (exclusive), kNoValue if there is none
+	u32 below(u64 bound) const
+	{
+		u64 pos(bound);
+		std::size_t k(0);
+		for (;;) {
+			u64 const w(pos >> 6), b(pos & 63);
+			u64 const m((b && w < m_level[k].size()) ? m_level[k][w] & ((u64(1) << b) - 1) : 0);
+			if (m) { pos = (w << 6) + 63 - u64(__builtin_clzll(m)); break; }
+			pos = w;                                            // nothing in this word: look for an earlier word one level up
+			if (++k == m_level.size()) return kNoValue;
+		}
+		while (k) { --k; pos = (pos << 6) + 63 - u64(__builtin_clzll(m_level[k][pos])); }
+		return u32(pos);
+	}
+
+	u32 largest() const { return below(m_count.size()); }
+
+private:
+	void mark(u64 v)
+	{
+		for (auto &level : m_level) {
+			u64 &w(level[v >> 6]);
+			bool const was_empty(0 == w);
+			w |= u64(1) << (v & 63);
+			if (!was_empty) break;
+			v >>= 6;
+		}
+	}
+
+	void unmark(u64 v)
+	{
+		for (auto &level : m_level) {
+			u64 &w(level[v >> 6]);
+			w &= ~(u64(1) << (v & 63));
+			if (w) break;
+			v >>= 6;
+		}
+	}
+
+	std::vector<u32> m_count;
+	std::vector<std::vector<u64>> m_level;                      // [0]: bit per value; [k + 1]: bit per word of [k]
 };
 
+// byte i of kSpread[x] = bit i of x
+struct spread_table {
+	u64 v[256];
+	spread_table() { for (u32 x(0); x < 256; ++x) { v[x] = 0; for (u32 i(0); i < 8; ++i) v[x] |= u64((x >> i) & 1) << (8 * i); } }
+};
+spread_table const kSpread;
+
 // Positional BWT over the ALT edges, one binary column per edge (pbwt.hh:21-145): the copies sorted by their
-// reversed edge-usage prefixes, the divergence array, and how often each divergence value occurs.
+// reversed edge-usage prefixes and the divergence array.  `counts`, when given, follows the divergence values
+// (find_cut_positions needs them, find_matchings does not).
 class edge_pbwt {
 public:
 	std::vector<u32> order;        // "permutation": copies in prefix order
-	std::vector<u64> divergence;
-	std::map<u64, u32, divergence_less> value_counts;
+	std::vector<u32> divergence;   // biased
 
-	explicit edge_pbwt(u32 copies) : order(copies), divergence(copies, kDivergenceMax)
+	edge_pbwt(u32 copies, divergence_counts *counts) : order(copies), divergence(copies, 0), m_counts(counts)
 	{
 		std::iota(order.begin(), order.end(), 0u);
 		if (copies) {                                       // pbwt.hh:62-70
-			divergence[0] = 0;
-			value_counts[0] = 1;
-			if (copies > 1) value_counts[kDivergenceMax] = copies - 1;
+			divergence[0] = 1;
+			if (m_counts) {
+				m_counts->add(1, 1);
+				if (copies > 1) m_counts->add(0, copies - 1);
+			}
 		}
+		m_prev_order.resize(copies);
+		m_prev_divergence.resize(copies);
 	}
 
 	// One step of Durbin's algorithm 2 for edge `edge` whose usage bits are `column` (pbwt.hh:77-134).
@@ -39,43 +123,67 @@ public:
 		m_prev_order.swap(order);                           // swap_vectors(), pbwt.hh:137-145
 		m_prev_divergence.swap(divergence);
 		u32 const n(u32(m_prev_order.size()));
-		order.resize(n);
-		divergence.resize(n);
 
+		// usage bits as one byte per copy: the loop below looks them up in prefix order
+		m_flag.resize(column_words * 64);
 		u32 ones(0);
-		for (u64 w(0); w < column_words; ++w) ones += u32(__builtin_popcountll(column[w]));
+		for (u64 w(0); w < column_words; ++w) {
+			u64 const x(column[w]);
+			ones += u32(__builtin_popcountll(x));
+			u64 *const dst(reinterpret_cast<u64 *>(m_flag.data()) + 8 * w);
+			for (u32 k(0); k < 8; ++k) dst[k] = kSpread.v[(x >> (8 * k)) & 255];
+		}
+
+		if (m_counts) step<true>(n, ones, edge);
+		else step<false>(n, ones, edge);
+	}
+
+private:
+	// The copies that follow the edge are few for most edges, so the two cases are ordinary (well predicted) branches.
+	template <bool kCounts>
+	void step(u32 const n, u32 const ones, u64 const edge)
+	{
+		u32 const *const __restrict prev_order(m_prev_order.data());
+		u32 const *const __restrict prev_div(m_prev_divergence.data());
+		unsigned char const *const __restrict flag(m_flag.data());
+		u32 *const __restrict out_order(order.data());
+		u32 *const __restrict out_div(divergence.data());
 		u32 zero_at(0), one_at(n - ones);
-		divergence_less const less;
-		u64 p(edge + 1), q(edge + 1);
+		u32 p(u32(edge) + 2), q(p);                         // biased edge + 1
 		for (u32 i(0); i < n; ++i) {
-			u32 const copy(m_prev_order[i]);
-			u64 const d(m_prev_divergence[i]);
-			if (less(p, d)) p = d;
-			if (less(q, d)) q = d;
-			bool const uses_edge((column[copy >> 6] >> (copy & 63)) & 1);
-			u64 const nd(uses_edge ? q : p);
+			u32 const copy(prev_order[i]);
+			u32 const d(prev_div[i]);
+			p = std::max(p, d);
+			q = std::max(q, d);
 			// The reference decrements the old value's count and increments the new one's for every copy
 			// (pbwt.hh:110-131); when the value does not change -- the common case, a copy whose predecessor in
-			// the order used the same allele -- the two cancel, so the map is only touched on a change.
-			if (nd != d) {
-				auto const it(value_counts.find(d));
-				if (0 == --it->second) value_counts.erase(it);
-				++value_counts[nd];
-			}
-			if (!uses_edge) {
-				order[zero_at] = copy; divergence[zero_at] = p; ++zero_at;
-				p = 0;
+			// the order used the same allele -- the two cancel, so the table is only touched on a change.
+			if (!flag[copy]) {
+				if (kCounts && p != d) m_counts->move(d, p);
+				out_order[zero_at] = copy;
+				out_div[zero_at] = p;
+				++zero_at;
+				p = 1;                                          // biased 0
 			} else {
-				order[one_at] = copy; divergence[one_at] = q; ++one_at;
-				q = 0;
+				if (kCounts && q != d) m_counts->move(d, q);
+				out_order[one_at] = copy;
+				out_div[one_at] = q;
+				++one_at;
+				q = 1;
 			}
 		}
 	}
 
-private:
-	std::vector<u32> m_prev_order;
-	std::vector<u64> m_prev_divergence;
+	divergence_counts *m_counts;
+	std::vector<u32> m_prev_order, m_prev_divergence;
+	std::vector<unsigned char> m_flag;
 };
+
+void check_edge_range(variant_graph const &graph)
+{
+	if (graph.edge_count() >= u64(UINT32_MAX) - 3)
+		throw std::length_error("founder search: edge indices are kept in 32 bits");
+}
 
 struct cut_candidate {
 	u64 edge;        // first edge of the node
@@ -104,7 +212,9 @@ u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector
 	out.clear();
 	u32 const copies(graph.total_chromosome_copies());
 	u64 const words_per_column(graph.paths_by_edge_and_chrom_copy.words_per_column());
-	edge_pbwt pbwt(copies);
+	check_edge_range(graph);
+	divergence_counts counts(graph.edge_count() + 2);                          // biased values 0 .. edge_count + 1
+	edge_pbwt pbwt(copies, &counts);
 
 	std::vector<cut_candidate> cuts;
 	cuts.push_back({0, kEdgeMax, 0, 0});                                      // :111-112
@@ -121,17 +231,17 @@ u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector
 			// Divergence values from the largest down: the number of path classes of the segment that starts at the
 			// corresponding edge grows as we go left, so every earlier candidate needs to be looked at once (:134-165).
 			auto right_bound(cuts.end());
-			auto const &vc(pbwt.value_counts);
-			u32 class_count(vc.empty() ? 0 : vc.rbegin()->second);
-			if (!vc.empty()) {
-				for (auto it(std::next(vc.rbegin())); it != vc.rend(); ++it) {   // all values but the largest, descending
-					auto const pred(std::lower_bound(cuts.begin(), right_bound, it->first, by_edge));
+			u32 value(counts.largest());
+			u32 class_count(kNoValue == value ? 0 : counts[value]);
+			if (kNoValue != value) {
+				for (value = counts.below(value); kNoValue != value; value = counts.below(value)) {   // all values but the largest, descending
+					auto const pred(std::lower_bound(cuts.begin(), right_bound, unbiased(value), by_edge));
 					if (pred != right_bound) {
 						right_bound = pred;
 						if (min_distance <= graph.aligned_positions[node] - graph.aligned_positions[pred->node])
 							current.improve(class_count, *pred);
 					}
-					class_count += it->second;
+					class_count += counts[value];
 				}
 			}
 			if (cuts.begin() != right_bound) {                                // the segment may reach further left still
@@ -287,7 +397,8 @@ bool find_matchings(
 
 	auto const &paths(graph.paths_by_edge_and_chrom_copy);
 	u64 const words_per_column(paths.words_per_column());
-	edge_pbwt pbwt(copies);
+	check_edge_range(graph);
+	edge_pbwt pbwt(copies, nullptr);
 	std::vector<u32> lhs_class(copies, kPloidyMax), rhs_class(copies, kPloidyMax);
 	std::vector<joined_class> joined;
 	u32 lhs_distinct(0), rhs_distinct(0), lhs_first_class(0), rhs_first_class(0);
@@ -308,8 +419,8 @@ bool find_matchings(
 			joined.clear();
 			for (u32 i(0); i < copies; ++i) {
 				u32 const copy(pbwt.order[i]);
-				u64 const d(pbwt.divergence[i]);
-				if (prev_cut_edge < d) { rep = copy; ++rhs_distinct; }        // plain integer comparison: kDivergenceMax starts a class
+				u64 const d(unbiased(pbwt.divergence[i]));
+				if (prev_cut_edge < d) { rep = copy; ++rhs_distinct; }        // plain integer comparison: "no match yet" starts a class
 				rhs_class[copy] = rep;
 				if (cuts_seen) {
 					if (cut_pair_edge < d) joined.push_back({lhs_class[copy], rep, 0});
@@ -344,7 +455,7 @@ bool find_matchings(
 		u32 rep(kPloidyMax);
 		joined.clear();
 		for (u32 i(0); i < copies; ++i) {
-			if (0 < pbwt.divergence[i]) { rep = pbwt.order[i]; ++rhs_distinct; joined.push_back({kPloidyMax, rep, 0}); }
+			if (0 < unbiased(pbwt.divergence[i])) { rep = pbwt.order[i]; ++rhs_distinct; joined.push_back({kPloidyMax, rep, 0}); }
 			rhs_class[pbwt.order[i]] = rep;
 			++joined.back().size;
 		}

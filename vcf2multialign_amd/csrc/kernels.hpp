@@ -309,36 +309,67 @@ struct row_segments {
 	u32 const *seg_offsets;     // [n_rows + 1]
 	u32 const *seg_edge_begin;  // [total segments]
 	u32 const *seg_copy;        // [total segments]  (0xFFFFFFFF = follow REF)
+	// bit columns of the rows that have more than one segment, put together by assemble_row_bits_kernel
+	u64 const *assembled;       // [n_rows x assembled_words]; not read for single-segment rows
+	u32 assembled_words;
 };
 
 __device__ __forceinline__ u64 load_row_word(
-	u64 const *__restrict__ paths, u64 words_per_copy, row_segments const &rs, u32 s_begin, u32 s_end, u32 wi)
+	u64 const *__restrict__ paths, u64 words_per_copy, row_segments const &rs, u32 row, u32 s_begin, u32 s_end, u32 wi)
 {
-	u32 const e0 = wi * 64u;
 	if (s_end - s_begin == 1) {
 		u32 const copy = rs.seg_copy[s_begin];
 		return (copy == 0xFFFFFFFFu) ? 0 : paths[(u64) copy * words_per_copy + wi];
 	}
-	// last segment whose first edge is <= e0
-	u32 lo = s_begin, hi = s_end;
-	while (hi - lo > 1) {
-		u32 const mid = lo + (hi - lo) / 2;
-		if (rs.seg_edge_begin[mid] <= e0) lo = mid; else hi = mid;
+	return rs.assembled[(u64) row * rs.assembled_words + wi];
+}
+
+// Founder rows switch chromosome copy at every cut node -- hundreds of thousands of segments per row at 1KG scale,
+// dozens per 64-edge word.  One wave puts 64 words of one row together: the segments that touch them are a
+// contiguous piece of the row's (sorted) segment table, found once; the lanes then take one segment each, so the
+// table is read coalesced and all the scattered path-word loads of the piece are in flight together.
+__global__ __launch_bounds__(256) void assemble_row_bits_kernel(
+	u64 const *__restrict__ paths, u64 words_per_copy, row_segments rs, u64 *__restrict__ assembled, u32 n_words, u32 row_base)
+{
+	__shared__ unsigned long long acc[256];
+	u32 const row = blockIdx.y + row_base;
+	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
+	if (s_end - s_begin <= 1) return;                        // whole workgroup: the row is read straight from its copy
+	u32 const lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	u32 const w0 = (blockIdx.x * 4 + wave) * 64;              // this wave's first word
+	acc[threadIdx.x] = 0;
+	__syncthreads();
+	if (w0 < n_words) {
+		u64 const e_lo = (u64) w0 * 64;
+		u64 const e_hi = (u64) (w0 + 64 < n_words ? w0 + 64 : n_words) * 64;
+		// last segment whose first edge is <= e_lo (the first segment of a row starts at edge 0)
+		u32 lo = s_begin, hi = s_end;
+		while (hi - lo > 1) {
+			u32 const mid = lo + (hi - lo) / 2;
+			if (rs.seg_edge_begin[mid] <= e_lo) lo = mid; else hi = mid;
+		}
+		for (u32 s = lo + lane; s < s_end; s += 64) {
+			u64 b = rs.seg_edge_begin[s];
+			if (b >= e_hi) break;
+			u64 e = (s + 1 < s_end) ? rs.seg_edge_begin[s + 1] : ~0ULL;
+			u32 const copy = rs.seg_copy[s];
+			if (copy == 0xFFFFFFFFu) continue;
+			b = b > e_lo ? b : e_lo;
+			e = e < e_hi ? e : e_hi;
+			if (b >= e) continue;
+			u64 const *const column = paths + (u64) copy * words_per_copy;
+			for (u64 wi = b >> 6; wi <= (e - 1) >> 6; ++wi) {
+				u64 const base = wi * 64;
+				u32 const from = b > base ? (u32) (b - base) : 0;   // first bit of this word in the segment
+				u32 const to = e < base + 64 ? (u32) (e - base) : 64;   // one past the last
+				u64 const mask = (to >= 64 ? ~0ULL : ((1ULL << to) - 1)) & ~((1ULL << from) - 1);
+				u64 const v = column[wi] & mask;
+				if (v) atomicOr(&acc[wave * 64 + (u32) (wi - w0)], (unsigned long long) v);
+			}
+		}
 	}
-	u64 w = 0;
-	for (u32 s = lo; s < s_end; ++s) {
-		u32 const b = rs.seg_edge_begin[s];
-		if (b >= e0 + 64) break;
-		u32 const e = (s + 1 < s_end) ? rs.seg_edge_begin[s + 1] : 0xFFFFFFFFu;
-		if (e <= e0) continue;
-		u32 const copy = rs.seg_copy[s];
-		if (copy == 0xFFFFFFFFu) continue;
-		u32 const from = (b > e0) ? b - e0 : 0;             // first bit of this word in the segment
-		u32 const to = (e < e0 + 64) ? e - e0 : 64;         // one past the last
-		u64 mask = (to >= 64 ? ~0ULL : ((1ULL << to) - 1)) & ~((1ULL << from) - 1);
-		w |= paths[(u64) copy * words_per_copy + wi] & mask;
-	}
-	return w;
+	__syncthreads();
+	if (w0 + lane < n_words) assembled[(u64) row * rs.assembled_words + w0 + lane] = acc[threadIdx.x];
 }
 
 constexpr u32 kMaxBackWords = 2048;   // default max_back_words: restart points > 131072 edges back go to the serial kernel
@@ -356,7 +387,7 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
 	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;   // padding bits are zero by contract; do not trust them
 
-	u64 w = load_row_word(paths, words_per_copy, rs, s_begin, s_end, wi);
+	u64 w = load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, wi);
 	if (wi == n_words - 1) w &= tail_mask;
 	u64 const ovl_w = overlappable[wi];
 	u64 const ov = w & ovl_w;
@@ -388,7 +419,7 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 			out = (sw == wi) ? (w & ((1ULL << sb) - 1)) : 0;   // set bits before the restart point in this word are certain
 			u32 cur = 0;
 			for (u32 ww = sw; ww <= wi; ++ww) {
-				u64 x = (ww == wi) ? w : load_row_word(paths, words_per_copy, rs, s_begin, s_end, ww);
+				u64 x = (ww == wi) ? w : load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, ww);
 				if (ww == sw) x &= ~((1ULL << sb) - 1);
 				for (; x; x &= x - 1) {
 					int const b = __builtin_ctzll(x);
@@ -425,7 +456,7 @@ __global__ __launch_bounds__(256) void resolve_rows_serial_kernel(
 		u32 const wi = base + lane;
 		u64 w = 0;
 		if (wi < n_words) {
-			w = load_row_word(paths, words_per_copy, rs, s_begin, s_end, wi);
+			w = load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, wi);
 			if (wi == n_words - 1 && (n_edges & 63))
 				w &= (1ULL << (n_edges & 63)) - 1;       // padding bits are zero by contract; do not trust them
 		}

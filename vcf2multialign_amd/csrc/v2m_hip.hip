@@ -102,7 +102,7 @@ struct v2m_ctx {
 	std::string info;
 
 	// per-call scratch
-	dev_buf d_eff, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial, d_tile_counts, d_row_lengths;
+	dev_buf d_eff, d_row_bits, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial, d_tile_counts, d_row_lengths;
 	dev_buf ring[2];
 	pinned_buf host_ring[2];
 	hipEvent_t ev_compute[2]{}, ev_copy[2]{};
@@ -339,13 +339,22 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 	V2M_HIP_TRY(ctx, ctx->d_needs_serial.ensure(n_rows * sizeof(u32)));
 	V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_needs_serial.p, 0, n_rows * sizeof(u32), ctx->stream));
 
-	v2m::row_segments rs{ctx->d_seg_offsets.as<u32>(), ctx->d_seg_edge_begin.as<u32>(), ctx->d_seg_copy.as<u32>()};
+	// rows that switch copies (founder rows) get their bit column put together first
+	bool any_switching_row(false);
+	for (u64 r(0); r < n_rows && !any_switching_row; ++r) any_switching_row = pr.seg_offsets[r + 1] - pr.seg_offsets[r] > 1;
+	if (any_switching_row) V2M_HIP_TRY(ctx, ctx->d_row_bits.ensure(n_rows * eff_words * sizeof(u64)));
+
+	v2m::row_segments rs{ctx->d_seg_offsets.as<u32>(), ctx->d_seg_edge_begin.as<u32>(), ctx->d_seg_copy.as<u32>(),
+		any_switching_row ? ctx->d_row_bits.as<u64>() : nullptr, u32(eff_words)};
 	char const *const back_env(std::getenv("V2M_MAX_BACK_WORDS"));   // test knob: 0 forces the serial kernel for every cross-word restart
 	u32 const max_back_words((back_env && *back_env) ? u32(std::strtoul(back_env, nullptr, 10)) : v2m::kMaxBackWords);
 	{
 		timed_launch tl(ctx, V2M_KERNEL_RESOLVE);
 		for (u64 r0(0); r0 < n_rows; r0 += 65535) {   // grid.y limit
 			u64 const nr(std::min<u64>(65535, n_rows - r0));
+			if (any_switching_row)
+				hipLaunchKernelGGL(v2m::assemble_row_bits_kernel, dim3(unsigned((n_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
+					ctx->d_paths, ctx->path_rows / 64, rs, ctx->d_row_bits.as<u64>(), u32(n_words), u32(r0));
 			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
 				ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
 				ctx->d_eff.as<u64>(), u32(n_words), u32(eff_words), u32(r0), ctx->d_needs_serial.as<u32>(), max_back_words);
