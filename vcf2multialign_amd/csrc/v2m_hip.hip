@@ -102,6 +102,7 @@ struct v2m_ctx {
 	std::string info;
 
 	// per-call scratch
+	pinned_buf h_row_stage;   // segment tables of the row batch being resolved
 	dev_buf d_eff, d_row_bits, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial, d_tile_counts, d_row_lengths;
 	dev_buf ring[2];
 	pinned_buf host_ring[2];
@@ -251,26 +252,52 @@ int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64
 
 
 // Host-side preparation of a row batch: validates it against the uploaded graph and flattens
-// every row into (edge_begin, copy) segments.
+// every row into (edge_begin, copy) segments.  The tables are written straight into the context's pinned
+// staging area: founder batches carry hundreds of thousands of segments per row, and uploading those from pageable
+// memory makes the runtime pin and unpin the pages as userptr memory, which stalls the queue for tens of ms.
 struct prepared_rows {
-	std::vector<u32> seg_offsets, seg_edge_begin, seg_copy;
+	u32 *seg_offsets{};      // [n_rows + 1]
+	u32 *seg_edge_begin{};   // [n_segments]
+	u32 *seg_copy{};         // [n_segments]
+	u64 n_rows{}, n_segments{};
+	bool any_switching_row{};
 };
 
 int prepare_rows(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row_end, prepared_rows &out)
 {
-	out.seg_offsets.assign(1, 0);
-	out.seg_edge_begin.clear();
-	out.seg_copy.clear();
+	u64 const n_rows(row_end - row_begin);
+	u64 max_segments(n_rows);                                 // a row without cuts is one segment ...
+	if (rows->cut_offsets) {
+		for (u64 r(row_begin); r < row_end; ++r) {
+			if (rows->cut_offsets[r + 1] < rows->cut_offsets[r])
+				return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut_offsets decrease at row %llu", (unsigned long long) r);
+			max_segments += rows->cut_offsets[r + 1] - rows->cut_offsets[r];   // ... one with cuts has one per cut, plus a leading REF one
+		}
+	}
+	if (max_segments >= 0xFFFFFFFFull)
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "row batch has too many cut segments (%llu) for one call", (unsigned long long) max_segments);
+	auto const pad([](u64 n) { return (n * sizeof(u32) + 63) & ~u64(63); });
+	V2M_HIP_TRY(ctx, ctx->h_row_stage.ensure(pad(n_rows + 1) + 2 * pad(max_segments)));
+	char *const base(static_cast<char *>(ctx->h_row_stage.p));
+	out.seg_offsets = reinterpret_cast<u32 *>(base);
+	out.seg_edge_begin = reinterpret_cast<u32 *>(base + pad(n_rows + 1));
+	out.seg_copy = reinterpret_cast<u32 *>(base + pad(n_rows + 1) + pad(max_segments));
+	out.n_rows = n_rows;
+	out.any_switching_row = false;
+
+	u32 n(0);
+	out.seg_offsets[0] = 0;
 	for (u64 r(row_begin); r < row_end; ++r) {
 		u64 const c_begin(rows->cut_offsets ? rows->cut_offsets[r] : 0), c_end(rows->cut_offsets ? rows->cut_offsets[r + 1] : 0);
-		if (c_end < c_begin) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut_offsets decrease at row %llu", (unsigned long long) r);
+		u32 const first(n);
 		if (c_begin == c_end) {
 			if (!rows->copy_index) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row %llu has no cuts and rows->copy_index is NULL", (unsigned long long) r);
 			u32 const copy(rows->copy_index[r]);
 			if (copy != V2M_PLOIDY_MAX && (!ctx->d_paths || copy >= ctx->path_cols))
 				return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row %llu: chromosome copy %u is outside the path matrix (%llu columns)", (unsigned long long) r, copy, (unsigned long long) ctx->path_cols);
-			out.seg_edge_begin.push_back(0);
-			out.seg_copy.push_back(copy);
+			out.seg_edge_begin[n] = 0;
+			out.seg_copy[n] = copy;
+			++n;
 		} else {
 			u64 prev(0);
 			for (u64 k(c_begin); k < c_end; ++k) {
@@ -285,16 +312,20 @@ int prepare_rows(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row
 				if (node > 0 && ctx->h_tgt_prefix_max[first_edge] > node)
 					return fail(ctx, V2M_ERR_PRECONDITION, "row %llu: cut node %llu lies inside the span of an ALT edge", (unsigned long long) r, (unsigned long long) node);
 				if (k == c_begin && node != 0) {   // copy index is PLOIDY_MAX until the first cut is visited
-					out.seg_edge_begin.push_back(0);
-					out.seg_copy.push_back(V2M_PLOIDY_MAX);
+					out.seg_edge_begin[n] = 0;
+					out.seg_copy[n] = V2M_PLOIDY_MAX;
+					++n;
 				}
-				out.seg_edge_begin.push_back(first_edge);
-				out.seg_copy.push_back(copy);
+				out.seg_edge_begin[n] = first_edge;
+				out.seg_copy[n] = copy;
+				++n;
 				prev = node;
 			}
 		}
-		out.seg_offsets.push_back(u32(out.seg_copy.size()));
+		out.any_switching_row = out.any_switching_row || n - first > 1;
+		out.seg_offsets[r - row_begin + 1] = n;
 	}
+	out.n_segments = n;
 	return V2M_OK;
 }
 
@@ -330,18 +361,22 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 
 	prepared_rows pr;
 	if (int const rc = prepare_rows(ctx, rows, row_begin, row_end, pr)) return rc;
-	if (int const rc = upload_vec(ctx, ctx->d_seg_offsets, pr.seg_offsets)) return rc;
-	if (int const rc = upload_vec(ctx, ctx->d_seg_edge_begin, pr.seg_edge_begin)) return rc;
-	if (int const rc = upload_vec(ctx, ctx->d_seg_copy, pr.seg_copy)) return rc;
-	// the vectors die at the end of this scope; pageable-memory async copies have been staged by then
+	auto const upload([&](dev_buf &dst, u32 const *src, u64 count) -> int {
+		V2M_HIP_TRY(ctx, dst.ensure(std::max<size_t>(count * sizeof(u32), 16)));
+		if (count) V2M_HIP_TRY(ctx, hipMemcpyAsync(dst.p, src, count * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
+		return V2M_OK;
+	});
+	if (int const rc = upload(ctx->d_seg_offsets, pr.seg_offsets, n_rows + 1)) return rc;
+	if (int const rc = upload(ctx->d_seg_edge_begin, pr.seg_edge_begin, pr.n_segments)) return rc;
+	if (int const rc = upload(ctx->d_seg_copy, pr.seg_copy, pr.n_segments)) return rc;
+	// the staging area is reused by the next call
 	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	V2M_HIP_TRY(ctx, ctx->d_eff.ensure(n_rows * eff_words * sizeof(u64)));
 	V2M_HIP_TRY(ctx, ctx->d_needs_serial.ensure(n_rows * sizeof(u32)));
 	V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_needs_serial.p, 0, n_rows * sizeof(u32), ctx->stream));
 
 	// rows that switch copies (founder rows) get their bit column put together first
-	bool any_switching_row(false);
-	for (u64 r(0); r < n_rows && !any_switching_row; ++r) any_switching_row = pr.seg_offsets[r + 1] - pr.seg_offsets[r] > 1;
+	bool const any_switching_row(pr.any_switching_row);
 	if (any_switching_row) V2M_HIP_TRY(ctx, ctx->d_row_bits.ensure(n_rows * eff_words * sizeof(u64)));
 
 	v2m::row_segments rs{ctx->d_seg_offsets.as<u32>(), ctx->d_seg_edge_begin.as<u32>(), ctx->d_seg_copy.as<u32>(),
