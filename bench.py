@@ -72,7 +72,7 @@ def main():
 	ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal of N > 1)")
 	ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this HIP device")
 	ap.add_argument("--output-candidates", type=int, default=3, help="device buffers v2m_alloc_output may try for the output (1 = plain allocation)")
-	ap.add_argument("--cpu-baseline-rows", type=int, default=64, help="haplotypes (plus REF) the CPU oracle is timed on; 0 disables")
+	ap.add_argument("--cpu-baseline-rows", type=int, default=320, help="haplotypes (plus REF) the CPU oracle is timed on (320 rows of config 3 = 32 Gbases, about 11 s on one core); 0 disables")
 	ap.add_argument("--verify-rows", type=int, default=3, help="rows of the last batch checked against the CPU oracle after timing; 0 disables")
 	args = ap.parse_args()
 
