@@ -167,10 +167,73 @@ def test_graph_checkpoint(tmp_path):
 	assert run(["-H", "-r", fa, "-g", str(graph), "-a", vcf, "-c", "1", "-s", str(b)]).returncode != 0
 
 
+def test_pipe(tmp_path):
+	"""--pipe=command (output.cc:26-38,49-68): `command <name>` reads what would have been written to <name>."""
+	fa, vcf = os.path.join(FIX, "test-2.fa"), os.path.join(FIX, "test-2.vcf")
+	script = tmp_path / "sink.sh"
+	script.write_text("#!/bin/sh\ncat > \"$1.piped\"\n")
+	script.chmod(0o755)
+	common = ["-H", "-r", fa, "-a", vcf, "-c", "1"]
+	direct = tmp_path / "direct.a2m"
+	assert run(common + ["-s", str(direct)]).returncode == 0
+	r = run(common + ["-s", str(tmp_path / "out.a2m"), "--pipe=" + str(script)])
+	assert r.returncode == 0, r.stderr.decode()
+	assert not (tmp_path / "out.a2m").exists()
+	assert (tmp_path / "out.a2m.piped").read_bytes() == direct.read_bytes()
+
+	# one subprocess per sequence with --output-sequences-separate
+	(tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+	assert run(common + ["--output-sequences-separate"], cwd=str(tmp_path / "a")).returncode == 0
+	r = run(common + ["--output-sequences-separate", "--pipe=" + str(script)], cwd=str(tmp_path / "b"))
+	assert r.returncode == 0, r.stderr.decode()
+	names = sorted(os.listdir(tmp_path / "a"))
+	assert len(names) == 7 and sorted(os.listdir(tmp_path / "b")) == [n + ".piped" for n in names]
+	for n in names:
+		assert (tmp_path / "b" / (n + ".piped")).read_bytes() == (tmp_path / "a" / n).read_bytes()
+
+	# founder mode through a pipe, several MB per row (more than one pipe buffer and more than the stream buffer)
+	g = synth.build_case(tmp_path, 64, 3_000_000, 3000, 4)
+	big = ["-F", "3", "-r", str(tmp_path / "synth.fa"), "-a", str(tmp_path / "synth.vcf"), "-c", "1"]
+	assert run(big + ["-s", str(tmp_path / "f.a2m")]).returncode == 0
+	assert run(big + ["-s", str(tmp_path / "g.a2m"), "--pipe=" + str(script)]).returncode == 0
+	assert (tmp_path / "g.a2m.piped").read_bytes() == (tmp_path / "f.a2m").read_bytes()
+	assert (tmp_path / "f.a2m").stat().st_size > 4 * g.aligned_length
+
+	# failures: a command that cannot be executed, one that exits non-zero, one that stops reading
+	r = run(common + ["-s", str(tmp_path / "x.a2m"), "--pipe=/nonexistent/command"])
+	assert r.returncode != 0 and b"Unable to execute subprocess" in r.stderr
+	r = run(common + ["-s", str(tmp_path / "x.a2m"), "--pipe=false"])
+	assert r.returncode != 0 and b"exited with status 1" in r.stderr
+	quitter = tmp_path / "quit.sh"
+	quitter.write_text("#!/bin/sh\nhead -c 10 > /dev/null\nexit 3\n")
+	quitter.chmod(0o755)
+	r = run(big + ["-s", str(tmp_path / "x.a2m"), "--pipe=" + str(quitter)])
+	assert r.returncode != 0 and b"exited with status 3" in r.stderr
+
+
+def test_cut_position_files(tmp_path):
+	"""--output-cut-positions, then --input-cut-positions instead of the search: same founders."""
+	synth.build_case(tmp_path, 65, 100000, 1500, 8)
+	common = ["-F", "4", "-r", str(tmp_path / "synth.fa"), "-a", str(tmp_path / "synth.vcf"), "-c", "1"]
+	r1 = run(common + ["-d", "40", "-s", str(tmp_path / "a.a2m"), "-t", str(tmp_path / "cuts.bin")])
+	assert r1.returncode == 0, r1.stderr.decode()
+	r2 = run(common + ["-s", str(tmp_path / "b.a2m"), "--input-cut-positions=" + str(tmp_path / "cuts.bin"), "--output-cut-positions=" + str(tmp_path / "cuts2.bin")])
+	assert r2.returncode == 0, r2.stderr.decode()
+	assert b"Optimising cut positions" in r1.stderr and b"Optimising cut positions" not in r2.stderr
+	assert (tmp_path / "a.a2m").read_bytes() == (tmp_path / "b.a2m").read_bytes()
+	assert (tmp_path / "cuts.bin").read_bytes() == (tmp_path / "cuts2.bin").read_bytes()     # min_distance and score are carried over
+	assert r1.stdout == r2.stdout                                                             # "Maximum segmentation height: ..."
+	from vcf2multialign_amd import host
+	cuts, min_distance, score = host.read_cut_positions(tmp_path / "cuts.bin")
+	assert min_distance == 40 and cuts[0] == 0 and ("Maximum segmentation height: %d" % (1 + score)).encode() in r1.stdout
+	(tmp_path / "bad.bin").write_bytes(b"garbage")
+	assert run(common + ["-s", str(tmp_path / "c.a2m"), "-p", str(tmp_path / "bad.bin")]).returncode != 0
+
+
 def test_unsupported_and_bad_arguments():
 	assert run(["--founder-sequences=0", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
 	assert run(["-H", "--founder-sequences=2", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
-	assert run(["-H", "--pipe=cat", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
+	assert run(["-H", "--output-graphviz=g.dot", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
 	assert run(["-H", "-r", "x", "-a", "y"]).returncode != 0
 	r = run(["-H", "-r", "/nonexistent.fa", "-a", "/nonexistent.vcf", "-c", "1"])
 	assert r.returncode != 0 and b"Unable to read the reference" in r.stderr

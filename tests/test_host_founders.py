@@ -70,3 +70,21 @@ def test_random_inputs_against_the_literal_restatement(HostGraph, tmp_path, seed
 	assert og.edge_count > 0
 	for founders, min_distance, keep in ((1, 0, False), (2, 0, False), (3, 10, True), (7, 50, False), (25, 50, False), (4, 1000, True), (5, 10 * ref_len, False)):
 		assert hg.find_founders(founders, min_distance, keep_ref_edges=keep) == og.find_founders(founders, min_distance, keep_ref_edges=keep), (founders, min_distance, keep)
+
+
+def test_cut_position_file_round_trip(HostGraph, tmp_path):
+	"""--output-cut-positions / --input-cut-positions: {min_distance, cut_positions, score} in cereal's portable-binary
+	layout (output.hh:133-139); the reference holds no such file, so only the layout stated in founder.hh is checked."""
+	import struct
+	from vcf2multialign_amd import host
+	p = tmp_path / "cuts.bin"
+	host.write_cut_positions(p, [0, 3, 17, 2 ** 40 + 5], 50, 7)
+	raw = p.read_bytes()
+	assert raw == b"\x01" + struct.pack("<IQQ", 0, 50, 4) + struct.pack("<4Q", 0, 3, 17, 2 ** 40 + 5) + struct.pack("<I", 7)
+	assert host.read_cut_positions(p) == ([0, 3, 17, 2 ** 40 + 5], 50, 7)
+	host.write_cut_positions(p, [], 0, 0)
+	assert host.read_cut_positions(p) == ([], 0, 0)
+	for bad in (b"", b"\x00" + raw[1:], raw[:-2], raw[:5] + struct.pack("<QQ", 50, 10 ** 15)):
+		p.write_bytes(bad)
+		with pytest.raises(ValueError):
+			host.read_cut_positions(p)

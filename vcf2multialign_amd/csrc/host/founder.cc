@@ -1,6 +1,8 @@
 #include "founder.hh"
 
 #include <algorithm>
+#include <cstring>
+#include <fstream>
 #include <map>
 #include <numeric>
 #include <stdexcept>
@@ -467,6 +469,60 @@ bool find_matchings(
 			assigned[founder * rows + 0] = c->rhs_rep;
 	}
 	return true;
+}
+
+
+namespace {
+	template <typename T> void put_le(std::ostream &os, T v)
+	{
+		unsigned char b[sizeof(T)];
+		for (std::size_t i(0); i < sizeof(T); ++i) b[i] = (unsigned char) (v >> (8 * i));
+		os.write(reinterpret_cast<char const *>(b), sizeof(T));
+	}
+
+	template <typename T> T get_le(std::istream &is, char const *path)
+	{
+		unsigned char b[sizeof(T)];
+		if (!is.read(reinterpret_cast<char *>(b), sizeof(T))) throw std::runtime_error(std::string(path) + ": truncated cut position file");
+		T v(0);
+		for (std::size_t i(0); i < sizeof(T); ++i) v |= T(b[i]) << (8 * i);
+		return v;
+	}
+}
+
+
+void write_cut_positions(cut_position_file const &cuts, char const *path)
+{
+	std::ofstream os(path, std::ios::binary | std::ios::trunc);
+	if (!os) throw std::runtime_error(std::string("unable to open ") + path + " for writing");
+	os.put(1);                                                                // archive header: little-endian
+	put_le<std::uint32_t>(os, 0);                                             // class version of cut_positions (first use of the type)
+	put_le<u64>(os, cuts.min_distance);                                       // serialize(): min_distance, cut_positions, score (output.hh:133-139)
+	put_le<u64>(os, cuts.cut_positions.size());
+	for (u64 const c : cuts.cut_positions) put_le<u64>(os, c);
+	put_le<u32>(os, cuts.score);
+	os.flush();
+	if (!os) throw std::runtime_error(std::string("error while writing ") + path);
+}
+
+
+cut_position_file read_cut_positions(char const *path)
+{
+	std::ifstream is(path, std::ios::binary);
+	if (!is) throw std::runtime_error(std::string("unable to open ") + path);
+	int const marker(is.get());
+	if (1 != marker) throw std::runtime_error(std::string(path) + ": not a little-endian portable-binary cut position file");
+	if (0 != get_le<std::uint32_t>(is, path)) throw std::runtime_error(std::string(path) + ": unknown cut position file version");
+	cut_position_file out;
+	out.min_distance = get_le<u64>(is, path);
+	u64 const count(get_le<u64>(is, path));
+	is.seekg(0, std::ios::end);
+	if (count > u64(is.tellg()) / 8) throw std::runtime_error(std::string(path) + ": cut position count exceeds the file size");
+	is.seekg(1 + 4 + 8 + 8, std::ios::beg);
+	out.cut_positions.resize(count);
+	for (u64 &c : out.cut_positions) c = get_le<u64>(is, path);
+	out.score = get_le<u32>(is, path);
+	return out;
 }
 
 } // namespace v2m::host

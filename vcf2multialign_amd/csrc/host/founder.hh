@@ -30,4 +30,17 @@ bool find_matchings(
 	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
 	std::vector<u32> &assigned_samples);
 
+// --output-cut-positions / --input-cut-positions (founder_sequence_greedy_output.cc:118-136).  The reference writes the
+// struct {min_distance, cut_positions, score} (output.hh:89-97,133-139) through cereal's PortableBinaryOutputArchive;
+// cereal is not part of the reference tree, so the layout below restates cereal's published portable-binary encoding
+// and is not pinned by any file of the reference: one byte 1 (little-endian marker), u32 class version 0,
+// u64 min_distance, u64 count, count x u64 node indices, u32 score; all little-endian.
+struct cut_position_file {
+	std::vector<u64> cut_positions;
+	u64 min_distance{};
+	u32 score{};
+};
+void write_cut_positions(cut_position_file const &cuts, char const *path);
+cut_position_file read_cut_positions(char const *path);
+
 } // namespace v2m::host

@@ -158,4 +158,32 @@ uint64_t v2mh_find_founders(void *h, uint64_t min_distance, uint32_t founder_cou
 	return cuts.size();
 }
 
+// Cut position files (founder.hh).  Return 0 on success, 1 with a message in err otherwise.
+int v2mh_write_cut_positions(char const *path, uint64_t const *cuts, uint64_t n_cuts, uint64_t min_distance, uint32_t score, char *err, size_t errlen)
+{
+	try {
+		vh::write_cut_positions({std::vector<vh::u64>(cuts, cuts + n_cuts), min_distance, score}, path);
+		return 0;
+	} catch (std::exception const &e) {
+		if (err && errlen) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+		return 1;
+	}
+}
+
+// cuts_out may be NULL to query the count (returned through *n_cuts); otherwise it must hold *n_cuts entries.
+int v2mh_read_cut_positions(char const *path, uint64_t *cuts_out, uint64_t *n_cuts, uint64_t *min_distance, uint32_t *score, char *err, size_t errlen)
+{
+	try {
+		auto const f(vh::read_cut_positions(path));
+		if (cuts_out && *n_cuts >= f.cut_positions.size()) std::copy(f.cut_positions.begin(), f.cut_positions.end(), cuts_out);
+		*n_cuts = f.cut_positions.size();
+		if (min_distance) *min_distance = f.min_distance;
+		if (score) *score = f.score;
+		return 0;
+	} catch (std::exception const &e) {
+		if (err && errlen) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+		return 1;
+	}
+}
+
 } // extern "C"

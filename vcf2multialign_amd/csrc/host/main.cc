@@ -1,6 +1,7 @@
 // main.cc -- thin command-line driver with the reference's flag names (vcf2multialign/cmdline.ggo:4-55,
-// vcf2multialign/main.cc:370-552) for the part this repository implements: --haplotypes with FASTA + VCF input,
-// A2M / separate / unaligned output, sample filters, overlap reports.  The per-row splicing and the path-matrix
+// vcf2multialign/main.cc:370-552) for the part this repository implements: --haplotypes and --founder-sequences with
+// FASTA + VCF (or checkpointed graph) input, A2M / separate / unaligned / piped output, sample filters, overlap
+// reports, cut-position files.  The per-row splicing and the path-matrix
 // transpose run on the GPU (there is no CPU path); everything else is host code.
 
 #include <getopt.h>
@@ -16,6 +17,8 @@
 #include <string>
 #include <tuple>
 #include <vector>
+
+#include <csignal>
 
 #include "founder.hh"
 #include "gpu_path.hh"
@@ -36,6 +39,7 @@ struct options {
 	char const *output_sequences_a2m{}, *dst_chromosome{}, *output_overlaps{};
 	char const *include_samples{}, *exclude_samples{};
 	char const *input_graph{}, *output_graph{};
+	char const *pipe{}, *input_cut_positions{}, *output_cut_positions{};
 	bool output_sequences_separate{}, separate_plain{}, omit_reference{}, unaligned{}, verbose{}, graph_statistics{};
 	bool ref_mismatch_error{};
 	std::vector<int> devices{0};
@@ -69,7 +73,10 @@ void usage()
 		"      --keep-ref-edges               Take the reference edges into account when matching\n"
 		"  -g, --input-graph=filename         Variant graph input (this build's flat V2MGRAF1 format)\n"
 		"  -f, --output-graph=filename        Output the variant graph\n"
-		"Not supported by this build: --output-graphviz, --pipe, --input/--output-cut-positions.\n";
+		"  -p, --input-cut-positions=file     Cut position input\n"
+		"  -t, --output-cut-positions=file    Output the cut positions\n"
+		"      --pipe=command                 Instead of writing sequences to files, pipe them to `command <name>`\n"
+		"Not supported by this build: --output-graphviz.\n";
 }
 
 typedef std::set<std::tuple<std::string, std::string, unsigned>> sample_set;
@@ -147,8 +154,9 @@ struct progress_delegate final : vh::output_delegate {
 
 int main(int argc, char **argv)
 {
+	::signal(SIGPIPE, SIG_IGN);   // main.cc:372: a --pipe child that goes away shows up as a write error
 	options opt;
-	enum { o_keep_ref = 900, o_separate = 1000, o_sep_format, o_omit_ref, o_unaligned, o_overlaps, o_stats, o_mismatch, o_include, o_device, o_verbose, o_unsupported };
+	enum { o_keep_ref = 900, o_separate = 1000, o_sep_format, o_omit_ref, o_unaligned, o_overlaps, o_stats, o_mismatch, o_include, o_device, o_verbose, o_pipe, o_unsupported };
 	static option const longopts[] = {
 		{"haplotypes", no_argument, nullptr, 'H'}, {"founder-sequences", required_argument, nullptr, 'F'},
 		{"input-reference", required_argument, nullptr, 'r'}, {"reference-sequence", required_argument, nullptr, 'e'},
@@ -160,12 +168,12 @@ int main(int argc, char **argv)
 		{"ref-mismatch-handling", required_argument, nullptr, o_mismatch}, {"include-samples", required_argument, nullptr, o_include},
 		{"exclude-samples", required_argument, nullptr, 'x'}, {"device", required_argument, nullptr, o_device}, {"verbose", no_argument, nullptr, o_verbose},
 		{"input-graph", required_argument, nullptr, 'g'}, {"output-graph", required_argument, nullptr, 'f'},
-		{"output-graphviz", required_argument, nullptr, o_unsupported}, {"pipe", required_argument, nullptr, o_unsupported},
-		{"minimum-distance", required_argument, nullptr, 'd'}, {"input-cut-positions", required_argument, nullptr, o_unsupported},
-		{"output-cut-positions", required_argument, nullptr, o_unsupported}, {"keep-ref-edges", no_argument, nullptr, o_keep_ref},
+		{"output-graphviz", required_argument, nullptr, o_unsupported}, {"pipe", required_argument, nullptr, o_pipe},
+		{"minimum-distance", required_argument, nullptr, 'd'}, {"input-cut-positions", required_argument, nullptr, 'p'},
+		{"output-cut-positions", required_argument, nullptr, 't'}, {"keep-ref-edges", no_argument, nullptr, o_keep_ref},
 		{"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
 	int c;
-	while (-1 != (c = getopt_long(argc, argv, "HF:d:r:e:a:c:s:m:x:g:f:h", longopts, nullptr))) {
+	while (-1 != (c = getopt_long(argc, argv, "HF:d:p:t:r:e:a:c:s:m:x:g:f:h", longopts, nullptr))) {
 		switch (c) {
 			case 'H': opt.haplotypes = true; break;
 			case 'F': opt.founder_mode = true; opt.founder_sequences = std::atol(optarg); break;
@@ -202,6 +210,9 @@ int main(int argc, char **argv)
 				break;
 			}
 			case o_verbose: opt.verbose = true; break;
+			case o_pipe: opt.pipe = optarg; break;
+			case 'p': opt.input_cut_positions = optarg; break;
+			case 't': opt.output_cut_positions = optarg; break;
 			case 'h': usage(); return EXIT_SUCCESS;
 			case o_unsupported: std::cerr << "ERROR: option " << argv[optind - 1] << " is not supported by this build.\n"; return EXIT_FAILURE;
 			default: usage(); return EXIT_FAILURE;
@@ -288,22 +299,33 @@ int main(int argc, char **argv)
 		});
 
 		if (opt.haplotypes) {
-			vh::haplotype_output output(gpu, nullptr, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
+			vh::haplotype_output output(gpu, opt.pipe, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
 			for (auto &g : more_gpus) output.add_gpu(*g);
 			do_output(output);
 		} else {                                            // main.cc:487-550
-			vh::founder_sequence_greedy_output output(gpu, nullptr, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
+			vh::founder_sequence_greedy_output output(gpu, opt.pipe, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
 			for (auto &g : more_gpus) output.add_gpu(*g);
-			std::cerr << "Optimising cut positions...\n";
 			std::vector<vh::u64> cuts;
-			vh::u32 const score(vh::find_cut_positions(graph, vh::u64(opt.minimum_distance), cuts));
-			if (vh::kCutPositionScoreMax == score) { std::cerr << "ERROR: Unable to optimise cut positions.\n"; return EXIT_FAILURE; }
-			if (opt.verbose) {
-				std::cout << "Cut positions:";
-				for (auto const cp : cuts) std::cout << ' ' << cp;
-				std::cout << '\n';
+			vh::u32 score(0);
+			vh::u64 cut_min_distance(vh::u64(opt.minimum_distance));
+			if (opt.input_cut_positions) {                  // main.cc:499-500
+				auto loaded(vh::read_cut_positions(opt.input_cut_positions));
+				cuts = std::move(loaded.cut_positions);
+				score = loaded.score;
+				cut_min_distance = loaded.min_distance;
+			} else {
+				std::cerr << "Optimising cut positions...\n";
+				score = vh::find_cut_positions(graph, vh::u64(opt.minimum_distance), cuts);
+				if (vh::kCutPositionScoreMax == score) { std::cerr << "ERROR: Unable to optimise cut positions.\n"; return EXIT_FAILURE; }
+				if (opt.verbose) {
+					std::cout << "Cut positions:";
+					for (auto const cp : cuts) std::cout << ' ' << cp;
+					std::cout << '\n';
+				}
 			}
 			std::cout << "Maximum segmentation height: " << (1 + vh::u64(score)) << '\n';   // main.cc:520
+			if (opt.output_cut_positions)                   // main.cc:522-523
+				vh::write_cut_positions({cuts, cut_min_distance, score}, opt.output_cut_positions);
 			std::cerr << "Finding matchings in the variant graph...\n";
 			std::vector<vh::u32> assigned;
 			if (!vh::find_matchings(graph, cuts, vh::u32(opt.founder_sequences), opt.keep_ref_edges, assigned)) { std::cerr << "ERROR: Unable to find matchings.\n"; return EXIT_FAILURE; }

@@ -2,20 +2,153 @@
 
 #include <fcntl.h>
 #include <sys/uio.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
+#include <cerrno>
+#include <cstring>
 #include <exception>
 #include <fstream>
 #include <stdexcept>
+#include <streambuf>
 #include <thread>
 
 namespace v2m::host {
 
 output::output(gpu_context &gpu, char const *pipe_cmd, char const *chromosome_id, bool should_output_reference, bool should_output_unaligned, output_delegate &delegate):
-	m_gpu(gpu), m_chromosome_id(chromosome_id), m_delegate(&delegate),
+	m_gpu(gpu), m_pipe_cmd(pipe_cmd), m_chromosome_id(chromosome_id), m_delegate(&delegate),
 	m_should_output_reference(should_output_reference), m_should_output_unaligned(should_output_unaligned)
 {
-	if (pipe_cmd) throw std::runtime_error("--pipe is not supported by this build");   // output.cc:26-38,49-68
+}
+
+
+namespace {
+	// --pipe (output.cc:26-38,49-68): `command dst_name` as a child process that reads the sequences from its standard
+	// input instead of us writing the file.  libbio::subprocess<STDIN> with KEEP_STDERR there: the child's stderr is
+	// ours; its stdout goes to /dev/null here (libbio is not part of the reference tree, so this detail is unpinned).
+	class pipe_process {
+	public:
+		pipe_process(char const *command, char const *dst_name)
+		{
+			int in[2], status[2];
+			if (0 != ::pipe2(in, O_CLOEXEC)) fail_errno("pipe");
+			if (0 != ::pipe2(status, O_CLOEXEC)) { int const e(errno); ::close(in[0]); ::close(in[1]); errno = e; fail_errno("pipe"); }
+			m_pid = ::fork();
+			if (m_pid < 0) { int const e(errno); ::close(in[0]); ::close(in[1]); ::close(status[0]); ::close(status[1]); errno = e; fail_errno("fork"); }
+			if (0 == m_pid) {
+				// child: only async-signal-safe calls from here on
+				if (::dup2(in[0], STDIN_FILENO) >= 0) {
+					int const null_fd(::open("/dev/null", O_WRONLY));
+					if (null_fd >= 0) { ::dup2(null_fd, STDOUT_FILENO); ::close(null_fd); }
+					char *const argv[] = {const_cast<char *>(command), const_cast<char *>(dst_name), nullptr};
+					::execvp(command, argv);
+				}
+				int const e(errno);
+				(void) !::write(status[1], &e, sizeof(e));
+				::_exit(127);
+			}
+			::close(in[0]);
+			::close(status[1]);
+			m_fd = in[1];
+			int child_errno(0);
+			ssize_t got;
+			do { got = ::read(status[0], &child_errno, sizeof(child_errno)); } while (got < 0 && EINTR == errno);
+			::close(status[0]);
+			if (got > 0) {                                                  // exec failed (main.cc:333-338)
+				::close(m_fd);
+				m_fd = -1;
+				int st;
+				::waitpid(m_pid, &st, 0);
+				throw std::runtime_error(std::string("Unable to execute subprocess. ") + command + ": " + std::strerror(child_errno));
+			}
+		}
+
+		pipe_process(pipe_process const &) = delete;
+		pipe_process &operator=(pipe_process const &) = delete;
+
+		~pipe_process()
+		{
+			if (m_fd >= 0) ::close(m_fd);
+			if (m_pid > 0 && !m_waited) { int st; ::waitpid(m_pid, &st, 0); }
+		}
+
+		int fd() const { return m_fd; }
+
+		// Close the child's standard input and wait for it; anything but exit(0) is an error (main.cc:341-367).
+		void finish()
+		{
+			::close(m_fd);
+			m_fd = -1;
+			int st(0);
+			pid_t r;
+			do { r = ::waitpid(m_pid, &st, 0); } while (r < 0 && EINTR == errno);
+			m_waited = true;
+			if (r == m_pid && WIFEXITED(st) && 0 == WEXITSTATUS(st)) return;
+			std::string msg("Subprocess with PID " + std::to_string(m_pid) + " exited with status ");
+			if (r != m_pid) msg += "0 (exiting reason not known)";
+			else if (WIFSIGNALED(st)) msg += std::to_string(WTERMSIG(st)) + " (terminated by signal)";
+			else if (WIFSTOPPED(st)) msg += std::to_string(WSTOPSIG(st)) + " (stopped by signal)";
+			else msg += std::to_string(WEXITSTATUS(st));
+			throw std::runtime_error(msg);
+		}
+
+	private:
+		[[noreturn]] static void fail_errno(char const *what)
+		{
+			throw std::runtime_error(std::string("Unable to execute subprocess. ") + what + ": " + std::strerror(errno));
+		}
+
+		pid_t m_pid{-1};
+		int m_fd{-1};
+		bool m_waited{};
+	};
+
+
+	// std::ostream over a file descriptor (the reference opens a libbio::file_ostream on the child's stdin handle).
+	class fd_streambuf final : public std::streambuf {
+	public:
+		explicit fd_streambuf(int fd) : m_fd(fd), m_buffer(1u << 20) { setp(m_buffer.data(), m_buffer.data() + m_buffer.size()); }
+		~fd_streambuf() override { sync(); }
+
+	protected:
+		int_type overflow(int_type ch) override
+		{
+			if (!flush_buffer()) return traits_type::eof();
+			if (!traits_type::eq_int_type(ch, traits_type::eof())) { *pptr() = traits_type::to_char_type(ch); pbump(1); }
+			return traits_type::not_eof(ch);
+		}
+
+		std::streamsize xsputn(char const *s, std::streamsize n) override
+		{
+			if (n < std::streamsize(m_buffer.size() / 4)) return std::streambuf::xsputn(s, n);
+			if (!flush_buffer() || !write_all(s, std::size_t(n))) return 0;      // row bodies go straight from the pinned ring
+			return n;
+		}
+
+		int sync() override { return flush_buffer() ? 0 : -1; }
+
+	private:
+		bool flush_buffer()
+		{
+			bool const ok(write_all(pbase(), std::size_t(pptr() - pbase())));
+			setp(m_buffer.data(), m_buffer.data() + m_buffer.size());
+			return ok;
+		}
+
+		bool write_all(char const *p, std::size_t n)
+		{
+			while (n) {
+				ssize_t const w(::write(m_fd, p, n));
+				if (w < 0) { if (EINTR == errno) continue; return false; }   // EPIPE when the child has gone away (SIGPIPE is ignored)
+				p += w;
+				n -= std::size_t(w);
+			}
+			return true;
+		}
+
+		int m_fd;
+		std::vector<char> m_buffer;
+	};
 }
 
 
@@ -52,17 +185,42 @@ namespace {
 		return st.stream->good() ? 0 : 1;
 	}
 
-	struct separate_state { std::vector<std::string> const *names; };
+	struct separate_state { std::vector<std::string> const *names; char const *pipe_cmd; std::exception_ptr error; };
+
+	// output_sequence_file always passes dst_name as the FASTA identifier, whatever should_include_fasta_header says
+	// (output.cc:36,42), and no newline follows the body.
+	void write_sequence_file(std::ostream &os, std::string const &name, char const *bytes, uint64_t length)
+	{
+		os << '>' << name << '\n';
+		os.write(bytes, std::streamsize(length));
+		os.flush();
+	}
 
 	int separate_sink(void *user, uint64_t row, char const *bytes, uint64_t length)
 	{
-		auto const &name((*static_cast<separate_state *>(user)->names)[row]);
+		auto &st(*static_cast<separate_state *>(user));
+		auto const &name((*st.names)[row]);
+		if (st.pipe_cmd) {                                                  // output.cc:26-38
+			try {
+				pipe_process proc(st.pipe_cmd, name.c_str());
+				bool good;
+				{
+					fd_streambuf buf(proc.fd());
+					std::ostream os(&buf);
+					write_sequence_file(os, name, bytes, length);
+					good = os.good();
+				}
+				proc.finish();                                                  // throws if the child did not exit(0)
+				if (!good) throw std::runtime_error("error while writing to the subprocess for " + name);
+			} catch (...) {
+				st.error = std::current_exception();
+				return 1;
+			}
+			return 0;
+		}
 		std::ofstream os(name, std::ios::binary | std::ios::trunc);
 		if (!os) return 1;
-		// output_sequence_file always passes dst_name as the FASTA identifier, whatever
-		// should_include_fasta_header says (output.cc:36,42), and no newline follows the body.
-		os << '>' << name << '\n';
-		os.write(bytes, std::streamsize(length));
+		write_sequence_file(os, name, bytes, length);
 		return os.good() ? 0 : 1;
 	}
 }
@@ -77,8 +235,13 @@ void output::write_a2m(row_set const &rows, std::ostream &stream)
 
 void output::write_separate(row_set const &rows)
 {
-	separate_state st{&rows.ids};
-	splice(rows, separate_sink, &st);
+	separate_state st{&rows.ids, m_pipe_cmd, nullptr};
+	try {
+		splice(rows, separate_sink, &st);
+	} catch (...) {
+		if (st.error) std::rethrow_exception(st.error);                     // what went wrong with the subprocess, not "sink failed"
+		throw;
+	}
 }
 
 
@@ -159,8 +322,26 @@ void output::write_a2m_sharded(row_set const &rows, char const *dst_name)
 }
 
 
-void output::output_a2m(variant_graph const &graph, char const *dst_name)          // output.cc:47-76 without the pipe branch
+void output::output_a2m(variant_graph const &graph, char const *dst_name)          // output.cc:47-76
 {
+	if (m_pipe_cmd) {                                                               // :49-68
+		pipe_process proc(m_pipe_cmd, dst_name);
+		bool good(false);
+		std::exception_ptr error;
+		try {
+			fd_streambuf buf(proc.fd());
+			std::ostream stream(&buf);
+			output_a2m(graph, stream);
+			stream.flush();
+			good = stream.good();
+		} catch (...) {
+			error = std::current_exception();
+		}
+		proc.finish();                                                              // a failed child is the more telling error
+		if (error) std::rethrow_exception(error);
+		if (!good) throw std::runtime_error(std::string("error while writing to the subprocess for ") + dst_name);
+		return;
+	}
 	if (!m_more_gpus.empty() && !m_should_output_unaligned) {
 		write_a2m_sharded(a2m_rows(graph), dst_name);
 		return;

@@ -1,9 +1,10 @@
 // output.hh -- the output classes of the reference (include/vcf2multialign/output.hh:26-130) over the GPU path.
 //
 // Same class names, constructor arguments and row/identifier conventions; output_a2m() batches all rows of a
-// file into one v2m_splice_rows() call instead of calling output_sequence() per row.  --pipe is not supported
-// (pipe_cmd must be null).  founder_sequence_greedy_output takes its cut positions and matchings as input:
-// finding them (find_cut_positions / find_matchings) is a sequential host algorithm outside this round's scope.
+// file into one v2m_splice_rows() call instead of calling output_sequence() per row.  With pipe_cmd the sequences go
+// to the standard input of `pipe_cmd <name>` instead of a file (output.cc:26-38,49-68).
+// founder_sequence_greedy_output takes its cut positions and matchings from founder.hh (find_cut_positions /
+// find_matchings, sequential host algorithms) or from a cut-position file.
 #pragma once
 
 #include <cstdint>
@@ -62,6 +63,7 @@ protected:
 
 	gpu_context &m_gpu;
 	std::vector<gpu_context *> m_more_gpus;
+	char const *m_pipe_cmd{};
 	char const *m_chromosome_id{};
 	output_delegate *m_delegate{};
 	bool m_should_output_reference{};

@@ -48,8 +48,33 @@ def _load():
 		L.v2mh_find_founders.restype = C.c_uint64
 		L.v2mh_find_founders.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]
 		L.v2mh_overlap_get.argtypes = [C.c_void_p, C.c_uint64, _u64p, _u64p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+		L.v2mh_write_cut_positions.restype = C.c_int
+		L.v2mh_write_cut_positions.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.c_size_t]
+		L.v2mh_read_cut_positions.restype = C.c_int
+		L.v2mh_read_cut_positions.argtypes = [C.c_char_p, C.c_void_p, _u64p, _u64p, C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
 		_lib = L
 	return _lib
+
+
+def write_cut_positions(path, cut_positions, min_distance, score):
+	"""--output-cut-positions file (layout: vcf2multialign_amd/csrc/host/founder.hh)."""
+	cuts = np.ascontiguousarray(cut_positions, dtype=np.uint64)
+	err = C.create_string_buffer(512)
+	if 0 != _load().v2mh_write_cut_positions(str(path).encode(), cuts.ctypes.data, len(cuts), min_distance, score, err, len(err)):
+		raise OSError(err.value.decode())
+
+
+def read_cut_positions(path):
+	"""Returns (cut_positions, min_distance, score)."""
+	L = _load()
+	err = C.create_string_buffer(512)
+	n, md, sc = C.c_uint64(0), C.c_uint64(), C.c_uint32()
+	if 0 != L.v2mh_read_cut_positions(str(path).encode(), None, C.byref(n), C.byref(md), C.byref(sc), err, len(err)):
+		raise ValueError(err.value.decode())
+	cuts = np.zeros(max(1, n.value), dtype=np.uint64)
+	if 0 != L.v2mh_read_cut_positions(str(path).encode(), cuts.ctypes.data, C.byref(n), C.byref(md), C.byref(sc), err, len(err)):
+		raise ValueError(err.value.decode())
+	return cuts[:n.value].tolist(), md.value, sc.value
 
 
 def _arr(ptr, n, dtype):
