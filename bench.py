@@ -71,7 +71,7 @@ def main():
 	ap.add_argument("--batch-gb", type=float, default=64.0, help="size of the reused device output buffer when --batch-rows is 0: launches that write a ~64-GB address range reach the full HBM write rate (DESIGN.md section 4)")
 	ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal of N > 1)")
 	ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this HIP device")
-	ap.add_argument("--output-candidates", type=int, default=3, help="device buffers v2m_alloc_output may try for the output (1 = plain allocation)")
+	ap.add_argument("--output-candidates", type=int, default=4, help="device buffers v2m_alloc_output may hold at once to choose the output buffer from (as many as fit are tried; 1 = plain allocation)")
 	ap.add_argument("--cpu-baseline-rows", type=int, default=320, help="haplotypes (plus REF) the CPU oracle is timed on (320 rows of config 3 = 32 Gbases, about 11 s on one core); 0 disables")
 	ap.add_argument("--verify-rows", type=int, default=3, help="rows of the last batch checked against the CPU oracle after timing; 0 disables")
 	args = ap.parse_args()

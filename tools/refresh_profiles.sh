@@ -1,0 +1,23 @@
+#!/bin/bash
+# Re-creates the judged profile set of bench.py's default run (config 3, one GPU) under gpurun_out/refresh/:
+#   bench.json                       plain run
+#   bench_under_rocprof.json         the same command under rocprofv3 --kernel-trace --stats
+#   kernel_stats.csv                 its per-kernel summary
+#   pmc_hbm.json                     HBM bytes per launch from two separate --pmc passes (one step each)
+# Run on the GPU box from the repository root; copy the files into profiles/rNN/ afterwards.
+set -e -o pipefail
+cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+OUT=gpurun_out/refresh
+mkdir -p $OUT
+timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
+echo "bench done"
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
+echo "trace done"
+timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -o w -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline-rows 0 --verify-rows 0 > $OUT/pmc_w.json 2> $OUT/pmc_w.err
+echo "pmc write done"
+timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -o f -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline-rows 0 --verify-rows 0 > $OUT/pmc_f.json 2> $OUT/pmc_f.err
+echo "pmc fetch done"
+python3 tools/pmc_summary.py $OUT/pmc_hbm.json "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE (separate passes, one step of bench.py's default run each; counter unit KiB; hbm_bytes = 1024*(WRITE_SIZE + 2*FETCH_SIZE), the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md). The splice average covers the step's launches plus the same-size calibration launches of the store flavour." WRITE_SIZE=$OUT/pmc_w FETCH_SIZE=$OUT/pmc_f
+rm -rf $OUT/trace $OUT/pmc_w $OUT/pmc_f
+tail -1 $OUT/bench.json | cut -c1-300
