@@ -158,3 +158,43 @@ def test_config3_row_window(env):
 		assert lengths.tolist() == [len(e) for e in exp]
 		usums = ctx.checksum_rows_device(uout.data_ptr(), upitch, len(urows), lengths=lengths)
 		assert np.array_equal(usums, v2m.checksum_rows_host(exp))
+
+
+@pytest.mark.parametrize("config", ["mini5", "mini3"])
+def test_small_configs_all_rows_all_bytes(env, config):
+	"""The variant mix of config 5 (MNPs, multi-allelic sites, indels under deletions) and of config 3 at a size where
+	every row of the synthetic generator's output can be compared byte for byte with the oracle, aligned and unaligned."""
+	torch, v2m, synth = env
+	ds = synth.dataset(config)
+	g = ds.graph
+	L = g.aligned_length
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(g, ds.reference)
+		src, dst = _device_paths(torch, v2m, ds, ctx)
+		ctx.set_paths_device(dst.data_ptr(), ds.path_rows, ds.path_cols)
+		copies = list(range(ds.n_copies))
+		og = _oracle_for(ds, copies)
+		rows = [v2m.PLOIDY_MAX] + copies
+		exp = [og.output_sequence(ds.reference)] + [og.output_sequence(ds.reference, copy_index=c) for c in copies]
+		assert len({len(e) for e in exp}) == 1 and len(exp[0]) == L
+		assert len(set(exp)) > len(exp) // 2                      # the rows really differ
+		pitch = ctx.min_row_pitch
+		out = torch.empty(len(rows) * pitch, dtype=torch.uint8, device="cuda")
+		torch.cuda.synchronize()
+		ctx.splice_rows_device(rows, out.data_ptr(), pitch)
+		host = out.cpu().numpy()
+		for r, e in enumerate(exp):
+			assert host[r * pitch:r * pitch + L].tobytes() == e, "row %d" % r
+		uexp = [og.output_sequence(ds.reference, unaligned=True)] + [og.output_sequence(ds.reference, copy_index=c, unaligned=True) for c in copies]
+		upitch = (ctx.max_unaligned_length + 255) // 256 * 256
+		uout = torch.empty(len(rows) * upitch, dtype=torch.uint8, device="cuda")
+		torch.cuda.synchronize()
+		lengths = ctx.splice_rows_device(rows, uout.data_ptr(), upitch, unaligned=True, want_lengths=True)
+		assert lengths.tolist() == [len(e) for e in uexp]
+		host = uout.cpu().numpy()
+		for r, e in enumerate(uexp):
+			assert host[r * upitch:r * upitch + len(e)].tobytes() == e, "unaligned row %d" % r
+		if config == "mini5":
+			labels = [bytes(g.label_bytes[int(a):int(b)]) for a, b in zip(g.label_offsets[:-1], g.label_offsets[1:])]
+			assert any(len(l) in (2, 3, 4) for l in labels)      # MNPs are in the mix
+			assert (np.diff(g.alt_edge_count_csum.astype(np.int64)) > 1).any()   # and multi-allelic sites
