@@ -873,6 +873,7 @@ __global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
 
 typedef vec4u vec4u_unaligned __attribute__((aligned(1)));   // 16-B access at any byte address (gfx950 / HSA unaligned access mode; tools/unaligned_store_test.hip)
 
+template <bool kNonTemporal>
 __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
 	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
@@ -943,7 +944,11 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			u32 const off = running + before + incl[k] - cnt[k];
 			running += total;
 			if (16 == cnt[k]) {
-				__builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));   // a wave's 64 such stores cover one contiguous KiB at whatever byte phase the row is in
+				// a wave's 64 such stores cover one contiguous KiB at whatever byte phase the row is in
+				// (rounding the address down to 16 B -- wrong output, timing only -- changes nothing: 6.59 vs 6.44 ms per
+				// 256 rows of config 3; the misalignment is not what this kernel is bound by)
+				if (kNonTemporal) __builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));
+				else *(vec4u_unaligned *) (dst + off) = v[k];
 			} else if (cnt[k]) {
 				u32 p = off;
 #pragma unroll
