@@ -283,6 +283,32 @@ def test_founder_rows_many_segments(v2m, ctx, tmp_path, monkeypatch, max_back):
 	assert ctx.splice_rows(rows[:2], unaligned=True) == _oracle_rows(g, rows[:2], unaligned=True)
 
 
+def test_more_rows_than_one_grid_dimension(v2m, ctx):
+	"""70 000 rows in one call (grid.y of the resolve / bit-assembly launches is limited to 65 535 rows, so they are
+	issued in two pieces), plain, REF and founder rows interleaved, aligned and unaligned."""
+	d = os.path.join(HERE, "golden", "reference-fixtures", "founder-sequences")
+	g = oracle.build_variant_graph(os.path.join(d, "test-2.fa"), os.path.join(d, "test-2.vcf"), "1")
+	_upload(v2m, ctx, g)
+	H = g.total_chromosome_copies
+	with open(os.path.join(HERE, "golden", "reference_goldens.json")) as f:
+		import json
+		case = next(c for c in json.load(f)["founder_sequences"] if c["vcf"] == "test-2.vcf")
+	k = case["assigned_samples_rows"]
+	founder = [list(zip(case["cut_positions"][:-1], case["assigned_samples_column_major"][f * k:(f + 1) * k])) for f in range(case["founder_count"])]
+	kinds = [v2m.PLOIDY_MAX] + list(range(H)) + founder
+	exp_kinds = _oracle_rows(g, kinds)
+	uexp_kinds = _oracle_rows(g, kinds, unaligned=True)
+	n = 70000
+	rows = [kinds[i % len(kinds)] for i in range(n)]
+	got = ctx.splice_rows(rows)
+	assert len(got) == n
+	for i in (0, 1, 2, 65534, 65535, 65536, 65537, n - 1):
+		assert got[i] == exp_kinds[i % len(kinds)], "row %d" % i
+	assert all(got[i] == exp_kinds[i % len(kinds)] for i in range(n))
+	ugot = ctx.splice_rows(rows, unaligned=True)
+	assert all(ugot[i] == uexp_kinds[i % len(kinds)] for i in range(n))
+
+
 def test_device_rows_checksums(v2m, ctx, tmp_path):
 	"""Device-resident output + on-device checksums == host checksums of the oracle rows; and the
 	sink path cut into several ring slices gives the same bytes."""
