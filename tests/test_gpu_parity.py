@@ -283,6 +283,57 @@ def test_founder_rows_many_segments(v2m, ctx, tmp_path, monkeypatch, max_back):
 	assert ctx.splice_rows(rows[:2], unaligned=True) == _oracle_rows(g, rows[:2], unaligned=True)
 
 
+@pytest.mark.parametrize("seed", range(96))
+def test_fuzz_small_graphs(v2m, ctx, tmp_path, seed):
+	"""Random small inputs with random shapes (0 .. 3000 records over 100 .. 70 000 bases, 1-5 samples, any variant mix,
+	long indels, multi-allelic sites, genotype or iid path bits): every row, REF, and founder-style rows cut at random
+	bridge nodes, aligned and unaligned, against the oracle."""
+	rng = np.random.default_rng(5000 + seed)
+	ref_len = int(rng.integers(100, 70000))
+	n_var = int(rng.integers(0, max(1, min(ref_len // 3, 3000))))
+	n_samples = int(rng.integers(1, 6))
+	snv = float(rng.random())
+	ins = float(rng.random()) * (1 - snv)
+	kw = dict(mix=(snv, ins, 1 - snv - ins), multi_allelic=float(rng.choice([0.0, 0.1, 0.4])), max_indel=int(rng.choice([4, 32, 200])),
+		long_every=int(rng.choice([0, 0, 7, 30])), ploidy=int(rng.choice([1, 2, 2, 3])))
+	density = rng.choice([-1.0, 0.5, 0.05])
+	if density > 0:
+		kw["density"] = float(density)
+	if n_var == 0:
+		ref = synth.random_reference(rng, ref_len)
+		fa, vcf = synth.write_inputs(str(tmp_path), ref, [], n_samples)
+		g = oracle.build_variant_graph(fa, vcf, "1")
+	else:
+		g = synth.build_case(tmp_path, 6000 + seed, ref_len, n_var, n_samples, **kw)
+		if seed % 2:
+			g = synth.with_random_paths(g, seed, float(rng.choice([0.02, 0.3, 0.8])))
+	_upload(v2m, ctx, g)
+	H = g.total_chromosome_copies
+	rows = [v2m.PLOIDY_MAX] + list(range(H))
+	reach, bridges = 0, []
+	for n in range(g.node_count - 1):
+		if n >= reach and n > 0:
+			bridges.append(n)
+		for e in range(int(g.alt_edge_count_csum[n]), int(g.alt_edge_count_csum[n + 1])):
+			reach = max(reach, int(g.alt_edge_targets[e]))
+	if bridges and H:
+		for _ in range(3):
+			k = int(rng.integers(1, min(len(bridges), 400) + 1))
+			cuts = sorted(int(x) for x in rng.choice(bridges, size=k, replace=False))
+			if rng.random() < 0.7:
+				cuts = [0] + cuts
+			copies = [int(x) if rng.random() > 0.05 else v2m.PLOIDY_MAX for x in rng.integers(0, H, size=len(cuts))]
+			rows.append(list(zip(cuts, copies)))
+	order = rng.permutation(len(rows))
+	rows = [rows[i] for i in order]
+	got = ctx.splice_rows(rows)
+	for i, (a, b) in enumerate(zip(got, _oracle_rows(g, rows))):
+		assert a == b, "seed %d row %d (%r)" % (seed, i, rows[i] if not isinstance(rows[i], list) else "cuts")
+	got = ctx.splice_rows(rows, unaligned=True)
+	for i, (a, b) in enumerate(zip(got, _oracle_rows(g, rows, unaligned=True))):
+		assert a == b, "seed %d unaligned row %d" % (seed, i)
+
+
 def test_more_rows_than_one_grid_dimension(v2m, ctx):
 	"""70 000 rows in one call (grid.y of the resolve / bit-assembly launches is limited to 65 535 rows, so they are
 	issued in two pieces), plain, REF and founder rows interleaved, aligned and unaligned."""
