@@ -10,8 +10,8 @@ before the timed region starts; nothing is copied to the host inside it.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Haplotypes shard across ranks in blocks of 64 chromosome copies with the reference and graph
-replicated; there is no collective on the data path.  The total work is the
+Haplotypes shard across ranks in blocks of 8 chromosome copies (whole bytes of the bit-packed path matrix) with the
+reference and graph replicated; there is no collective on the data path.  The total work is the
 named config's and is fixed as N grows, hence "scaling": "strong".
 
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
@@ -148,7 +148,7 @@ def main():
 	paths_dst = torch.empty(max(words, 1), dtype=torch.int64, device=dev)   # paths_by_chrom_copy_and_edge (Ep x this rank's copies)
 	torch.cuda.synchronize()
 	if hp_local:
-		ds.fill_paths_device(ctx.stream, paths_src.data_ptr(), thr.data_ptr(), copy_base=c0, n_rows=hp_local, n_cols=Ep)
+		ds.fill_paths_device(ctx.stream, paths_src.data_ptr(), thr.data_ptr(), copy_base=c0, n_rows=hp_local, n_cols=Ep, copy_end=c1)
 	ctx.synchronize()
 
 	batches = [v2m.RowBatch(rows[i:i + batch_rows]) for i in range(0, n_rows, batch_rows)]
@@ -229,7 +229,7 @@ def main():
 			"workload": "%s: synthetic %d bp reference, %d variant records (%d ALT edges), %d diploid samples = %d haplotype rows + REF, --haplotypes aligned A2M, L=%d"
 				% (args.config, R, ds.n_variants, E, ds.samples, H, L),
 			"rows_total": total_rows, "aligned_length": L, "batch_rows": batch_rows,
-			"sharding": "chromosome copies in blocks of 64 per rank, graph + reference replicated, no collective",
+			"sharding": "contiguous chromosome copies per rank (multiples of 8), graph + reference replicated, no collective",
 			"tuning": ctx.info,
 		},
 		"roofline": {

@@ -94,13 +94,15 @@ def test_sharding_covers_all_rows_in_order(n_copies, world):
 	seen = []
 	for r in range(world):
 		c0, c1, hp = shard_copies(n_copies, world, r)
-		assert c0 % 64 == 0 or c0 == n_copies
-		assert hp % 64 == 0 and c1 - c0 <= hp
+		assert c0 % 8 == 0 or c0 == n_copies                   # whole bytes of the bit-packed source matrix
+		assert hp % 64 == 0 and c1 - c0 <= hp < c1 - c0 + 64
 		rows = local_rows(n_copies, world, r)
 		for gi, lc in rows:
 			assert lc == PLOIDY_MAX or 0 <= lc < hp
 		seen.extend(gi for gi, _ in rows)
 	assert seen == list(range(n_copies + 1))
+	sizes = [len(local_rows(n_copies, world, r)) for r in range(world)]
+	assert max(sizes) - min(sizes) <= 8                         # REF sits on rank 0, which gets no left-over block
 
 
 def _free_port():
@@ -144,4 +146,4 @@ def test_two_rank_gloo_partition():
 	for rank, t, gathered in results:
 		assert t == 2.0
 		assert gathered[0] + gathered[1] == list(range(301))
-		assert gathered[0][-1] == 192 and gathered[1][0] == 193   # rank 0: REF + copies 0..191 (3 words), rank 1: copies 192..299
+		assert gathered[0][-1] == 152 and gathered[1][0] == 153   # rank 0: REF + copies 0..151 (19 bytes of every column), rank 1: copies 152..299

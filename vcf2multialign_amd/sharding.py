@@ -1,19 +1,26 @@
 """Multi-GPU partition of the splice path: chromosome copies shard across ranks in contiguous blocks of whole
-64-copy words (so the bit-packed path matrix splits on word boundaries), graph and reference are replicated,
-rows stay in file order when the ranks' outputs are concatenated.  No collective is needed on the data path
+bytes of the bit-packed path matrix (8 copies: a rank's slice of paths_by_edge_and_chrom_copy is then a strided 2-D
+byte copy, bytes [c0/8, c1/8) of every column, zero-padded to a multiple of 64 rows for the transpose), graph and
+reference are replicated, rows stay in file order when the ranks' outputs are concatenated.  No collective is needed on the data path
 (rows are independent, haplotype_output.cc:62-81); torch.distributed is used only for barriers and for the
 max-over-ranks of timings."""
 
 PLOIDY_MAX = 0xFFFFFFFF
 
 
+COPY_GRANULE = 8
+
+
 def shard_copies(n_copies, world, rank):
-	"""Returns (first copy, end copy, padded local copy count) of `rank`."""
-	n_words = (n_copies + 63) // 64
-	base, extra = divmod(n_words, world)
-	w0 = rank * base + min(rank, extra)
-	w1 = w0 + base + (1 if rank < extra else 0)
-	return min(n_copies, 64 * w0), min(n_copies, 64 * w1), 64 * (w1 - w0)
+	"""Returns (first copy, end copy, padded local copy count) of `rank`.  Blocks that do not divide evenly go to the
+	last ranks: rank 0 also carries the REF row."""
+	n_blocks = (n_copies + COPY_GRANULE - 1) // COPY_GRANULE
+	base, extra = divmod(n_blocks, world)
+	first_heavy = world - extra
+	b0 = rank * base + max(0, rank - first_heavy)
+	b1 = b0 + base + (1 if rank >= first_heavy else 0)
+	c0, c1 = min(n_copies, COPY_GRANULE * b0), min(n_copies, COPY_GRANULE * b1)
+	return c0, c1, 64 * ((c1 - c0 + 63) // 64)
 
 
 def local_rows(n_copies, world, rank, include_reference=True):

@@ -107,12 +107,14 @@ class Dataset:
 		except Exception:
 			pass
 
-	def fill_paths_device(self, stream, d_words, d_thresholds, copy_base=0, n_rows=None, n_cols=None):
+	def fill_paths_device(self, stream, d_words, d_thresholds, copy_base=0, n_rows=None, n_cols=None, copy_end=None):
 		"""Fills paths_by_edge_and_chrom_copy in HBM: rows = the chromosome copies [copy_base, copy_base + n_rows)
-		(n_rows a multiple of 64, default all Hp), cols = n_cols edges (default Ep; columns past the last edge are zero)."""
+		(n_rows a multiple of 64, default all Hp), cols = n_cols edges (default Ep; columns past the last edge are zero).
+		Rows of copies >= copy_end (default: the number of copies) are zero: a rank's padding."""
 		n_rows = self.path_cols if n_rows is None else n_rows
 		n_cols = self.path_rows if n_cols is None else n_cols
-		rc = _load().v2ms_fill_paths_device(stream, d_words, n_rows, n_cols, copy_base, self.n_copies, self.graph.edge_count, d_thresholds, self.seed)
+		copy_end = self.n_copies if copy_end is None else min(copy_end, self.n_copies)
+		rc = _load().v2ms_fill_paths_device(stream, d_words, n_rows, n_cols, copy_base, copy_end, self.graph.edge_count, d_thresholds, self.seed)
 		if rc != 0:
 			raise RuntimeError("fill_paths_kernel launch failed (%d)" % rc)
 
