@@ -46,7 +46,9 @@ def test_minimum_distance_and_founder_count_are_honoured(HostGraph, fixtures_dir
 
 
 # The host's pBWT skips work the reference does literally (divergence counts touched only on a change, 32-bit biased
-# divergence values, a flat count table); the oracle's restatement makes every update.  Same answers on random inputs.
+# divergence values, a flat count table) and, with more than one thread, rebuilds the pBWT state from scratch at chunk
+# boundaries instead of stepping to it; the oracle's restatement makes every update of the reference.  Same answers on
+# random inputs.
 @pytest.mark.parametrize("seed,ref_len,n_variants,n_samples,kw", [
 	(1, 3000, 120, 6, dict()),
 	(2, 5000, 400, 9, dict(multi_allelic=0.3)),
@@ -68,8 +70,12 @@ def test_random_inputs_against_the_literal_restatement(HostGraph, tmp_path, seed
 	og = oracle.build_variant_graph(fa, vcf, "1")
 	hg = HostGraph(fa, vcf, "1")
 	assert og.edge_count > 0
+	# the transpose's result, for the chunked (multi-threaded) matching: here from the oracle, in the product from the GPU
+	hg.set_transposed_paths(og.paths_by_chrom_copy_and_edge, og.path_rows, og.path_cols)
 	for founders, min_distance, keep in ((1, 0, False), (2, 0, False), (3, 10, True), (7, 50, False), (25, 50, False), (4, 1000, True), (5, 10 * ref_len, False)):
-		assert hg.find_founders(founders, min_distance, keep_ref_edges=keep) == og.find_founders(founders, min_distance, keep_ref_edges=keep), (founders, min_distance, keep)
+		exp = og.find_founders(founders, min_distance, keep_ref_edges=keep)
+		for threads in (1, 2, 7):
+			assert hg.find_founders(founders, min_distance, keep_ref_edges=keep, threads=threads) == exp, (founders, min_distance, keep, threads)
 
 
 def test_cut_position_file_round_trip(HostGraph, tmp_path):

@@ -29,14 +29,18 @@ print("%s: %d nodes, %d edges, %d copies; GPU transpose %.3f ms" % (cfg, g.node_
 
 t = time.time()
 hg = HostGraph.from_arrays(g, src.cpu().numpy().view(np.uint64), hp, ep, ds.samples, ds.ploidy)
-print("host graph (D2H of the %d MB matrix + copy): %.1f s" % (src.numel() * 8 >> 20, time.time() - t), flush=True)
+hg.set_transposed_paths(dst.cpu().numpy().view(np.uint64), ep, hp)     # the GPU transpose's result: lets the search run on several threads
+print("host graph (D2H of the two %d MB matrices + copy): %.1f s" % (src.numel() * 8 >> 20, time.time() - t), flush=True)
+threads = int(os.environ.get("V2M_FOUNDER_THREADS", "0"))
 t = time.time()
-res = hg.find_founders(founders, min_dist, keep_ref_edges=False)
+res = hg.find_founders(founders, min_dist, keep_ref_edges=False, threads=threads)
 t_host = time.time() - t
 assert res is not None
 cuts, assigned, score = res
 rows_per_col = len(cuts) - 1
-print("find_cut_positions + find_matchings on the host (1 thread): %.1f s; %d cut positions, maximum segmentation height %d" % (t_host, len(cuts), 1 + score), flush=True)
+import zlib
+print("crc32 of the cut positions / assigned samples: %08x / %08x" % (zlib.crc32(np.asarray(cuts, dtype=np.uint64).tobytes()), zlib.crc32(np.asarray(assigned, dtype=np.uint32).tobytes())), flush=True)
+print("find_cut_positions + find_matchings on the host (%s): %.1f s; %d cut positions, maximum segmentation height %d" % ("1 thread" if threads == 1 else "up to 16 threads" if threads == 0 else "%d threads" % threads, t_host, len(cuts), 1 + score), flush=True)
 
 batch_rows = [v2m.PLOIDY_MAX] + [list(zip(cuts[:-1], assigned[f * rows_per_col:(f + 1) * rows_per_col])) for f in range(founders)]
 pitch = ctx.min_row_pitch

@@ -1,6 +1,11 @@
 #include "founder.hh"
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <exception>
+#include <thread>
 #include <cstring>
 #include <fstream>
 #include <map>
@@ -119,6 +124,9 @@ public:
 		m_prev_divergence.resize(copies);
 	}
 
+	// From now on keep `counts` in step with the divergence values (it must already describe them).
+	void follow(divergence_counts *counts) { m_counts = counts; }
+
 	// One step of Durbin's algorithm 2 for edge `edge` whose usage bits are `column` (pbwt.hh:77-134).
 	void advance(u64 const *column, u64 column_words, u64 edge)
 	{
@@ -209,7 +217,27 @@ inline u64 const *edge_column(variant_graph const &g, u64 edge)
 } // namespace
 
 
-u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &out)
+namespace {
+
+// Walks the predecessor links back from the last candidate (find_cut_positions.cc:182-209).
+u32 collect_cut_positions(std::vector<cut_candidate> const &cuts, variant_graph const &graph, std::vector<u64> &out)
+{
+	if (cuts.size() <= 1) return kCutPositionScoreMax;                        // :182-183
+	auto const by_edge([](cut_candidate const &c, u64 e) { return c.edge < e; });
+	auto it(cuts.cend() - 1);
+	u32 const score(it->score);
+	for (;;) {
+		out.push_back(it->node);
+		if (kEdgeMax == it->prev_edge) break;
+		it = std::lower_bound(cuts.cbegin(), it, it->prev_edge, by_edge);
+	}
+	if (0 != out.back()) out.push_back(0);
+	std::reverse(out.begin(), out.end());
+	if (out.back() != graph.node_count() - 1) out.back() = graph.node_count() - 1;   // the sink usually has no ALT in-edges
+	return score;
+}
+
+u32 find_cut_positions_sequential(variant_graph const &graph, u64 min_distance, std::vector<u64> &out)
 {
 	out.clear();
 	u32 const copies(graph.total_chromosome_copies());
@@ -259,21 +287,10 @@ u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector
 		}
 	}
 
-	if (cuts.size() <= 1) return kCutPositionScoreMax;                        // :182-183
-
-	// walk the predecessor links back from the last candidate (:185-209)
-	auto it(cuts.cend() - 1);
-	u32 const score(it->score);
-	for (;;) {
-		out.push_back(it->node);
-		if (kEdgeMax == it->prev_edge) break;
-		it = std::lower_bound(cuts.cbegin(), it, it->prev_edge, by_edge);
-	}
-	if (0 != out.back()) out.push_back(0);
-	std::reverse(out.begin(), out.end());
-	if (out.back() != graph.node_count() - 1) out.back() = graph.node_count() - 1;   // the sink usually has no ALT in-edges
-	return score;
+	return collect_cut_positions(cuts, graph, out);
 }
+
+} // namespace
 
 
 namespace {
@@ -386,7 +403,9 @@ struct matcher {
 } // namespace
 
 
-bool find_matchings(
+namespace {
+
+bool find_matchings_sequential(
 	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
 	std::vector<u32> &assigned)
 {
@@ -469,6 +488,395 @@ bool find_matchings(
 			assigned[founder * rows + 0] = c->rhs_rep;
 	}
 	return true;
+}
+
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same matching with the expensive part -- the pBWT over all edges and the path classes at every cut -- spread over
+// threads.  What makes that possible: the pBWT state after the first k edges does not have to be reached step by
+// step.  The order is the copies sorted by their reversed k-edge prefixes (read as a k-bit integer with edge k - 1 as the
+// most significant bit; ties keep the copy order), and a copy's divergence value is one past the highest edge on which
+// it differs from its predecessor in that order (0 if they agree everywhere, k for the first copy) -- exactly what k
+// steps of pbwt.hh:77-134 leave behind.  Both are read off paths_by_chrom_copy_and_edge, where a copy's prefix is a run
+// of words.  A chunk of consecutive cuts therefore starts from a state built from scratch, walks its own edges and
+// leaves one record per cut; the greedy assignment itself (cheap, strictly sequential) then consumes the records in
+// cut order.
+// ---------------------------------------------------------------------------------------------------------------------
+void pbwt_state_at(variant_graph const &graph, u64 k, edge_pbwt &pbwt)
+{
+	if (0 == k) return;                                                       // the constructor's state
+	auto const &m(graph.paths_by_chrom_copy_and_edge);                        // rows = edges, cols = copies
+	u64 const wpc(m.words_per_column());
+	u64 const top((k - 1) >> 6);
+	u64 const top_mask((k & 63) ? (u64(1) << (k & 63)) - 1 : ~u64(0));
+	u64 const *const words(m.words.data());
+	u32 const n(u32(pbwt.order.size()));
+	auto const prefix_word([&](u32 copy, u64 w) { u64 const x(words[copy * wpc + w]); return w == top ? x & top_mask : x; });
+
+	std::iota(pbwt.order.begin(), pbwt.order.end(), 0u);
+	std::stable_sort(pbwt.order.begin(), pbwt.order.end(), [&](u32 a, u32 b) {
+		for (u64 w(top + 1); w-- > 0;) {
+			u64 const x(prefix_word(a, w)), y(prefix_word(b, w));
+			if (x != y) return x < y;
+		}
+		return false;
+	});
+	pbwt.divergence[0] = u32(k) + 1;                                          // biased k
+	for (u32 i(1); i < n; ++i) {
+		u32 const a(pbwt.order[i - 1]), b(pbwt.order[i]);
+		u32 d(1);                                                             // biased 0: the two agree on every edge so far
+		for (u64 w(top + 1); w-- > 0;) {
+			u64 const diff(prefix_word(a, w) ^ prefix_word(b, w));
+			if (diff) { d = u32(64 * w + 63 - u64(__builtin_clzll(diff))) + 2; break; }   // one past the edge, biased
+		}
+		pbwt.divergence[i] = d;
+	}
+}
+
+
+// What the sequential loop knows at one cut position (founder_sequence_greedy_output.cc:208-264), minus the assignment.
+struct cut_record {
+	std::size_t joined_begin, joined_end;   // into the chunk's pool; sorted by size
+	u32 rhs_distinct;
+	u32 rhs_first_class;
+	bool rhs_first_is_ref;                  // over the edges since the previous cut
+};
+
+struct cut_chunk {
+	std::size_t first_cut{}, end_cut{};     // cut indices [first_cut, end_cut), first_cut >= 1
+	std::vector<joined_class> pool;
+	std::vector<cut_record> records;
+};
+
+void scan_cut_chunk(variant_graph const &graph, std::vector<u64> const &cut_positions, cut_chunk &chunk)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	auto const &paths(graph.paths_by_edge_and_chrom_copy);
+	u64 const words_per_column(paths.words_per_column());
+	auto const edge_at([&](std::size_t cut) { return graph.alt_edge_count_csum[cut_positions[cut]]; });   // edges before the cut node
+
+	edge_pbwt pbwt(copies, nullptr);
+	std::vector<u32> lhs_class(copies, kPloidyMax), rhs_class(copies, kPloidyMax);
+	std::size_t const start_cut(chunk.first_cut - 1);
+	u64 edge(edge_at(start_cut));
+	pbwt_state_at(graph, edge, pbwt);
+	if (start_cut >= 1) {                                                     // the classes the previous cut left behind
+		u64 const threshold(edge_at(start_cut - 1));
+		u32 rep(kPloidyMax);
+		for (u32 i(0); i < copies; ++i) {
+			if (threshold < unbiased(pbwt.divergence[i])) rep = pbwt.order[i];
+			rhs_class[pbwt.order[i]] = rep;
+		}
+	}
+
+	bool rhs_first_is_ref(true);
+	std::size_t next_cut(chunk.first_cut);
+	u64 const last_node(cut_positions[chunk.end_cut - 1]);
+	for (u64 node(cut_positions[start_cut]); node <= last_node; ++node) {
+		if (next_cut < chunk.end_cut && node == cut_positions[next_cut]) {
+			u64 const prev_cut_edge(edge_at(next_cut - 1));
+			u64 const cut_pair_edge(next_cut >= 2 ? edge_at(next_cut - 2) : 0);
+			lhs_class.swap(rhs_class);
+			cut_record rec{chunk.pool.size(), 0, 0, pbwt.order.front(), rhs_first_is_ref};
+			u32 rep(kPloidyMax);
+			for (u32 i(0); i < copies; ++i) {
+				u32 const copy(pbwt.order[i]);
+				u64 const d(unbiased(pbwt.divergence[i]));
+				if (prev_cut_edge < d) { rep = copy; ++rec.rhs_distinct; }
+				rhs_class[copy] = rep;
+				if (next_cut >= 2) {
+					if (cut_pair_edge < d) chunk.pool.push_back({lhs_class[copy], rep, 0});
+					++chunk.pool.back().size;
+				}
+			}
+			rec.joined_end = chunk.pool.size();
+			std::sort(chunk.pool.begin() + std::ptrdiff_t(rec.joined_begin), chunk.pool.end());   // :256; same input order as the sequential loop
+			chunk.records.push_back(rec);
+			++next_cut;
+			rhs_first_is_ref = true;
+			if (node == last_node) break;
+		}
+		for (u64 e(graph.alt_edge_count_csum[node]); e < graph.alt_edge_count_csum[node + 1]; ++e) {
+			pbwt.advance(edge_column(graph, edge), words_per_column, edge);
+			rhs_first_is_ref = rhs_first_is_ref && !paths.test(pbwt.order.front(), edge);
+			++edge;
+		}
+	}
+}
+
+
+bool find_matchings_chunked(
+	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
+	std::vector<u32> &assigned, unsigned threads)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	std::size_t const n_cuts(cut_positions.size());
+	std::size_t const rows(n_cuts - 1);
+	assigned.assign(rows * founder_count, kPloidyMax);
+	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}};
+
+	// chunks of consecutive cuts with about the same number of edges each, several per thread
+	std::size_t const wanted(std::min<std::size_t>(std::size_t(threads) * 4, n_cuts - 1));
+	u64 const n_edges(graph.edge_count());
+	std::vector<cut_chunk> chunks;
+	{
+		std::size_t k(1);
+		for (std::size_t j(1); j <= wanted && k < n_cuts; ++j) {
+			u64 const edge_goal(j == wanted ? n_edges + 1 : n_edges * j / wanted);
+			std::size_t end(k + 1);
+			while (end < n_cuts && graph.alt_edge_count_csum[cut_positions[end]] < edge_goal) ++end;
+			if (j == wanted) end = n_cuts;
+			chunks.emplace_back();
+			chunks.back().first_cut = k;
+			chunks.back().end_cut = end;
+			k = end;
+		}
+	}
+
+	std::atomic<std::size_t> next_chunk(0);
+	std::vector<std::exception_ptr> errors(threads);
+	auto const work([&](unsigned tid) {
+		try {
+			for (std::size_t c; (c = next_chunk.fetch_add(1)) < chunks.size();) scan_cut_chunk(graph, cut_positions, chunks[c]);
+		} catch (...) {
+			errors[tid] = std::current_exception();
+		}
+	});
+	std::vector<std::thread> pool;
+	for (unsigned tid(1); tid < threads; ++tid) pool.emplace_back(work, tid);
+	work(0);
+	for (auto &t : pool) t.join();
+	for (auto const &e : errors) if (e) std::rethrow_exception(e);
+
+	// the assignment, in cut order (founder_sequence_greedy_output.cc:254-457)
+	u32 lhs_distinct(0), rhs_distinct(0), lhs_first_class(0), rhs_first_class(0);
+	bool lhs_first_is_ref(true);
+	std::vector<joined_class> joined;
+	std::size_t cuts_seen(0);
+	for (auto const &chunk : chunks) {
+		for (auto const &rec : chunk.records) {
+			lhs_distinct = rhs_distinct;
+			lhs_first_class = rhs_first_class;
+			rhs_distinct = rec.rhs_distinct;
+			rhs_first_class = rec.rhs_first_class;
+			if (cuts_seen) {
+				joined.assign(chunk.pool.begin() + std::ptrdiff_t(rec.joined_begin), chunk.pool.begin() + std::ptrdiff_t(rec.joined_end));
+				if (!keep_ref_edges && lhs_first_is_ref && rec.rhs_first_is_ref)      // :258-264
+					std::erase_if(joined, [&](joined_class const &c) { return c.lhs_rep == lhs_first_class && c.rhs_rep == rhs_first_class; });
+				if (1 == cuts_seen) m.seed(joined, lhs_distinct);
+				m.extend(cuts_seen, joined, rhs_distinct);
+			}
+			++cuts_seen;
+			lhs_first_is_ref = rec.rhs_first_is_ref;
+		}
+	}
+	return true;
+}
+
+} // namespace
+
+
+bool find_matchings(
+	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
+	std::vector<u32> &assigned, unsigned threads)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	if (cut_positions.size() < 2 || 0 == copies) return false;               // :163-167
+	if (0 == threads) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	auto const &transposed(graph.paths_by_chrom_copy_and_edge);
+	bool const have_transposed(transposed.cols >= copies && transposed.rows >= graph.edge_count() && !transposed.words.empty());
+	// a single block (two cut positions) takes the reference's separate path (:475-508); so does a search without the
+	// copy-major matrix, or on one thread
+	if (threads <= 1 || cut_positions.size() <= 2 || !have_transposed)
+		return find_matchings_sequential(graph, cut_positions, founder_count, keep_ref_edges, assigned);
+	return find_matchings_chunked(graph, cut_positions, founder_count, keep_ref_edges, assigned, threads);
+}
+
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The cut search over threads.  Which nodes are candidates, and which earlier candidate a divergence value points to,
+// depend on the graph alone; the scores do not, but they are cheap.  So the edges are cut into chunks; a worker builds
+// the pBWT state at the start of its chunk from scratch (pbwt_state_at), walks its edges and, at every candidate node,
+// writes down the (earlier candidate, class count) pairs the reference would try, in its order; the calling thread
+// consumes the chunks in order and does nothing but the score updates (find_cut_positions.cc:55-63).  At most
+// `window` finished chunks wait for it at any time.
+// ---------------------------------------------------------------------------------------------------------------------
+struct cut_trial { u32 pred; u32 class_count; };
+
+struct cut_search_chunk {
+	std::size_t first{}, end{};            // candidates [first, end), indices into the candidate list (>= 1)
+	std::vector<cut_trial> trials;
+	std::vector<std::size_t> trial_end;    // per candidate
+};
+
+void scan_cut_search_chunk(
+	variant_graph const &graph, u64 min_distance, std::vector<cut_candidate> const &cuts, std::vector<u32> const &first_candidate_from_edge,
+	cut_search_chunk &chunk)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	u64 const words_per_column(graph.paths_by_edge_and_chrom_copy.words_per_column());
+	u64 const n_edges(graph.edge_count());
+	divergence_counts counts(n_edges + 2);
+	edge_pbwt pbwt(copies, nullptr);
+	u64 edge(cuts[chunk.first].edge);
+	pbwt_state_at(graph, edge, pbwt);
+	if (0 == edge) { counts.add(1, 1); if (copies > 1) counts.add(0, copies - 1); }   // the initial state (pbwt.hh:62-70)
+	else for (u32 const d : pbwt.divergence) counts.add(d, 1);
+	pbwt.follow(&counts);
+
+	std::size_t next(chunk.first);
+	u64 const last_node(cuts[chunk.end - 1].node);
+	for (u64 node(cuts[chunk.first].node); node <= last_node; ++node) {
+		if (next < chunk.end && node == cuts[next].node) {
+			std::size_t right_bound(next + 1);                                 // the candidate itself is already in the list (:129,135)
+			u32 value(counts.largest());
+			u32 class_count(counts[value]);
+			for (value = counts.below(value); kNoValue != value; value = counts.below(value)) {
+				u64 const v(unbiased(value));
+				std::size_t const pred(v <= n_edges ? std::min<std::size_t>(first_candidate_from_edge[v], right_bound) : right_bound);
+				if (pred != right_bound) {
+					right_bound = pred;
+					// (trying the candidate itself never changes anything: its score is the number of copies)
+					if (pred != next && min_distance <= graph.aligned_positions[node] - graph.aligned_positions[cuts[pred].node])
+						chunk.trials.push_back({u32(pred), class_count});
+				}
+				class_count += counts[value];
+			}
+			if (0 != right_bound && right_bound - 1 != next) chunk.trials.push_back({u32(right_bound - 1), class_count});
+			chunk.trial_end.push_back(chunk.trials.size());
+			++next;
+			if (node == last_node) break;
+		}
+		for (u64 e(graph.alt_edge_count_csum[node]); e < graph.alt_edge_count_csum[node + 1]; ++e) {
+			pbwt.advance(edge_column(graph, edge), words_per_column, edge);
+			++edge;
+		}
+	}
+}
+
+u32 find_cut_positions_chunked(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads)
+{
+	out.clear();
+	u32 const copies(graph.total_chromosome_copies());
+	u64 const n_edges(graph.edge_count());
+	check_edge_range(graph);
+
+	// the candidates: bridge nodes, one per distinct edge index (find_cut_positions.cc:111-112,126-131)
+	std::vector<cut_candidate> cuts;
+	cuts.push_back({0, kEdgeMax, 0, 0});
+	{
+		u64 rightmost_target(0), edge(0), last_cut_edge(kEdgeMax);
+		for (u64 node(0); node < graph.node_count(); ++node) {
+			if (rightmost_target <= node && last_cut_edge != edge) {
+				cuts.push_back({edge, kEdgeMax, node, copies});
+				last_cut_edge = edge;
+			}
+			for (u64 e(graph.alt_edge_count_csum[node]); e < graph.alt_edge_count_csum[node + 1]; ++e, ++edge)
+				rightmost_target = std::max(rightmost_target, graph.alt_edge_targets[e]);
+		}
+	}
+	if (cuts.size() >= u64(UINT32_MAX)) throw std::length_error("founder search: candidate indices are kept in 32 bits");
+	// first candidate whose edge index is >= e (what std::lower_bound over the whole list returns)
+	std::vector<u32> first_candidate_from_edge(n_edges + 1);
+	{
+		std::size_t c(0);
+		for (u64 e(0); e <= n_edges; ++e) {
+			while (c < cuts.size() && cuts[c].edge < e) ++c;
+			first_candidate_from_edge[e] = u32(c);
+		}
+	}
+
+	// chunks of candidates with about the same number of edges each
+	std::size_t const n_cand(cuts.size());
+	std::size_t const wanted(std::min<std::size_t>(std::max<std::size_t>(std::size_t(threads) * 8, std::size_t(n_edges / 8192) + 1), n_cand - 1));
+	std::vector<cut_search_chunk> chunks;
+	for (std::size_t j(1), k(1); j <= wanted && k < n_cand; ++j) {
+		u64 const edge_goal(n_edges * j / wanted);
+		std::size_t end(k + 1);
+		while (end < n_cand && cuts[end].edge < edge_goal) ++end;
+		if (j == wanted) end = n_cand;
+		chunks.emplace_back();
+		chunks.back().first = k;
+		chunks.back().end = end;
+		k = end;
+	}
+
+	std::mutex mutex;
+	std::condition_variable changed;
+	std::size_t next_claim(0), consumed(0);
+	std::size_t const window(std::size_t(threads) * 2 + 2);
+	std::vector<char> done(chunks.size(), 0);
+	std::exception_ptr error;
+	auto const work([&] {
+		for (;;) {
+			std::size_t c;
+			{
+				std::unique_lock<std::mutex> lock(mutex);
+				changed.wait(lock, [&] { return error || next_claim >= chunks.size() || next_claim < consumed + window; });
+				if (error || next_claim >= chunks.size()) return;
+				c = next_claim++;
+			}
+			try {
+				scan_cut_search_chunk(graph, min_distance, cuts, first_candidate_from_edge, chunks[c]);
+			} catch (...) {
+				std::lock_guard<std::mutex> lock(mutex);
+				if (!error) error = std::current_exception();
+			}
+			{
+				std::lock_guard<std::mutex> lock(mutex);
+				done[c] = 1;
+			}
+			changed.notify_all();
+		}
+	});
+	std::vector<std::thread> pool;
+	for (unsigned t(0); t < threads; ++t) pool.emplace_back(work);
+	for (std::size_t c(0); c < chunks.size(); ++c) {
+		{
+			std::unique_lock<std::mutex> lock(mutex);
+			changed.wait(lock, [&] { return error || done[c]; });
+			if (error) break;
+		}
+		auto &chunk(chunks[c]);
+		std::size_t t(0);
+		for (std::size_t j(chunk.first); j < chunk.end; ++j) {
+			cut_candidate &current(cuts[j]);
+			for (std::size_t const t_end(chunk.trial_end[j - chunk.first]); t < t_end; ++t)
+				current.improve(chunk.trials[t].class_count, cuts[chunk.trials[t].pred]);
+		}
+		std::vector<cut_trial>().swap(chunk.trials);
+		std::vector<std::size_t>().swap(chunk.trial_end);
+		{
+			std::lock_guard<std::mutex> lock(mutex);
+			consumed = c + 1;
+		}
+		changed.notify_all();
+	}
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		if (error) next_claim = chunks.size();
+	}
+	changed.notify_all();
+	for (auto &t : pool) t.join();
+	if (error) std::rethrow_exception(error);
+	return collect_cut_positions(cuts, graph, out);
+}
+
+} // namespace
+
+
+u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	if (0 == threads) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	auto const &transposed(graph.paths_by_chrom_copy_and_edge);
+	bool const have_transposed(transposed.cols >= copies && transposed.rows >= graph.edge_count() && !transposed.words.empty());
+	if (threads <= 1 || 0 == copies || 0 == graph.edge_count() || !have_transposed)
+		return find_cut_positions_sequential(graph, min_distance, out);
+	return find_cut_positions_chunked(graph, min_distance, out, threads);
 }
 
 

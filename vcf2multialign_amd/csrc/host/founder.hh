@@ -1,9 +1,10 @@
 // founder.hh -- host side of --founder-sequences: where to cut the graph and which chromosome copy each
 // founder follows between consecutive cuts.
 //
-// Both are strictly sequential over the ALT edges (a positional BWT with divergence counts; every step
-// depends on the previous one), which is why they stay on the host.  They
-// restate the reference's find_initial_cut_positions_lambda_min (libvcf2multialign/find_cut_positions.cc:93-211),
+// Both walk a positional BWT with divergence counts over the ALT edges, every step depending on the previous
+// one, which is why they stay on the host -- but the state after any number of
+// edges can also be built from scratch from the transposed path matrix, so the walk is cut into chunks that run on
+// several threads (founder.cc: pbwt_state_at).  They restate the reference's find_initial_cut_positions_lambda_min (libvcf2multialign/find_cut_positions.cc:93-211),
 // pbwt_context (include/vcf2multialign/pbwt.hh:21-145) and founder_sequence_greedy_output::find_matchings
 // (libvcf2multialign/founder_sequence_greedy_output.cc:154-512); the rows they select are then spliced on the
 // GPU (output.hh: founder_sequence_greedy_output).  They read paths_by_edge_and_chrom_copy, the builder's own
@@ -21,14 +22,18 @@ constexpr u32 kCutPositionScoreMax = UINT32_MAX;   // find_cut_positions.hh:17
 // Cut positions (node indices, first 0, last the sink) minimising the largest number of distinct path
 // segments between two consecutive cuts, subject to a minimum aligned distance.  Returns the score
 // (kCutPositionScoreMax if there is no solution).
-u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &cut_positions);
+// threads: as for find_matchings below.
+u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &cut_positions, unsigned threads = 1);
 
 // Greedy assignment of path equivalence classes to founders.  assigned_samples receives the
 // (cut_positions.size() - 1) x founder_count matrix, column-major, one column per founder; slots that stay
 // unassigned hold kPloidyMax.  Returns false when there is nothing to match.
+// threads: 1 = the reference's sequential loop; more (0 = up to 16 hardware threads) splits the cuts into chunks whose
+// pBWT state is built from scratch from paths_by_chrom_copy_and_edge (the transpose's result), with the same outcome;
+// without that matrix the search is sequential whatever `threads` says.
 bool find_matchings(
 	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
-	std::vector<u32> &assigned_samples);
+	std::vector<u32> &assigned_samples, unsigned threads = 1);
 
 // --output-cut-positions / --input-cut-positions (founder_sequence_greedy_output.cc:118-136).  The reference writes the
 // struct {min_distance, cut_positions, score} (output.hh:89-97,133-139) through cereal's PortableBinaryOutputArchive;

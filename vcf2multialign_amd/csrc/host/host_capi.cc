@@ -142,20 +142,35 @@ void v2mh_overlap_get(void *h, uint64_t i, uint64_t *lineno, uint64_t *ref_pos, 
 // find_cut_positions + find_matchings on a built graph.  cuts_out must hold node_count entries; assigned_out
 // (cuts - 1) * founder_count entries (column-major).  Returns the number of cut positions, 0 if there is no
 // solution; *score_out receives the segmentation score.
-uint64_t v2mh_find_founders(void *h, uint64_t min_distance, uint32_t founder_count, int keep_ref_edges,
-	uint64_t *cuts_out, uint32_t *assigned_out, uint64_t assigned_capacity, uint32_t *score_out)
+uint64_t v2mh_find_founders_mt(void *h, uint64_t min_distance, uint32_t founder_count, int keep_ref_edges,
+	uint64_t *cuts_out, uint32_t *assigned_out, uint64_t assigned_capacity, uint32_t *score_out, unsigned threads)
 {
 	auto const &g(HG(h).graph);
 	std::vector<vh::u64> cuts;
-	vh::u32 const score(vh::find_cut_positions(g, min_distance, cuts));
+	vh::u32 const score(vh::find_cut_positions(g, min_distance, cuts, threads));
 	if (score_out) *score_out = score;
 	if (vh::kCutPositionScoreMax == score) return 0;
 	std::vector<vh::u32> assigned;
-	if (!vh::find_matchings(g, cuts, founder_count, 0 != keep_ref_edges, assigned)) return 0;
+	if (!vh::find_matchings(g, cuts, founder_count, 0 != keep_ref_edges, assigned, threads)) return 0;
 	if (assigned.size() > assigned_capacity) return 0;
 	std::copy(cuts.begin(), cuts.end(), cuts_out);
 	std::copy(assigned.begin(), assigned.end(), assigned_out);
 	return cuts.size();
+}
+
+uint64_t v2mh_find_founders(void *h, uint64_t min_distance, uint32_t founder_count, int keep_ref_edges,
+	uint64_t *cuts_out, uint32_t *assigned_out, uint64_t assigned_capacity, uint32_t *score_out)
+{
+	return v2mh_find_founders_mt(h, min_distance, founder_count, keep_ref_edges, cuts_out, assigned_out, assigned_capacity, score_out, 1);
+}
+
+// The transpose's result (rows = edges, cols = copies, column-major words) for a graph whose builder ran without a GPU;
+// the multi-threaded founder search reads copy prefixes from it.
+void v2mh_set_paths_by_chrom_copy_and_edge(void *h, uint64_t const *words, uint64_t rows, uint64_t cols)
+{
+	auto &m(HG(h).graph.paths_by_chrom_copy_and_edge);
+	m = vh::bit_matrix(rows, cols);
+	std::copy(words, words + rows / 64 * cols, m.words.begin());
 }
 
 // Cut position files (founder.hh).  Return 0 on success, 1 with a message in err otherwise.

@@ -358,7 +358,7 @@ int main(int argc, char **argv)
 				cut_min_distance = loaded.min_distance;
 			} else {
 				std::cerr << "Optimising cut positions...\n";
-				score = vh::find_cut_positions(graph, vh::u64(opt.minimum_distance), cuts);
+				score = vh::find_cut_positions(graph, vh::u64(opt.minimum_distance), cuts, 0);
 				if (vh::kCutPositionScoreMax == score) { std::cerr << "ERROR: Unable to optimise cut positions.\n"; return EXIT_FAILURE; }
 				if (opt.verbose) {
 					std::cout << "Cut positions:";
@@ -371,7 +371,7 @@ int main(int argc, char **argv)
 				vh::write_cut_positions({cuts, cut_min_distance, score}, opt.output_cut_positions);
 			std::cerr << "Finding matchings in the variant graph...\n";
 			std::vector<vh::u32> assigned;
-			if (!vh::find_matchings(graph, cuts, vh::u32(opt.founder_sequences), opt.keep_ref_edges, assigned)) { std::cerr << "ERROR: Unable to find matchings.\n"; return EXIT_FAILURE; }
+			if (!vh::find_matchings(graph, cuts, vh::u32(opt.founder_sequences), opt.keep_ref_edges, assigned, 0)) { std::cerr << "ERROR: Unable to find matchings.\n"; return EXIT_FAILURE; }
 			if (opt.verbose) {                              // main.cc:534-545
 				std::cout << "Matchings:\n";
 				std::size_t const rows(cuts.size() - 1);

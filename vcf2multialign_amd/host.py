@@ -47,6 +47,9 @@ def _load():
 		L.v2mh_paths_by_edge_and_chrom_copy.argtypes = [C.c_void_p, _u64p, _u64p]
 		L.v2mh_find_founders.restype = C.c_uint64
 		L.v2mh_find_founders.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32)]
+		L.v2mh_find_founders_mt.restype = C.c_uint64
+		L.v2mh_find_founders_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint]
+		L.v2mh_set_paths_by_chrom_copy_and_edge.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
 		L.v2mh_overlap_get.argtypes = [C.c_void_p, C.c_uint64, _u64p, _u64p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
 		L.v2mh_write_cut_positions.restype = C.c_int
 		L.v2mh_write_cut_positions.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.c_size_t]
@@ -152,14 +155,21 @@ class HostGraph:
 		if 0 != _load().v2mh_write_graph(self._h, str(path).encode(), err, len(err)):
 			raise OSError(err.value.decode())
 
-	def find_founders(self, founder_count, min_distance=0, keep_ref_edges=False):
+	def set_transposed_paths(self, words, rows, cols):
+		"""paths_by_chrom_copy_and_edge (rows = edges, cols = copies) as produced by the transpose: needed by the
+		multi-threaded founder search when the graph was built without a GPU context."""
+		w = np.ascontiguousarray(words, dtype=np.uint64)
+		assert w.size == rows // 64 * cols
+		_load().v2mh_set_paths_by_chrom_copy_and_edge(self._h, w.ctypes.data, rows, cols)
+
+	def find_founders(self, founder_count, min_distance=0, keep_ref_edges=False, threads=1):
 		"""find_cut_positions + find_matchings (host algorithms).  Returns (cut_positions, assigned_samples column-major, score)
-		or None when there is no solution."""
+		or None when there is no solution.  threads > 1 (0 = automatic) spreads the matching's pBWT over threads."""
 		n = len(self.reference_positions)
 		cuts = np.zeros(n, dtype=np.uint64)
 		assigned = np.zeros(max(1, n * founder_count), dtype=np.uint32)
 		score = C.c_uint32()
-		k = _load().v2mh_find_founders(self._h, min_distance, founder_count, int(keep_ref_edges), cuts.ctypes.data, assigned.ctypes.data, assigned.size, C.byref(score))
+		k = _load().v2mh_find_founders_mt(self._h, min_distance, founder_count, int(keep_ref_edges), cuts.ctypes.data, assigned.ctypes.data, assigned.size, C.byref(score), threads)
 		if k == 0:
 			return None
 		return cuts[:k].tolist(), assigned[:(k - 1) * founder_count].tolist(), score.value
