@@ -12,6 +12,7 @@ from vcf2multialign_amd import synth, build
 from vcf2multialign_amd.host import HostGraph
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "config3"
+mode = sys.argv[2] if len(sys.argv) > 2 else "founders"    # or "haplotypes": BASELINE config 3 (all 5009 rows, 501 GB of A2M)
 tmp = os.environ.get("TMPDIR", "/tmp")
 fa, gf = os.path.join(tmp, cfg + ".fa"), os.path.join(tmp, cfg + ".v2mgraph")
 t = time.time()
@@ -37,7 +38,7 @@ ctx.close(); del src, dst
 print("prepared %s: graph file %.0f MB, FASTA %.0f MB in %.1f s" % (cfg, os.path.getsize(gf) / 1e6, os.path.getsize(fa) / 1e6, time.time() - t), flush=True)
 
 t = time.time()
-p = subprocess.Popen([build.CLI_PATH, "-F", "25", "-d", "50", "-r", fa, "-g", gf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"],
+p = subprocess.Popen([build.CLI_PATH] + (["-F", "25", "-d", "50"] if mode == "founders" else ["-H"]) + ["-r", fa, "-g", gf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"],
 	stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 marks = []
 for line in p.stderr:
@@ -47,6 +48,7 @@ total = time.time() - t
 for m in marks:
 	print("  %7.2f s  %s" % m)
 print(p.stdout.read().strip())
-print("exit %d; total %.2f s (26 rows x %d bases)" % (p.returncode, total, g.aligned_length))
+rows = 26 if mode == "founders" else ds.n_copies + 1
+print("exit %d; total %.2f s (%d rows x %d bases = %.1f Gbases -> %.1f Gbases/s end to end)" % (p.returncode, total, rows, g.aligned_length, rows * g.aligned_length / 1e9, rows * g.aligned_length / 1e9 / total))
 os.remove(gf); os.remove(fa)
 sys.exit(p.returncode)
