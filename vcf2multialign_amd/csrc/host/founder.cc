@@ -300,12 +300,43 @@ struct joined_class {                                                         //
 	bool operator<(joined_class const &o) const { return size < o.size; }
 };
 
+// The reference keeps "class representative -> founder" in a std::multimap (founder_sequence_greedy_output.cc:174); it
+// never holds more entries than there are founders and is rebuilt at every cut, so a sorted array does the same without
+// an allocation per entry: entries with equal keys stay in insertion order, find() returns the first of them (what
+// libstdc++'s and libc++'s multimap::find do), begin() is the smallest key.
+class class_to_founder_map {
+public:
+	typedef std::pair<u32, u32> value_type;
+	typedef std::vector<value_type>::iterator iterator;
+
+	iterator begin() { return m_entries.begin(); }
+	iterator end() { return m_entries.end(); }
+	bool empty() const { return m_entries.empty(); }
+	void clear() { m_entries.clear(); }
+	void erase(iterator it) { m_entries.erase(it); }
+
+	void insert(value_type const &v)
+	{
+		m_entries.insert(std::upper_bound(m_entries.begin(), m_entries.end(), v.first, [](u32 key, value_type const &e) { return key < e.first; }), v);
+	}
+	void emplace(u32 key, u32 founder) { insert({key, founder}); }
+
+	iterator find(u32 key)
+	{
+		auto const it(std::lower_bound(m_entries.begin(), m_entries.end(), key, [](value_type const &e, u32 k) { return e.first < k; }));
+		return (it != m_entries.end() && it->first == key) ? it : m_entries.end();
+	}
+
+private:
+	std::vector<value_type> m_entries;
+};
+
 // The matching state that survives from one cut to the next.
 struct matcher {
 	u32 founders;
 	std::size_t rows;
 	std::vector<u32> &assigned;                    // rows x founders, column-major
-	std::multimap<u32, u32> founder_by_class;      // class representative of the previous block -> founder
+	class_to_founder_map founder_by_class;         // class representative of the previous block -> founder
 	std::vector<char> reserved;
 	std::vector<u32> loose_rhs;
 
@@ -491,6 +522,69 @@ bool find_matchings_sequential(
 }
 
 
+// Chunks produced by `threads` workers in any order, consumed by the calling thread in chunk order; a worker does not
+// start chunk c before chunk c - window has been consumed, so at most `window` produced chunks are alive at a time.
+template <typename Produce, typename Consume>
+void run_chunk_pipeline(std::size_t n_chunks, unsigned threads, std::size_t window, Produce &&produce, Consume &&consume)
+{
+	std::mutex mutex;
+	std::condition_variable changed;
+	std::size_t next_claim(0), consumed(0);
+	std::vector<char> done(n_chunks, 0);
+	std::exception_ptr error;
+	auto const work([&] {
+		for (;;) {
+			std::size_t c;
+			{
+				std::unique_lock<std::mutex> lock(mutex);
+				changed.wait(lock, [&] { return error || next_claim >= n_chunks || next_claim < consumed + window; });
+				if (error || next_claim >= n_chunks) return;
+				c = next_claim++;
+			}
+			try {
+				produce(c);
+			} catch (...) {
+				std::lock_guard<std::mutex> lock(mutex);
+				if (!error) error = std::current_exception();
+			}
+			{
+				std::lock_guard<std::mutex> lock(mutex);
+				done[c] = 1;
+			}
+			changed.notify_all();
+		}
+	});
+	std::vector<std::thread> pool;
+	for (unsigned t(0); t < threads; ++t) pool.emplace_back(work);
+	for (std::size_t c(0); c < n_chunks; ++c) {
+		{
+			std::unique_lock<std::mutex> lock(mutex);
+			changed.wait(lock, [&] { return error || done[c]; });
+			if (error) break;
+		}
+		try {
+			consume(c);
+		} catch (...) {
+			std::lock_guard<std::mutex> lock(mutex);
+			if (!error) error = std::current_exception();
+			break;
+		}
+		{
+			std::lock_guard<std::mutex> lock(mutex);
+			consumed = c + 1;
+		}
+		changed.notify_all();
+	}
+	{
+		std::lock_guard<std::mutex> lock(mutex);
+		if (error) next_claim = n_chunks;                                       // nobody claims anything any more
+	}
+	changed.notify_all();
+	for (auto &t : pool) t.join();
+	if (error) std::rethrow_exception(error);
+}
+
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The same matching with the expensive part -- the pBWT over all edges and the path classes at every cut -- spread over
@@ -617,8 +711,8 @@ bool find_matchings_chunked(
 	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}};
 
 	// chunks of consecutive cuts with about the same number of edges each, several per thread
-	std::size_t const wanted(std::min<std::size_t>(std::size_t(threads) * 4, n_cuts - 1));
 	u64 const n_edges(graph.edge_count());
+	std::size_t const wanted(std::min<std::size_t>(std::max<std::size_t>(std::size_t(threads) * 8, std::size_t(n_edges / 8192) + 1), n_cuts - 1));
 	std::vector<cut_chunk> chunks;
 	{
 		std::size_t k(1);
@@ -634,43 +728,33 @@ bool find_matchings_chunked(
 		}
 	}
 
-	std::atomic<std::size_t> next_chunk(0);
-	std::vector<std::exception_ptr> errors(threads);
-	auto const work([&](unsigned tid) {
-		try {
-			for (std::size_t c; (c = next_chunk.fetch_add(1)) < chunks.size();) scan_cut_chunk(graph, cut_positions, chunks[c]);
-		} catch (...) {
-			errors[tid] = std::current_exception();
-		}
-	});
-	std::vector<std::thread> pool;
-	for (unsigned tid(1); tid < threads; ++tid) pool.emplace_back(work, tid);
-	work(0);
-	for (auto &t : pool) t.join();
-	for (auto const &e : errors) if (e) std::rethrow_exception(e);
-
-	// the assignment, in cut order (founder_sequence_greedy_output.cc:254-457)
+	// the assignment, in cut order (founder_sequence_greedy_output.cc:254-457), while the workers scan the chunks ahead
 	u32 lhs_distinct(0), rhs_distinct(0), lhs_first_class(0), rhs_first_class(0);
 	bool lhs_first_is_ref(true);
 	std::vector<joined_class> joined;
 	std::size_t cuts_seen(0);
-	for (auto const &chunk : chunks) {
-		for (auto const &rec : chunk.records) {
-			lhs_distinct = rhs_distinct;
-			lhs_first_class = rhs_first_class;
-			rhs_distinct = rec.rhs_distinct;
-			rhs_first_class = rec.rhs_first_class;
-			if (cuts_seen) {
-				joined.assign(chunk.pool.begin() + std::ptrdiff_t(rec.joined_begin), chunk.pool.begin() + std::ptrdiff_t(rec.joined_end));
-				if (!keep_ref_edges && lhs_first_is_ref && rec.rhs_first_is_ref)      // :258-264
-					std::erase_if(joined, [&](joined_class const &c) { return c.lhs_rep == lhs_first_class && c.rhs_rep == rhs_first_class; });
-				if (1 == cuts_seen) m.seed(joined, lhs_distinct);
-				m.extend(cuts_seen, joined, rhs_distinct);
+	run_chunk_pipeline(chunks.size(), threads, std::size_t(threads) * 2 + 2,
+		[&](std::size_t c) { scan_cut_chunk(graph, cut_positions, chunks[c]); },
+		[&](std::size_t c) {
+			auto &chunk(chunks[c]);
+			for (auto const &rec : chunk.records) {
+				lhs_distinct = rhs_distinct;
+				lhs_first_class = rhs_first_class;
+				rhs_distinct = rec.rhs_distinct;
+				rhs_first_class = rec.rhs_first_class;
+				if (cuts_seen) {
+					joined.assign(chunk.pool.begin() + std::ptrdiff_t(rec.joined_begin), chunk.pool.begin() + std::ptrdiff_t(rec.joined_end));
+					if (!keep_ref_edges && lhs_first_is_ref && rec.rhs_first_is_ref)      // :258-264
+						std::erase_if(joined, [&](joined_class const &jc) { return jc.lhs_rep == lhs_first_class && jc.rhs_rep == rhs_first_class; });
+					if (1 == cuts_seen) m.seed(joined, lhs_distinct);
+					m.extend(cuts_seen, joined, rhs_distinct);
+				}
+				++cuts_seen;
+				lhs_first_is_ref = rec.rhs_first_is_ref;
 			}
-			++cuts_seen;
-			lhs_first_is_ref = rec.rhs_first_is_ref;
-		}
-	}
+			std::vector<joined_class>().swap(chunk.pool);
+			std::vector<cut_record>().swap(chunk.records);
+		});
 	return true;
 }
 
@@ -804,64 +888,19 @@ u32 find_cut_positions_chunked(variant_graph const &graph, u64 min_distance, std
 		k = end;
 	}
 
-	std::mutex mutex;
-	std::condition_variable changed;
-	std::size_t next_claim(0), consumed(0);
-	std::size_t const window(std::size_t(threads) * 2 + 2);
-	std::vector<char> done(chunks.size(), 0);
-	std::exception_ptr error;
-	auto const work([&] {
-		for (;;) {
-			std::size_t c;
-			{
-				std::unique_lock<std::mutex> lock(mutex);
-				changed.wait(lock, [&] { return error || next_claim >= chunks.size() || next_claim < consumed + window; });
-				if (error || next_claim >= chunks.size()) return;
-				c = next_claim++;
+	run_chunk_pipeline(chunks.size(), threads, std::size_t(threads) * 2 + 2,
+		[&](std::size_t c) { scan_cut_search_chunk(graph, min_distance, cuts, first_candidate_from_edge, chunks[c]); },
+		[&](std::size_t c) {
+			auto &chunk(chunks[c]);
+			std::size_t t(0);
+			for (std::size_t j(chunk.first); j < chunk.end; ++j) {
+				cut_candidate &current(cuts[j]);
+				for (std::size_t const t_end(chunk.trial_end[j - chunk.first]); t < t_end; ++t)
+					current.improve(chunk.trials[t].class_count, cuts[chunk.trials[t].pred]);
 			}
-			try {
-				scan_cut_search_chunk(graph, min_distance, cuts, first_candidate_from_edge, chunks[c]);
-			} catch (...) {
-				std::lock_guard<std::mutex> lock(mutex);
-				if (!error) error = std::current_exception();
-			}
-			{
-				std::lock_guard<std::mutex> lock(mutex);
-				done[c] = 1;
-			}
-			changed.notify_all();
-		}
-	});
-	std::vector<std::thread> pool;
-	for (unsigned t(0); t < threads; ++t) pool.emplace_back(work);
-	for (std::size_t c(0); c < chunks.size(); ++c) {
-		{
-			std::unique_lock<std::mutex> lock(mutex);
-			changed.wait(lock, [&] { return error || done[c]; });
-			if (error) break;
-		}
-		auto &chunk(chunks[c]);
-		std::size_t t(0);
-		for (std::size_t j(chunk.first); j < chunk.end; ++j) {
-			cut_candidate &current(cuts[j]);
-			for (std::size_t const t_end(chunk.trial_end[j - chunk.first]); t < t_end; ++t)
-				current.improve(chunk.trials[t].class_count, cuts[chunk.trials[t].pred]);
-		}
-		std::vector<cut_trial>().swap(chunk.trials);
-		std::vector<std::size_t>().swap(chunk.trial_end);
-		{
-			std::lock_guard<std::mutex> lock(mutex);
-			consumed = c + 1;
-		}
-		changed.notify_all();
-	}
-	{
-		std::lock_guard<std::mutex> lock(mutex);
-		if (error) next_claim = chunks.size();
-	}
-	changed.notify_all();
-	for (auto &t : pool) t.join();
-	if (error) std::rethrow_exception(error);
+			std::vector<cut_trial>().swap(chunk.trials);
+			std::vector<std::size_t>().swap(chunk.trial_end);
+		});
 	return collect_cut_positions(cuts, graph, out);
 }
 
