@@ -1,0 +1,39 @@
+// Sanitizer harness for the host's readers, graph builder and graph checkpoint (csrc/host/readers.cc,
+// graph_builder.cc, graph_file.cc): reader_harness FASTA VCF SCRATCH_FILE builds the graph on 1, 3 and 8 threads
+// (with a sample filter and both matrix paddings), compares the results and round-trips the checkpoint.
+#include "graph_file.hh"
+#include "readers.hh"
+
+#include <cstdio>
+
+using namespace v2m::host;
+
+struct delegate final : build_graph_delegate {
+	u64 overlaps{};
+	bool should_include(std::string_view sample, u32 copy) const override { return !(sample == "S3" && 1 == copy); }
+	void report_overlapping_alternative(u64, u64, std::string_view, std::string_view, u32, u32) override { ++overlaps; }
+	bool ref_column_mismatch(u64, u64, std::string_view, std::string_view) override { return true; }
+};
+
+int main(int argc, char **argv)
+{
+	if (argc < 4) return 2;
+	sequence_type ref;
+	if (!read_single_fasta_sequence(argv[1], ref)) return 2;
+	u64 signature[3] = {};
+	int k(0);
+	for (unsigned threads : {1u, 3u, 8u}) {
+		variant_graph g;
+		build_graph_statistics stats;
+		delegate d;
+		build_variant_graph(ref, argv[2], "1", g, stats, d, threads, 3 == threads ? 1024 : 64);
+		std::printf("threads %u: %llu nodes, %llu edges, %llu overlaps, %llu records\n", threads, (unsigned long long) g.node_count(),
+			(unsigned long long) g.edge_count(), (unsigned long long) d.overlaps, (unsigned long long) stats.handled_variants);
+		signature[k++] = g.node_count() ^ (g.edge_count() << 20) ^ (d.overlaps << 40);
+		write_graph(g, argv[3]);
+		variant_graph back;
+		read_graph(argv[3], back);
+		if (back.alt_edge_targets != g.alt_edge_targets || back.paths_by_edge_and_chrom_copy.words != g.paths_by_edge_and_chrom_copy.words) return 3;
+	}
+	return (signature[0] == signature[1] && signature[1] == signature[2]) ? 0 : 4;
+}
