@@ -391,6 +391,32 @@ def test_device_rows_checksums(v2m, ctx, tmp_path):
 	assert np.array_equal(sums, v2m.checksum_rows_host(exp))
 
 
+def test_nothing_is_written_outside_the_rows(v2m, ctx, tmp_path):
+	"""Guard bytes: with a pitch wider than the rows and guard zones before the first and after the last row, the kernels
+	may touch only the rows themselves (aligned: up to the row length rounded up to 16 bytes; unaligned: exactly the
+	row's bytes)."""
+	import torch
+	g = synth.build_case(tmp_path, 41, 90000, 1500, 9, long_every=60)
+	_upload(v2m, ctx, g)
+	L = g.aligned_length
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies))           # 19 rows: one full group of 16 + a ragged one
+	guard = 1 << 16
+	for unaligned in (False, True):
+		exp = _oracle_rows(g, rows, unaligned=unaligned)
+		pitch = ((ctx.max_unaligned_length if unaligned else L) + 255) // 256 * 256 + 768
+		buf = torch.full((2 * guard + len(rows) * pitch,), 0xAB, dtype=torch.uint8, device="cuda")
+		torch.cuda.synchronize()
+		ctx.splice_rows_device(rows, buf.data_ptr() + guard, pitch, unaligned=unaligned)
+		ctx.synchronize()
+		host = buf.cpu().numpy()
+		assert (host[:guard] == 0xAB).all() and (host[guard + len(rows) * pitch:] == 0xAB).all()
+		body = host[guard:guard + len(rows) * pitch].reshape(len(rows), pitch)
+		for i, b in enumerate(exp):
+			assert body[i, :len(b)].tobytes() == b
+			written_to = len(b) if unaligned else (len(b) + 15) // 16 * 16
+			assert (body[i, written_to:] == 0xAB).all(), "row %d: bytes past %d were touched" % (i, written_to)
+
+
 def test_sink_slices(v2m, ctx, tmp_path, monkeypatch):
 	g = synth.build_case(tmp_path, 32, 90000, 1500, 8)
 	monkeypatch.setenv("V2M_RING_SLOT_BYTES", "300000")   # ~3 rows per slice: several slices, both ring halves reused
