@@ -83,6 +83,28 @@ def test_transpose_random(ctx, monkeypatch, kernel, h, w):  # tests/transpose_ma
 	assert np.array_equal(ctx.transpose_matrix(got, cols, rows), src)   # involution
 
 
+@pytest.mark.parametrize("kernel", ["8x8", "stream16", "4x16"])
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 17), (17, 3), (9, 33), (16, 16)])
+def test_transpose_writes_only_the_destination(ctx, monkeypatch, kernel, h, w):
+	"""Device-resident transpose with guard words around the destination: panels that stick out over the matrix edge
+	must not write there."""
+	import torch
+	monkeypatch.setenv("V2M_TRANSPOSE_PANEL", kernel)
+	rng = np.random.default_rng(77 * h + w)
+	rows, cols = 64 * h, 64 * w
+	n = rows * cols // 64
+	src = rng.integers(0, 2 ** 63, size=n, dtype=np.uint64) | (rng.integers(0, 2, size=n, dtype=np.uint64) << np.uint64(63))
+	guard = 4096
+	d_src = torch.from_numpy(src.view(np.int64)).cuda()
+	d_dst = torch.full((n + 2 * guard,), 0x5A5A5A5A5A5A5A5A, dtype=torch.int64, device="cuda")
+	torch.cuda.synchronize()
+	ctx.transpose_bits_device(d_src.data_ptr(), rows, cols, d_dst.data_ptr() + 8 * guard)
+	ctx.synchronize()
+	host = d_dst.cpu().numpy().view(np.uint64)
+	assert (host[:guard] == 0x5A5A5A5A5A5A5A5A).all() and (host[guard + n:] == 0x5A5A5A5A5A5A5A5A).all()
+	assert np.array_equal(host[guard:guard + n], oracle.transpose_matrix(src, rows, cols, naive=True))
+
+
 def test_transpose_edge_cases(ctx, v2m):
 	assert ctx.transpose_matrix(np.zeros(0, np.uint64), 64, 0).size == 0           # transpose_matrix.cc:48-49
 	with pytest.raises(v2m.V2MError) as e:
