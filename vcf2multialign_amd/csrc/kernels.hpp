@@ -723,7 +723,9 @@ __device__ __forceinline__ void patch_row_tile(
 // groups; inside one, consecutive workgroups take consecutive TILES of the same row group.  The ~1000
 // workgroups in flight therefore write a few long contiguous runs per row (what a memset looks like to the
 // TLB and to DRAM pages) instead of 16 KiB islands 100 MB apart, while a super-block's template tiles
-// (tile_run x 16 KiB) stay L2-resident for the row groups that follow.
+// (tile_run x 16 KiB) stay L2-resident for the row groups that follow.  Workgroups are handed to the 8 XCDs round-robin
+// and tile_run is a multiple of 8, so (tile, any group) always lands on XCD (tile - t0) % 8: each XCD's L2 serves one
+// eighth of the super-block's tiles to all row groups.
 __device__ __forceinline__ void map_block(u32 b, u32 n_groups, u32 n_tiles, u32 tile_run, u32 &tile, u32 &group)
 {
 	u32 const per_super = tile_run * n_groups;
