@@ -272,3 +272,16 @@ def test_unsupported_and_bad_arguments():
 	assert run(["-H", "-r", "x", "-a", "y"]).returncode != 0
 	r = run(["-H", "-r", "/nonexistent.fa", "-a", "/nonexistent.vcf", "-c", "1"])
 	assert r.returncode != 0 and b"Unable to read the reference" in r.stderr
+
+
+def test_plain_c_example(tmp_path):
+	"""examples/splice_rows.c: the ABI used from C99 with nothing but include/v2m_hip.h; it checks its own rows."""
+	import shutil
+	from vcf2multialign_amd import build
+	src = os.path.join(ROOT, "examples", "splice_rows.c")
+	exe = tmp_path / "splice_rows"
+	subprocess.check_call([shutil.which("gcc"), "-std=c99", "-I" + os.path.join(ROOT, "include"), src, "-L" + build.PKG_DIR, "-lv2m_hip",
+		"-Wl,-rpath," + build.PKG_DIR, "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)])
+	r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+	assert r.returncode == 0, r.stderr.decode()
+	assert r.stdout.decode().splitlines() == ["REF     ACG--TACGT", "copy 0  ACGTTTACGT", "copy 1  ACG--TACG-"]

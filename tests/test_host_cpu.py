@@ -147,3 +147,21 @@ def test_two_rank_gloo_partition():
 		assert t == 2.0
 		assert gathered[0] + gathered[1] == list(range(301))
 		assert gathered[0][-1] == 152 and gathered[1][0] == 153   # rank 0: REF + copies 0..151 (19 bytes of every column), rank 1: copies 152..299
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+	"""include/v2m_hip.h compiles as C99 (no C++ in the boundary) and examples/splice_rows.c links against the library
+	with nothing but the header (it is run by the GPU suite)."""
+	import shutil
+	import subprocess
+	from vcf2multialign_amd import build
+	root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	gcc = shutil.which("gcc")
+	assert gcc, "gcc is part of the image"
+	src = os.path.join(root, "examples", "splice_rows.c")
+	subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"), "-fsyntax-only", src])
+	build.build_native()
+	exe = tmp_path / "splice_rows"
+	subprocess.check_call([gcc, "-std=c99", "-I" + os.path.join(root, "include"), src, "-L" + build.PKG_DIR, "-lv2m_hip",
+		"-Wl,-rpath," + build.PKG_DIR, "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)])
+	assert exe.exists()
