@@ -265,6 +265,7 @@ namespace {
 		int k(0);
 		while (k < 3) {   // pwritev may write less than asked
 			ssize_t const w(::pwritev(st.fd, iov + k, 3 - k, off_t(off)));
+			if (w < 0 && EINTR == errno) continue;
 			if (w <= 0) return 1;
 			off += std::uint64_t(w);
 			std::size_t left = std::size_t(w);
