@@ -181,10 +181,11 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 int v2m_splice_rows_device(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, void *d_out, uint64_t row_pitch, uint64_t *row_lengths_out);
 
 /* Device memory for row output (the d_out of v2m_splice_rows_device), chosen by measurement: on MI355X the
- * write rate the splice's store pattern reaches differs by ~25 % between physical regions of HBM
- * (tools/streams_probe.hip), which a caller cannot see from a pointer.  Allocates up to `candidates`
- * buffers of `bytes` (fewer if HBM runs out), times the store pattern on each, keeps the fastest and frees
- * the others.  candidates <= 1 is a plain allocation.  Free with v2m_free_output().  Synchronous. */
+ * write rate the splice's store pattern reaches differs by ~25 % between allocations, depending on how
+ * fragmented their physical backing is (tools/vmm_probe2.hip), which a caller cannot see from a pointer.
+ * Allocates up to `candidates` buffers of `bytes` (fewer if HBM runs out -- all of them are held until the
+ * choice is made), times the store pattern on each, keeps the fastest and frees the others.
+ * candidates <= 1 is a plain allocation.  Free with v2m_free_output().  Synchronous. */
 int v2m_alloc_output(v2m_ctx *ctx, uint64_t bytes, int candidates, void **d_out);
 int v2m_free_output(v2m_ctx *ctx, void *d_ptr);
 
