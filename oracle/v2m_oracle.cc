@@ -1217,6 +1217,43 @@ std::int64_t v2mo_output_sequence(
 	return std::int64_t(s.size());
 }
 
+// Checksum of one row as the oracle writes it -- the formula of v2m_checksum_rows_device (include/v2m_hip.h): sum over the
+// row's 8-byte little-endian words w (zero padded past the end) of mix64((w_index + 1) * GOLDEN ^ word), plus mix64(length).
+// Lets full-size tests compare whole 100-250 MB rows without moving them through Python.  Thread-safe (the graph is only read).
+std::uint64_t v2mo_row_checksum(
+	v2mo_graph *h, char const *ref_seq, int unaligned,
+	std::uint32_t copy_index, std::uint64_t const *cut_nodes, std::uint32_t const *cut_copies, std::uint64_t n_cuts,
+	std::uint64_t *length_out
+)
+{
+	std::ostringstream os;
+	if (n_cuts) {
+		founder_delegate d;
+		d.cut_nodes = cut_nodes; d.copies = cut_copies; d.n_cuts = n_cuts;
+		output_sequence(ref_seq, G(h), os, nullptr, unaligned, d);
+	} else {
+		fixed_copy_delegate d(copy_index);
+		output_sequence(ref_seq, G(h), os, nullptr, unaligned, d);
+	}
+	auto const s(std::move(os).str());
+	auto const mix64([](std::uint64_t z) {
+		z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+		z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+		z ^= z >> 31;
+		return z;
+	});
+	std::uint64_t const golden(0x9E3779B97F4A7C15ULL), n(s.size());
+	std::uint64_t acc(0);
+	for (std::uint64_t w(0); w * 8 < n; ++w) {
+		std::uint64_t v(0);
+		std::memcpy(&v, s.data() + w * 8, std::min<std::uint64_t>(8, n - w * 8));   // little-endian host
+		acc += mix64((w + 1) * golden ^ v);
+	}
+	acc += mix64(n);
+	if (length_out) *length_out = n;
+	return acc;
+}
+
 // dst_path == NULL -> discard through the counting null stream (timed baseline).
 // Returns bytes written, or -1.  seconds_out (optional) receives the wall time
 // of the output loop alone.

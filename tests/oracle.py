@@ -67,6 +67,8 @@ def lib():
 		f.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]
 	L.v2mo_output_sequence.restype = C.c_int64
 	L.v2mo_output_sequence.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+	L.v2mo_row_checksum.restype = C.c_uint64
+	L.v2mo_row_checksum.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, _u64p]
 	L.v2mo_haplotype_output_a2m.restype = C.c_int64
 	L.v2mo_haplotype_output_a2m.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_uint64, C.c_uint64, C.c_char_p, C.POINTER(C.c_double)]
 	L.v2mo_founder_output_a2m.restype = C.c_int64
@@ -165,6 +167,30 @@ class OracleGraph:
 			n = L.v2mo_output_sequence(self._h, ref, fasta_id.encode() if fasta_id else None, int(unaligned), copy_index, None, None, 0, buf, cap)
 		assert 0 <= n <= cap
 		return buf.raw[:n]
+
+	def row_checksum(self, ref, copy_index=PLOIDY_MAX, cuts=None, unaligned=False):
+		"""(checksum, length) of the row output_sequence() writes: v2m_checksum_rows_device's formula computed inside the
+		oracle, so whole 100-250 MB rows can be compared without coming through Python.  `ref` must be bytes (not copied)."""
+		L = lib()
+		n = C.c_uint64()
+		if cuts:
+			cn = np.ascontiguousarray([c[0] for c in cuts], dtype=np.uint64)
+			cc = np.ascontiguousarray([c[1] for c in cuts], dtype=np.uint32)
+			s = L.v2mo_row_checksum(self._h, ref, int(unaligned), 0, cn.ctypes.data, cc.ctypes.data, len(cuts), C.byref(n))
+		else:
+			s = L.v2mo_row_checksum(self._h, ref, int(unaligned), copy_index, None, None, 0, C.byref(n))
+		return int(s), int(n.value)
+
+	def row_checksums(self, ref, rows, unaligned=False, threads=8):
+		"""row_checksum() of many rows (each an int copy index, PLOIDY_MAX, or a list of (cut node, copy) pairs) on a few
+		threads (the C call releases the GIL and only reads the graph).  Returns (checksums u64 array, lengths u64 array)."""
+		from concurrent.futures import ThreadPoolExecutor
+		ref = bytes(ref)
+		def one(r):
+			return self.row_checksum(ref, cuts=r, unaligned=unaligned) if isinstance(r, (list, tuple)) else self.row_checksum(ref, copy_index=int(r), unaligned=unaligned)
+		with ThreadPoolExecutor(max_workers=max(1, min(threads, len(rows) or 1))) as ex:
+			res = list(ex.map(one, rows))
+		return np.array([s for s, _ in res], dtype=np.uint64), np.array([n for _, n in res], dtype=np.uint64)
 
 	# -- haplotype_output::output_a2m (haplotype_output.cc:38-82) ---------------------------------
 	def haplotype_output_a2m(self, ref, path=None, chromosome_id=None, output_reference=True, unaligned=False, first_copy=0, n_copies=None):

@@ -3,7 +3,12 @@ oracle on sampled rows (the oracle needs ~0.1 s per 10 MB row; the GPU writes 20
 
 config 2: synthetic 10 Mb reference, 100k SNV-only records, 1000 diploid samples -> all 2001 rows (20 GB).
 config 3: synthetic 100 Mb reference, 1M SNV+indel records, 2504 diploid samples -> the full 5056 x 1M path-matrix
-          transpose, and a 96-row window of the splice (9.6 GB)."""
+          transpose, and a 96-row window of the splice (9.6 GB).
+config 4: the config-3 input with --founder-sequences=25 --minimum-distance=50 -> host search on 1 and 16 threads, the
+          26 rows (672 495 copy switches per founder row) against the oracle's walk with the same cuts.
+config 5: synthetic 250 Mb reference, 6M records incl. MNPs / multi-allelic sites, 10000 diploid samples -> the full
+          20032 x 6.24M transpose (15.6 GB), and a 64-row window of the splice (16 GB) holding REF, the last real copies
+          and padding copies."""
 
 import numpy as np
 import pytest
@@ -43,6 +48,24 @@ def _oracle_for(ds, copies):
 		g.label_offsets, g.label_bytes, cols, ds.path_rows, 64 * ((len(copies) + 63) // 64))
 
 
+def _popcount(torch, t):
+	"""Number of set bits of an int64 device tensor (SWAR per word, in 1-GiB pieces)."""
+	total = 0
+	for c in t.split(1 << 27):
+		x = c.clone()
+		x -= (x >> 1) & 0x5555555555555555
+		x = (x & 0x3333333333333333) + ((x >> 2) & 0x3333333333333333)
+		x = (x + (x >> 4)) & 0x0F0F0F0F0F0F0F0F
+		total += int((((x * 0x0101010101010101) >> 56) & 0xFF).sum().item())
+	return total
+
+
+def test_popcount_helper(env):
+	torch, _, _ = env
+	t = torch.tensor([0, 1, -1, 0x7FFFFFFFFFFFFFFF, -0x8000000000000000, 0x0123456789ABCDEF], dtype=torch.int64, device="cuda")
+	assert _popcount(torch, t) == 0 + 1 + 64 + 63 + 1 + 32
+
+
 def test_config3_transpose_full_size(env):
 	torch, v2m, synth = env
 	ds = synth.dataset("config3")
@@ -55,12 +78,8 @@ def test_config3_transpose_full_size(env):
 		ctx.transpose_bits_device(dst.data_ptr(), ep, hp, back.data_ptr())
 		ctx.synchronize()
 		assert torch.equal(back, src)
-		# the number of set bits survives (popcount via bytes)
-		def popcount(t):
-			b = t.view(torch.uint8)
-			lut = torch.tensor([bin(i).count("1") for i in range(256)], dtype=torch.int64, device=b.device)
-			return int(lut[b.long()].sum().item()) if b.numel() < (1 << 28) else sum(int(lut[c.long()].sum().item()) for c in b.split(1 << 27))
-		assert popcount(src) == popcount(dst)
+		# the number of set bits survives
+		assert _popcount(torch, src) == _popcount(torch, dst)
 		# sampled destination columns (= chromosome copies) against the CPU re-derivation of the genotype hash
 		wpc = ep // 64
 		for copy in (0, 1, 63, 64, 2503, 5007):
@@ -198,3 +217,127 @@ def test_small_configs_all_rows_all_bytes(env, config):
 			labels = [bytes(g.label_bytes[int(a):int(b)]) for a, b in zip(g.label_offsets[:-1], g.label_offsets[1:])]
 			assert any(len(l) in (2, 3, 4) for l in labels)      # MNPs are in the mix
 			assert (np.diff(g.alt_edge_count_csum.astype(np.int64)) > 1).any()   # and multi-allelic sites
+
+
+def test_config5_transpose_full_size(env):
+	"""BASELINE config 5's whole path matrix: 20032 copies x 6.24 M edges = 15.6 GB, transposed there and back."""
+	torch, v2m, synth = env
+	ds = synth.dataset("config5")
+	hp, ep = ds.path_cols, ds.path_rows
+	assert hp == 20032 and ds.n_copies == 20000 and ep % 64 == 0 and ep >= ds.graph.edge_count > 6_000_000
+	with v2m.Context(0) as ctx:
+		src, dst = _device_paths(torch, v2m, ds, ctx)
+		back = torch.empty_like(src)
+		ctx.transpose_bits_device(dst.data_ptr(), ep, hp, back.data_ptr())
+		ctx.synchronize()
+		assert torch.equal(back, src)                                  # involution, word for word
+		del back
+		n_set = _popcount(torch, src)
+		assert n_set == _popcount(torch, dst) and n_set > 0
+		wpc = ep // 64
+		for copy in (0, 1, 63, 64, 9999, 19967, 19968, 19999):           # destination columns = chromosome copies, vs the CPU genotype hash
+			got = dst[copy * wpc:(copy + 1) * wpc].cpu().numpy().view(np.uint64)
+			assert np.array_equal(got, ds.copy_column(copy)), "copy %d" % copy
+		assert int((dst[20000 * wpc:] != 0).sum().item()) == 0         # padding copies are empty
+		# an edge's source column against the same hash, bit by bit for a few edges (rows = copies)
+		swc = hp // 64
+		cols = {c: ds.copy_column(c) for c in (0, 1, 777, 19999)}
+		for e in (0, 1, 12345, ds.graph.edge_count - 1):
+			col = src[e * swc:(e + 1) * swc].cpu().numpy().view(np.uint64)
+			for c, words in cols.items():
+				assert (int(col[c // 64]) >> (c % 64)) & 1 == (int(words[e // 64]) >> (e % 64)) & 1, (e, c)
+
+
+def test_config5_row_window(env):
+	"""64 rows x 252 Mbases of config 5 (16 GB): REF, the last 32 real copies and 31 padding copies of the last 64-copy
+	word; every row by device checksum against the oracle, four of them byte for byte, unaligned lengths and checksums."""
+	torch, v2m, synth = env
+	ds = synth.dataset("config5")
+	g = ds.graph
+	L = g.aligned_length
+	assert len(ds.reference) == 250_000_000 and L > 250_000_000
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(g, ds.reference)
+		base, hp = 19968, 64
+		src, dst = _device_paths(torch, v2m, ds, ctx, copy_base=base, hp=hp)
+		ctx.set_paths_device(dst.data_ptr(), ds.path_rows, hp)
+		n_real = ds.n_copies - base                                    # 32
+		rows = [v2m.PLOIDY_MAX] + list(range(63))
+		pitch = ctx.min_row_pitch
+		out = torch.empty(len(rows) * pitch, dtype=torch.uint8, device="cuda")
+		torch.cuda.synchronize()
+		ctx.splice_rows_device(rows, out.data_ptr(), pitch)
+		sums = ctx.checksum_rows_device(out.data_ptr(), pitch, len(rows), length=L)
+
+		real = list(range(n_real))
+		og = _oracle_for(ds, [base + c for c in real])
+		exp_sums, exp_len = og.row_checksums(ds.reference, [oracle.PLOIDY_MAX] + real, threads=12)
+		assert set(exp_len.tolist()) == {L}
+		assert np.array_equal(sums[:1 + n_real], exp_sums)             # REF + every real copy of the window
+		assert len(set(sums[1:1 + n_real].tolist())) > n_real // 2     # and they differ from each other
+		for c in range(n_real, 63):                                   # padding copies carry no bits: REF
+			assert sums[1 + c] == sums[0]
+		for c in (0, 13, n_real - 1):                                 # byte for byte (the last real copy of the data set among them)
+			exp = og.output_sequence(ds.reference, copy_index=c)
+			assert out[(1 + c) * pitch:(1 + c) * pitch + L].cpu().numpy().tobytes() == exp, "copy %d" % (base + c)
+		assert out[:L].cpu().numpy().tobytes() == og.output_sequence(ds.reference)
+		del out
+
+		# unaligned: lengths and checksums of REF + 5 copies
+		upitch = (ctx.max_unaligned_length + 255) // 256 * 256
+		usample = [0, 1, 13, 30, n_real - 1]
+		uout = torch.empty((1 + len(usample)) * upitch, dtype=torch.uint8, device="cuda")
+		torch.cuda.synchronize()
+		lengths = ctx.splice_rows_device([v2m.PLOIDY_MAX] + usample, uout.data_ptr(), upitch, unaligned=True, want_lengths=True)
+		exp_usums, exp_ulen = og.row_checksums(ds.reference, [oracle.PLOIDY_MAX] + usample, unaligned=True, threads=6)
+		assert lengths.tolist() == exp_ulen.tolist() and lengths[0] == len(ds.reference)
+		usums = ctx.checksum_rows_device(uout.data_ptr(), upitch, len(lengths), lengths=lengths)
+		assert np.array_equal(usums, exp_usums)
+
+
+def test_config4_full_size(env):
+	"""BASELINE config 4: the config-3 input, --founder-sequences=25 --minimum-distance=50.  transpose on the GPU, cut
+	positions + greedy matching on the host (1 thread == 16 threads), REF + 25 founder rows on the GPU against the oracle's
+	walk (founder_sequence_greedy_output.cc:106-114 over sequence_writer.cc:22-85) with the same cuts."""
+	import zlib
+	torch, v2m, synth = env
+	from vcf2multialign_amd.host import HostGraph
+	founders, min_dist = 25, 50
+	ds = synth.dataset("config3")
+	g = ds.graph
+	L = g.aligned_length
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(g, ds.reference)
+		src, dst = _device_paths(torch, v2m, ds, ctx)
+		hp, ep = ds.path_cols, ds.path_rows
+		ctx.set_paths_device(dst.data_ptr(), ep, hp)
+		src_host, dst_host = src.cpu().numpy().view(np.uint64), dst.cpu().numpy().view(np.uint64)
+		hg = HostGraph.from_arrays(g, src_host, hp, ep, ds.samples, ds.ploidy)
+		hg.set_transposed_paths(dst_host, ep, hp)
+		res = hg.find_founders(founders, min_dist, keep_ref_edges=False, threads=16)
+		assert res is not None
+		cuts, assigned, score = res
+		n_seg = len(cuts) - 1
+		assert cuts[0] == 0 and cuts[-1] == g.node_count - 1 and n_seg > 100_000 and len(assigned) == n_seg * founders
+		aln = g.aligned_positions
+		assert int(np.diff(aln[np.asarray(cuts, dtype=np.int64)].astype(np.int64)).min()) >= min_dist      # --minimum-distance
+		res1 = hg.find_founders(founders, min_dist, keep_ref_edges=False, threads=1)
+		crc = lambda r: (zlib.crc32(np.asarray(r[0], dtype=np.uint64).tobytes()), zlib.crc32(np.asarray(r[1], dtype=np.uint32).tobytes()), r[2])
+		assert crc(res1) == crc(res)                                  # the chunked multi-thread search == the sequential loop
+
+		batch_rows = [v2m.PLOIDY_MAX] + [list(zip(cuts[:-1], assigned[f * n_seg:(f + 1) * n_seg])) for f in range(founders)]
+		pitch = ctx.min_row_pitch
+		out = torch.empty(len(batch_rows) * pitch, dtype=torch.uint8, device="cuda")
+		torch.cuda.synchronize()
+		ctx.splice_rows_device(v2m.RowBatch(batch_rows), out.data_ptr(), pitch)
+		sums = ctx.checksum_rows_device(out.data_ptr(), pitch, len(batch_rows), length=L)
+		assert len(set(sums.tolist())) == len(batch_rows)             # 26 different rows
+
+		og = oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
+			g.label_offsets, g.label_bytes, dst_host, ep, hp)
+		check = [0, 1, 7, founders // 2, founders]
+		exp_sums, exp_len = og.row_checksums(ds.reference, [batch_rows[r] for r in check], threads=len(check))
+		assert set(exp_len.tolist()) == {L}
+		assert np.array_equal(sums[check], exp_sums)
+		r = founders
+		assert out[r * pitch:r * pitch + L].cpu().numpy().tobytes() == og.output_sequence(ds.reference, cuts=batch_rows[r])

@@ -127,3 +127,18 @@ def test_graph_path_matrices_are_transposes(case, fixtures_dir):
 	hp, ep = g.paths_by_edge_and_chrom_copy_dims
 	assert hp % 64 == 0 and ep % 64 == 0 and (g.path_rows, g.path_cols) == (ep, hp)
 	assert np.array_equal(oracle.transpose_matrix(g.paths_by_edge_and_chrom_copy, hp, ep, naive=True), g.paths_by_chrom_copy_and_edge)
+
+
+def test_row_checksum_is_the_documented_formula(fixtures_dir):
+	"""v2mo_row_checksum (used by the full-size GPU tests and bench.py) == the numpy form of v2m_checksum_rows_device's
+	formula over the bytes output_sequence() returns; haplotype rows, REF, founder rows, aligned and unaligned."""
+	import numpy as np
+	from vcf2multialign_amd.context import checksum_rows_host
+	d = os.path.join(fixtures_dir, "variant-graph")
+	g = oracle.build_variant_graph(os.path.join(d, "test-4.fa"), os.path.join(d, "test-4.vcf"), "1")
+	rows = [oracle.PLOIDY_MAX] + list(range(g.total_chromosome_copies)) + [[(0, 1), (g.node_count - 1, 0)]]
+	for unaligned in (False, True):
+		exp = [g.output_sequence(g.ref, cuts=r, unaligned=unaligned) if isinstance(r, list) else g.output_sequence(g.ref, copy_index=r, unaligned=unaligned) for r in rows]
+		sums, lengths = g.row_checksums(g.ref, rows, unaligned=unaligned, threads=3)
+		assert np.array_equal(sums, checksum_rows_host(exp))
+		assert lengths.tolist() == [len(e) for e in exp]

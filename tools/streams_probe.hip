@@ -19,6 +19,7 @@ __global__ __launch_bounds__(256) void rows_kernel(char *out, size_t pitch, unsi
 		char *dst = out + (size_t)(group * rows_per_group + r) * pitch + (size_t) tile * SEG;
 #pragma unroll
 		for (int k = 0; k < SEG / 16 / 256; ++k) {
+			if ((size_t) tile * SEG + (threadIdx.x + 256 * k) * 16 + 16 > pitch) continue;   // the last segment of a row is partial: stay inside the row
 			vec4u *p = (vec4u *)(dst + (threadIdx.x + 256 * k) * 16);
 			if (NT) __builtin_nontemporal_store(v, p); else *p = v;
 		}
