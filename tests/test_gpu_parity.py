@@ -70,8 +70,11 @@ def test_transpose_fixed(ctx, case):   # tests/transpose_matrix.cc:188-251
 	assert np.array_equal(ctx.transpose_matrix(src, case["rows"], case["cols"]), exp)
 
 
-@pytest.mark.parametrize("kernel", ["8x8", "stream16", "4x16"])
-@pytest.mark.parametrize("h,w", [(1, 1), (1, 2), (2, 1), (3, 5), (8, 8), (9, 7), (16, 17), (79, 33), (5, 130), (64, 64), (17, 15), (33, 31)])
+TRANSPOSE_KERNELS = ["8x8", "stream16", "4x16", "8x8/rr", "ring:16,8,8,4,16", "ring:16,8,8,4,64,slow", "ring:8,4,8,4,8", "ring:16,8,4,4,64", "ring:16,8,16,4,32", "ring:16,16,8,8,64/rr"]
+
+
+@pytest.mark.parametrize("kernel", TRANSPOSE_KERNELS)
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 2), (2, 1), (3, 5), (8, 8), (9, 7), (16, 17), (79, 33), (5, 130), (64, 64), (17, 15), (33, 31), (2, 200)])
 def test_transpose_random(ctx, monkeypatch, kernel, h, w):  # tests/transpose_matrix.cc:254-279 (1/3 of the bits set), plus ragged panels
 	monkeypatch.setenv("V2M_TRANSPOSE_PANEL", kernel)   # both transpose kernels (the library picks per shape by measurement)
 	rng = np.random.default_rng(1000 * h + w)
@@ -83,8 +86,8 @@ def test_transpose_random(ctx, monkeypatch, kernel, h, w):  # tests/transpose_ma
 	assert np.array_equal(ctx.transpose_matrix(got, cols, rows), src)   # involution
 
 
-@pytest.mark.parametrize("kernel", ["8x8", "stream16", "4x16"])
-@pytest.mark.parametrize("h,w", [(1, 1), (3, 17), (17, 3), (9, 33), (16, 16)])
+@pytest.mark.parametrize("kernel", TRANSPOSE_KERNELS)
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 17), (17, 3), (9, 33), (16, 16), (1, 79)])
 def test_transpose_writes_only_the_destination(ctx, monkeypatch, kernel, h, w):
 	"""Device-resident transpose with guard words around the destination: panels that stick out over the matrix edge
 	must not write there."""

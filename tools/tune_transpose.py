@@ -1,29 +1,65 @@
 #!/usr/bin/env python3
-"""A/B of the transpose panel shape in one process: the config-3 path matrix (5056 x 1M bits) and its inverse."""
-import os, sys
+"""A/B of the transpose kernels in one process: a path matrix (default: config 3's 5056 x 1 000 000 bits, the reference's
+own 64-bit padding) forward and inverse, every candidate checked word for word against the first one's result.
+
+    python tools/tune_transpose.py [rows cols] [--set quick|full] [name ...]
+
+Kernel names are those of V2M_TRANSPOSE_PANEL (vcf2multialign_amd/csrc/v2m_hip.hip: launch_transpose_named)."""
+import os
+import sys
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np, torch
-import vcf2multialign_amd as v2m
-from vcf2multialign_amd import _native as N
+import torch  # noqa: E402
+
+import vcf2multialign_amd as v2m  # noqa: E402
+from vcf2multialign_amd import _native as N  # noqa: E402
+
+QUICK = ["8x8/rr", "8x8", "stream16/rr", "stream16",
+	"ring:16,8,8,4,64", "ring:16,8,8,4,64,slow", "ring:16,8,8,4,64/rr", "ring:16,8,8,4,128", "ring:16,8,8,4,256",
+	"ring:16,4,8,4,64", "ring:16,16,8,4,64", "ring:16,16,8,8,64", "ring:16,8,8,8,64",
+	"ring:16,8,4,4,64", "ring:16,8,16,4,64", "ring:8,4,8,4,64", "ring:8,8,8,4,64", "ring:8,4,8,8,64", "ring:8,8,4,8,64"]
+FULL = QUICK + ["4x16", "16x4", "ring:8,4,8,4,128", "ring:8,8,8,4,128", "ring:16,8,4,4,128", "ring:16,16,8,4,128", "ring:8,4,8,8,256"]
+
+args = sys.argv[1:]
+names_set = QUICK
+if "--set" in args:
+	i = args.index("--set")
+	names_set = FULL if args[i + 1] == "full" else QUICK
+	del args[i:i + 2]
+dims = [a for a in args if a.isdigit()]
+names = [a for a in args if not a.isdigit()] or names_set
+hp, ep = (int(dims[0]), int(dims[1])) if len(dims) >= 2 else (5056, 1000000)
+
 ctx = v2m.Context(0)
-hp, ep = (int(x) for x in (sys.argv[1:3] if len(sys.argv) > 2 else (5056, 1000000)))
-print("matrix %d x %d bits" % (hp, ep))
 n = hp // 64 * ep
+print("matrix %d x %d bits, %.3f GB moved per transpose" % (hp, ep, 2 * n * 8 / 1e9), flush=True)
 src = torch.randint(-2**62, 2**62, (n,), dtype=torch.int64, device="cuda")
-dst = torch.empty_like(src); back = torch.empty_like(src)
-torch.cuda.synchronize(); ctx.profile_enable(True)
-for shape in ("8x8", "stream16", "4x16", "8x8", "stream16"):
-	os.environ["V2M_TRANSPOSE_PANEL"] = shape
+dst = torch.empty_like(src)
+back = torch.empty_like(src)
+want_dst = None
+torch.cuda.synchronize()
+ctx.profile_enable(True)
+for name in names:
+	os.environ["V2M_TRANSPOSE_PANEL"] = name
 	ts = []
-	for rep in range(4):
-		ctx.profile_reset()
-		ctx.transpose_bits_device(src.data_ptr(), hp, ep, dst.data_ptr())
-		t1 = ctx.profile_get(N.KERNEL_TRANSPOSE)[1]
-		ctx.profile_reset()
-		ctx.transpose_bits_device(dst.data_ptr(), ep, hp, back.data_ptr())
-		t2 = ctx.profile_get(N.KERNEL_TRANSPOSE)[1]
-		if rep: ts.append((t1, t2))
-	ok = torch.equal(back, src)
+	try:
+		dst.zero_(); back.zero_()
+		torch.cuda.synchronize()
+		for rep in range(4):
+			ctx.profile_reset()
+			ctx.transpose_bits_device(src.data_ptr(), hp, ep, dst.data_ptr())
+			t1 = ctx.profile_get(N.KERNEL_TRANSPOSE)[1]
+			ctx.profile_reset()
+			ctx.transpose_bits_device(dst.data_ptr(), ep, hp, back.data_ptr())
+			t2 = ctx.profile_get(N.KERNEL_TRANSPOSE)[1]
+			if rep:
+				ts.append((t1, t2))
+	except v2m.V2MError as e:
+		print("%-26s %s" % (name, e), flush=True)
+		continue
+	if want_dst is None:
+		want_dst = dst.clone()
+	ok = torch.equal(back, src) and torch.equal(dst, want_dst)
 	t1, t2 = min(a for a, _ in ts), min(b for _, b in ts)
-	print("%-5s forward (copies x edges -> edges x copies) %.3f ms = %.0f GB/s   inverse %.3f ms = %.0f GB/s   involution %s" % (shape, t1, 2 * n * 8 / t1 / 1e6, t2, 2 * n * 8 / t2 / 1e6, ok))
+	print("%-26s forward %.3f ms = %5.0f GB/s   inverse %.3f ms = %5.0f GB/s   %s" % (name, t1, 2 * n * 8 / t1 / 1e6, t2, 2 * n * 8 / t2 / 1e6, "ok" if ok else "WRONG RESULT"), flush=True)

@@ -84,11 +84,61 @@ __device__ __forceinline__ u64 wave_transpose_64x64(u64 x, int lane)
 	return x;
 }
 
+// The same butterfly with gfx950's register-to-register lane exchanges instead of ds_bpermute (which goes through the
+// LDS crossbar and costs an LDS round trip per stage): DPP quad/row permutes for distances 1, 2, 4 and 8,
+// v_permlane16_swap for 16, and for 32 a single v_permlane32_swap of the word's two halves, which IS the stage
+// (lane i's high dword and lane i + 32's low dword change places).
+template <int kDist> __device__ __forceinline__ u32 lane_xor_u32(u32 v, int lane)
+{
+	if constexpr (kDist == 1) return (u32) __builtin_amdgcn_mov_dpp((int) v, 0xB1, 0xF, 0xF, false);         // quad_perm [1,0,3,2]
+	else if constexpr (kDist == 2) return (u32) __builtin_amdgcn_mov_dpp((int) v, 0x4E, 0xF, 0xF, false);    // quad_perm [2,3,0,1]
+	else if constexpr (kDist == 4)   // i -> 7 - i (row_half_mirror), then i -> 3 - i within the quad: together i ^ 4
+		return (u32) __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int) v, 0x141, 0xF, 0xF, false), 0x1B, 0xF, 0xF, false);
+	else if constexpr (kDist == 8) return (u32) __builtin_amdgcn_mov_dpp((int) v, 0x128, 0xF, 0xF, false);   // row_ror:8
+	else {
+		static_assert(kDist == 16, "distance 32 is handled on the register pair");
+		auto const r = __builtin_amdgcn_permlane16_swap(v, v, false, false);   // r[0]: odd 16-lane rows hold their lower neighbour's value; r[1]: even rows hold their upper neighbour's
+		return (lane & 16) ? r[0] : r[1];
+	}
+}
+
+template <int kDist> __device__ __forceinline__ u64 transpose_stage(u64 x, u64 low, int lane)
+{
+	u64 const y = ((u64) lane_xor_u32<kDist>((u32) (x >> 32), lane) << 32) | lane_xor_u32<kDist>((u32) x, lane);
+	return (lane & kDist) ? ((x & ~low) | ((y & ~low) >> kDist)) : ((x & low) | ((y & low) << kDist));
+}
+
+__device__ __forceinline__ u64 wave_transpose_64x64_fast(u64 x, int lane)
+{
+	{
+		auto const r = __builtin_amdgcn_permlane32_swap((u32) x, (u32) (x >> 32), false, false);   // lanes 32..63 of the low dword <-> lanes 0..31 of the high dword
+		x = ((u64) r[1] << 32) | r[0];
+	}
+	x = transpose_stage<16>(x, 0x0000FFFF0000FFFFULL, lane);
+	x = transpose_stage<8>(x, 0x00FF00FF00FF00FFULL, lane);
+	x = transpose_stage<4>(x, 0x0F0F0F0F0F0F0F0FULL, lane);
+	x = transpose_stage<2>(x, 0x3333333333333333ULL, lane);
+	x = transpose_stage<1>(x, 0x5555555555555555ULL, lane);
+	return x;
+}
+
+// Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.  Panels that
+// are neighbours in the matrix share 128-B lines on the side whose run is shorter than a line or not line-aligned, so the
+// work items (numbered so that neighbours are consecutive) are cut into 8 contiguous chunks, one per XCD: a shared line
+// is then fetched / written back by ONE L2, by workgroups that run at about the same time.
+__device__ __forceinline__ bool xcd_chunked_item(u32 block, u64 n_items, u32 items_per_xcd, u64 &item)
+{
+	if (0 == items_per_xcd) { item = block; return item < n_items; }   // plain dispatch order (A/B switch of the tuning tools)
+	u32 const xcd = block & 7, i = block >> 3;
+	item = (u64) xcd * items_per_xcd + i;
+	return i < items_per_xcd && item < n_items;
+}
+
 // Panel of kR source row-words x kC source column groups (64*kR x 64*kC bits).  Every source column contributes
 // 8*kR contiguous bytes, every destination column receives 8*kC contiguous bytes.
 template <int kR, int kC>
 __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
-	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW)
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd)
 {
 	static_assert(kR % 4 == 0, "each of the 4 waves owns kR / 4 row-words");
 	// phase 1 view: [source column within panel = 64*kC][kR + 1]; phase 2 view: [destination column = 64*kR][kC + 1].
@@ -99,8 +149,12 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 	int const t = threadIdx.x;
 	int const lane = t & 63;
 	int const wave = t >> 6;
-	u64 const rw0 = (u64) blockIdx.x * kR;    // first source row-word
-	u64 const cg0 = (u64) blockIdx.y * kC;    // first source column group
+	u64 item;
+	if (!xcd_chunked_item(blockIdx.x, (u64) n_row_panels * n_col_panels, items_per_xcd, item)) return;   // whole workgroup
+	// the shorter dimension runs fastest: both kinds of neighbours (sharing source lines / destination lines) stay close in time
+	bool const rows_fastest = n_row_panels <= n_col_panels;
+	u64 const rw0 = (rows_fastest ? item % n_row_panels : item / n_col_panels) * kR;    // first source row-word
+	u64 const cg0 = (rows_fastest ? item / n_row_panels : item % n_col_panels) * kC;    // first source column group
 	u64 const n_cols = DW * 64;
 
 	// load: kR consecutive lanes fetch one column's 8*kR contiguous bytes
@@ -152,7 +206,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 constexpr int kTsR = 16, kTsC = 16;
 
 __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
-	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW)
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd)
 {
 	constexpr int kA = kTsR / 4;                         // row-words per wave
 	__shared__ u64 in[2][64][kTsR + 1];
@@ -161,8 +215,11 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 	int const t = threadIdx.x;
 	int const lane = t & 63;
 	int const wave = t >> 6;
-	u64 const rw0 = (u64) blockIdx.x * kTsR;
-	u64 const cg0 = (u64) blockIdx.y * kTsC;
+	u64 item;
+	if (!xcd_chunked_item(blockIdx.x, (u64) n_row_panels * n_col_panels, items_per_xcd, item)) return;   // whole workgroup
+	bool const rows_fastest = n_row_panels <= n_col_panels;
+	u64 const rw0 = (rows_fastest ? item % n_row_panels : item / n_col_panels) * kTsR;
+	u64 const cg0 = (rows_fastest ? item / n_row_panels : item % n_col_panels) * kTsC;
 	u64 const n_cols = DW * 64;
 
 	// one sub-panel = 64 columns x 16 row-words; 16 consecutive lanes fetch one column's 128 contiguous bytes.
@@ -215,6 +272,142 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 				if (cg0 + cw < DW)
 					dst[(rw * 64 + dcol) * DW + cg0 + cw] = slab[wave][dcol][cw];
 			}
+		}
+	}
+}
+
+
+// Sector-aligned streaming transpose ("ring" kernel).
+//
+// What the two kernels above lose at the reference's own padding (dimensions that are multiples of 64 and nothing
+// more, transpose_matrix.cc:53-54) is alignment: a destination column starts at byte 8 * r * DW, so their 64-B / 128-B
+// runs begin at arbitrary 8-byte offsets, straddle 64-B DRAM sectors and 128-B lines, and leave the L2s writing most
+// sectors in two masked pieces.  Here the destination side is addressed as the flat word array it is: a workgroup
+// owns kR source row-words and streams along a span of source column groups, one group (64 columns) per step; each wave
+// transposes its tiles in registers (lane = destination row) and drops every lane's word into a wave-private LDS ring of
+// kS words per destination row, at slot (flat word index mod kS).  A row whose slot kS - 1 has just been written owns a
+// complete, naturally aligned kS * 8-byte sector: kS consecutive lanes store it with one coalesced piece of a store
+// instruction.  Rows reach their boundaries at different steps (row r's phase is r * DW mod kS), so every step a few
+// rows flush -- 64 / kS of them when DW is odd -- and the stores spread evenly over the stream.  Which rows: the set is an
+// arithmetic progression of lanes (a solution set of j * DW = c mod kS), read off the ballot.
+//
+// Span edges: row r's window is the span moved back to r's nearest sector boundary, so that windows of neighbouring
+// spans meet on sector boundaries; the workgroup therefore starts kS - 1 groups early and a row simply does not store
+// sectors outside its window.  Only the two ends of a destination row (where its first / last sector is shared with
+// the neighbouring rows) are written as partial sectors.
+//
+// Source side: the kR-word runs (128 B for kR = 16) of a column start at arbitrary 8-byte offsets too, so vertically
+// adjacent panels share their first / last line; xcd_chunked_item() puts them on one XCD at the same time and the
+// shared lines are fetched from HBM once.  Source words are prefetched kD steps ahead in registers and staged through
+// a double-buffered LDS tile (one barrier per step); the ring needs no barrier (LDS operations of one wave execute in order).
+// ---------------------------------------------------------------------------------------------
+template <int kR, int kW, int kS, int kD, bool kFastLanes>
+__global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW,
+	u32 n_panels, u32 n_spans, u32 span_groups /* multiple of kS */, u32 items_per_xcd, u32 panel_fastest)
+{
+	static_assert(kR % kW == 0 && (kS & (kS - 1)) == 0 && kS >= 2 && kS <= 16 && kD % 2 == 0, "geometry");
+	constexpr int kA = kR / kW;              // row-words (tiles per step) per wave; also source words per thread per step
+	constexpr int kT = 64 * kW;
+	constexpr int kLgS = kS == 2 ? 1 : kS == 4 ? 2 : kS == 8 ? 3 : 4;
+	constexpr int kSectorsPerStore = 64 / kS;
+	__shared__ u64 stage[2][64][kR + 1];     // [source column within the group][row-word], odd stride: conflict-free column reads
+	__shared__ u64 ring[kW][kA][64][kS + 1]; // [wave][tile][destination row within the tile][slot]
+
+	u64 item;
+	if (!xcd_chunked_item(blockIdx.x, (u64) n_panels * n_spans, items_per_xcd, item)) return;   // whole workgroup
+	u32 const panel = panel_fastest ? (u32) (item % n_panels) : (u32) (item / n_spans);
+	u32 const span = panel_fastest ? (u32) (item / n_panels) : (u32) (item % n_spans);
+
+	int const t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	u64 const rw0 = (u64) panel * kR;
+	u64 const span_begin = (u64) span * span_groups;                                   // nominal window [span_begin, span_end)
+	u64 const span_end = (span_begin + span_groups < DW) ? span_begin + span_groups : DW;
+	bool const first_span = 0 == span, last_span = span_end == DW;
+	u32 const cg_lo = first_span ? 0u : (u32) span_begin - (kS - 1);
+	u32 const n_steps = (u32) span_end - cg_lo;
+
+	// source words of this thread: column (t + kT * k) / kR of the group, row-word (t + kT * k) % kR of the panel
+	u64 src_off[kA];
+	bool src_ok[kA];
+#pragma unroll
+	for (int k = 0; k < kA; ++k) {
+		int const idx = t + kT * k;
+		src_off[k] = (u64) (idx / kR) * SW + rw0 + idx % kR;
+		src_ok[k] = rw0 + idx % kR < SW;
+	}
+	u64 pf[kD][kA];
+	auto const fetch = [&](u64 (&r)[kA], u32 cg) {
+		u64 const *const base = src + (u64) cg * 64 * SW;
+#pragma unroll
+		for (int k = 0; k < kA; ++k) r[k] = src_ok[k] ? base[src_off[k]] : 0;
+	};
+	auto const stash = [&](int buf, u64 const (&r)[kA]) {
+#pragma unroll
+		for (int k = 0; k < kA; ++k) {
+			int const idx = t + kT * k;
+			stage[buf][idx / kR][idx % kR] = r[k];
+		}
+	};
+
+	// destination rows of this wave's tiles: tile a = row-word rw0 + kA * wave + a, lane = row within it
+	u64 tile_base[kA];                        // flat destination word index of the tile's row 0, column group 0
+	u64 const lane_off = (u64) lane * DW;
+#pragma unroll
+	for (int a = 0; a < kA; ++a) tile_base[a] = (rw0 + kA * wave + a) * 64 * DW;
+
+	auto const compute = [&](u32 cg, int buf) {
+		u64 tv[kA];
+#pragma unroll
+		for (int a = 0; a < kA; ++a) tv[a] = stage[buf][lane][kA * wave + a];
+#pragma unroll
+		for (int a = 0; a < kA; ++a) tv[a] = kFastLanes ? wave_transpose_64x64_fast(tv[a], lane) : wave_transpose_64x64(tv[a], lane);
+		bool done[kA];
+#pragma unroll
+		for (int a = 0; a < kA; ++a) {
+			u32 const slot = ((u32) tile_base[a] + (u32) lane_off + cg) & (kS - 1);
+			ring[wave][a][lane][slot] = tv[a];
+			done[a] = slot == kS - 1 || cg + 1 == (u32) DW;
+		}
+		__builtin_amdgcn_wave_barrier();
+#pragma unroll
+		for (int a = 0; a < kA; ++a) {
+			if (rw0 + kA * wave + a >= SW) continue;                                   // wave-uniform: row-words past the matrix
+			u64 const mask = __ballot(done[a]);
+			if (0 == mask) continue;
+			// the rows that completed a sector at this step: lanes j0, j0 + stride, ... (n of them, n a power of two)
+			u32 const n = (u32) __builtin_popcountll(mask), j0 = (u32) __builtin_ctzll(mask);
+			u32 const lg_stride = 6 - (31 - (u32) __builtin_clz(n));
+			u32 const w = lane & (kS - 1);
+			for (u32 f = 0; f * kSectorsPerStore < n; ++f) {
+				u32 const idx = f * kSectorsPerStore + (lane >> kLgS);
+				if (idx >= n) continue;
+				u32 const row = j0 + (idx << lg_stride);
+				u64 const row_base = tile_base[a] + (u64) row * DW;                     // flat index of the row's word 0
+				u64 const g = row_base + cg;
+				u32 const slot = (u32) g & (kS - 1);
+				u64 const g0 = g - slot;                                                // the sector's first word
+				bool ok = w <= slot && g0 + w >= row_base;                             // row end / row start: the rest belongs to the neighbouring rows
+				if (!first_span) ok = ok && g0 >= ((row_base + span_begin) & ~(u64) (kS - 1));
+				if (!last_span) ok = ok && g0 < ((row_base + span_end) & ~(u64) (kS - 1));
+				if (ok) dst[g0 + w] = ring[wave][a][row][w];
+			}
+		}
+	};
+
+#pragma unroll
+	for (int j = 0; j < kD; ++j)
+		if ((u32) j < n_steps) fetch(pf[j], cg_lo + j);
+	stash(0, pf[0]);
+	for (u32 base = 0; base < n_steps; base += kD) {
+#pragma unroll
+		for (int j = 0; j < kD; ++j) {
+			u32 const st = base + j;
+			if (st >= n_steps) break;
+			__syncthreads();                       // stage[j & 1] is complete; everyone is done with the other buffer
+			if (st + kD < n_steps) fetch(pf[j], cg_lo + st + kD);   // pf[j] was stashed during the previous step
+			compute(cg_lo + st, j & 1);
+			if (st + 1 < n_steps) stash((j + 1) & 1, pf[(j + 1) % kD]);
 		}
 	}
 }

@@ -94,8 +94,8 @@ struct v2m_ctx {
 	dev_buf owned_paths;
 	u64 path_rows{}, path_cols{};
 
-	struct transpose_pick { u64 rows, cols; bool stream; };
-	std::vector<transpose_pick> transpose_choice;   // per matrix shape: which transpose kernel measured faster
+	struct transpose_pick { u64 rows, cols; std::string kernel; };
+	std::vector<transpose_pick> transpose_choice;   // per matrix shape: which transpose kernel measured fastest
 
 	// store flavour of the aligned splice: -1 = not calibrated yet, 0 = plain, 1 = nontemporal
 	int store_mode{-1};
@@ -167,48 +167,129 @@ int upload_vec(v2m_ctx *ctx, dev_buf &dst, std::vector<T> const &src, size_t min
 }
 
 
-template <int kR, int kC>
-int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
+// Events that destroy themselves, and a guard that puts ctx->profiling back: the calibration paths below return early
+// on any HIP error.
+struct scoped_events {
+	std::vector<hipEvent_t> ev;
+	~scoped_events() { for (auto e : ev) (void) hipEventDestroy(e); }
+	hipError_t create(std::size_t n)
+	{
+		for (std::size_t i(0); i < n; ++i) {
+			hipEvent_t e{};
+			hipError_t const st(hipEventCreate(&e));
+			if (hipSuccess != st) return st;
+			ev.push_back(e);
+		}
+		return hipSuccess;
+	}
+	hipEvent_t operator[](std::size_t i) const { return ev[i]; }
+};
+
+struct scoped_profiling_off {
+	v2m_ctx *ctx;
+	bool was;
+	explicit scoped_profiling_off(v2m_ctx *c) : ctx(c), was(c->profiling) { c->profiling = false; }
+	~scoped_profiling_off() { ctx->profiling = was; }
+};
+
+
+// 1-D grids in XCD chunks (kernels.hpp: xcd_chunked_item); xcd = false keeps the plain dispatch order (tuning A/B).
+struct xcd_grid { unsigned blocks; u32 items_per_xcd; };
+
+bool make_xcd_grid(u64 n_items, bool xcd, xcd_grid &g)
 {
-	u64 const gx((SW + kR - 1) / kR), gy((DW + kC - 1) / kC);
-	if (gy > 65535 || gx > 0x7FFFFFFFu)
+	u64 const per((n_items + 7) / 8), blocks(xcd ? per * 8 : n_items);
+	if (0 == n_items || blocks > 0x7FFFFFFFull) return false;
+	g.blocks = unsigned(blocks);
+	g.items_per_xcd = xcd ? u32(per) : 0u;
+	return true;
+}
+
+template <int kR, int kC>
+int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, bool xcd)
+{
+	u64 const P((SW + kR - 1) / kR), Q((DW + kC - 1) / kC);
+	xcd_grid g;
+	if (P > 0xFFFFFFFFull || Q > 0xFFFFFFFFull || !make_xcd_grid(P * Q, xcd, g))
 		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch (%llu x %llu bits)", (unsigned long long) (SW * 64), (unsigned long long) (DW * 64));
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL((v2m::transpose_bits_kernel<kR, kC>), dim3((unsigned) gx, (unsigned) gy), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW);
+		hipLaunchKernelGGL((v2m::transpose_bits_kernel<kR, kC>), dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, u32(P), u32(Q), g.items_per_xcd);
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
 }
 
-int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
+int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, bool xcd)
 {
-	u64 const gx((SW + v2m::kTsR - 1) / v2m::kTsR), gy((DW + v2m::kTsC - 1) / v2m::kTsC);
-	if (gy > 65535 || gx > 0x7FFFFFFFu) return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
+	u64 const P((SW + v2m::kTsR - 1) / v2m::kTsR), Q((DW + v2m::kTsC - 1) / v2m::kTsC);
+	xcd_grid g;
+	if (P > 0xFFFFFFFFull || Q > 0xFFFFFFFFull || !make_xcd_grid(P * Q, xcd, g)) return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL(v2m::transpose_bits_stream_kernel, dim3((unsigned) gx, (unsigned) gy), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW);
+		hipLaunchKernelGGL(v2m::transpose_bits_stream_kernel, dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, u32(P), u32(Q), g.items_per_xcd);
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
 }
 
-int launch_transpose_named(v2m_ctx *ctx, std::string const &shape, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
+// The sector-aligned streaming kernel: kR row-words per workgroup on kW waves, kS-word sectors, kD steps of prefetch,
+// spans of `span_groups` column groups (0 = default).
+template <int kR, int kW, int kS, int kD, bool kFast>
+int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, u64 span_groups, bool xcd)
 {
-	if (shape == "stream16") return launch_transpose_stream(ctx, d_src, SW, DW, d_dst);
-	if (shape == "4x16") return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, d_dst);
-	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, d_dst);
-	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, d_dst);
-	if (shape == "4x8") return launch_transpose_shape<4, 8>(ctx, d_src, SW, DW, d_dst);
-	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, d_dst);
-	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, d_dst);
-	return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, d_dst);
+	if (0 == span_groups) span_groups = 64;
+	span_groups = (span_groups + kS - 1) / kS * kS;
+	u64 const P((SW + kR - 1) / kR), NS((DW + span_groups - 1) / span_groups);
+	xcd_grid g;
+	if (P > 0xFFFFFFFFull || NS > 0xFFFFFFFFull || span_groups > 0x7FFFFFFFull || DW > 0xFFFFFFFFull || !make_xcd_grid(P * NS, xcd, g))
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
+	{
+		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
+		hipLaunchKernelGGL((v2m::transpose_bits_ring_kernel<kR, kW, kS, kD, kFast>), dim3(g.blocks), dim3(64 * kW), 0, ctx->stream,
+			d_src, d_dst, SW, DW, u32(P), u32(NS), u32(span_groups), g.items_per_xcd, u32(P <= NS ? 1 : 0));
+	}
+	V2M_HIP_TRY(ctx, hipGetLastError());
+	return V2M_OK;
 }
 
-// Two kernels implement the transpose: the 8x8 LDS panel and the streaming 16x16 one.  Which is faster depends on
-// the matrix shape (tools/tune_transpose.py: 5056 x 1M bits -> streaming 0.45 ms vs panel 0.60 ms; 20032 x 6.2M bits
-// -> panel 11.3 ms vs streaming 13.2 ms), so matrices of at least 32 MiB are timed once per shape and context with both
-// (the result is the same either way) and the faster kernel is remembered.  V2M_TRANSPOSE_PANEL forces one.
+// Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "ring:R,W,S,D[,K[,slow]]" (slow = ds_bpermute
+// butterfly); a trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks.
+int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
+{
+	bool xcd(true);
+	if (shape.size() > 3 && 0 == shape.compare(shape.size() - 3, 3, "/rr")) { xcd = false; shape.resize(shape.size() - 3); }
+	if (0 == shape.compare(0, 5, "ring:")) {
+		int R(0), W(0), S(0), D(0), K(0);
+		char tail[16] = "";
+		int const got(std::sscanf(shape.c_str() + 5, "%d,%d,%d,%d,%d,%15s", &R, &W, &S, &D, &K, tail));
+		if (got < 4) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
+		bool const fast(0 != std::strcmp(tail, "slow"));
+#define V2M_RING(r, w, s, d)                                                                                         \
+		if (R == r && W == w && S == s && D == d)                                                                    \
+			return fast ? launch_transpose_ring<r, w, s, d, true>(ctx, d_src, SW, DW, d_dst, u64(K), xcd)              \
+			            : launch_transpose_ring<r, w, s, d, false>(ctx, d_src, SW, DW, d_dst, u64(K), xcd);
+		V2M_RING(16, 8, 8, 4) V2M_RING(16, 4, 8, 4) V2M_RING(16, 16, 8, 4) V2M_RING(16, 8, 8, 8) V2M_RING(16, 16, 8, 8)
+		V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4) V2M_RING(8, 4, 8, 4) V2M_RING(8, 8, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 4, 8)
+#undef V2M_RING
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not instantiated", shape.c_str());
+	}
+	if (shape == "stream16") return launch_transpose_stream(ctx, d_src, SW, DW, d_dst, xcd);
+	if (shape == "4x16") return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, d_dst, xcd);
+	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, d_dst, xcd);
+	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, d_dst, xcd);
+	if (shape == "4x8") return launch_transpose_shape<4, 8>(ctx, d_src, SW, DW, d_dst, xcd);
+	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, d_dst, xcd);
+	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, d_dst, xcd);
+	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, d_dst, xcd);
+	return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "unknown transpose kernel '%s'", shape.c_str());
+}
+
+// Several kernels implement the transpose; which is fastest depends on the matrix shape, so matrices of at least 32 MiB
+// are timed once per shape and context with each candidate (the result is the same either way) and the fastest is
+// remembered.  V2M_TRANSPOSE_PANEL forces one; V2M_TRANSPOSE_CANDIDATES (comma-free list separated by ';') replaces the list.
+char const *const kTransposeCandidates[] = {"8x8", "stream16"};
+
 int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst)
 {
 	u64 const SW(n_rows / 64), DW(n_cols / 64);
@@ -216,38 +297,52 @@ int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64
 	if (e && *e) return launch_transpose_named(ctx, e, d_src, SW, DW, d_dst);
 	if (SW * DW * 512 < (u64(32) << 20)) return launch_transpose_named(ctx, "8x8", d_src, SW, DW, d_dst);
 	for (auto const &c : ctx->transpose_choice)
-		if (c.rows == n_rows && c.cols == n_cols) return launch_transpose_named(ctx, c.stream ? "stream16" : "8x8", d_src, SW, DW, d_dst);
+		if (c.rows == n_rows && c.cols == n_cols) return launch_transpose_named(ctx, c.kernel, d_src, SW, DW, d_dst);
 
-	hipEvent_t ev[3];
-	for (auto &x : ev) V2M_HIP_TRY(ctx, hipEventCreate(&x));
-	float t[2] = {0, 0};
-	bool const was_profiling(ctx->profiling);
-	ctx->profiling = false;   // the calibration launches are not the caller's
-	int rc(V2M_OK);
-	for (int rep(0); rep < 2 && V2M_OK == rc; ++rep) {   // second round's times count (first touches the pages)
-		V2M_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
-		rc = launch_transpose_named(ctx, "8x8", d_src, SW, DW, d_dst);
-		V2M_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
-		if (V2M_OK == rc) rc = launch_transpose_named(ctx, "stream16", d_src, SW, DW, d_dst);
-		V2M_HIP_TRY(ctx, hipEventRecord(ev[2], ctx->stream));
-		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-		V2M_HIP_TRY(ctx, hipEventElapsedTime(&t[0], ev[0], ev[1]));
-		V2M_HIP_TRY(ctx, hipEventElapsedTime(&t[1], ev[1], ev[2]));
+	std::vector<std::string> names;
+	if (char const *list = std::getenv("V2M_TRANSPOSE_CANDIDATES")) {
+		std::string cur;
+		for (char const *p(list); ; ++p) {
+			if (';' == *p || 0 == *p) { if (!cur.empty()) names.push_back(cur); cur.clear(); if (0 == *p) break; }
+			else cur.push_back(*p);
+		}
 	}
-	ctx->profiling = was_profiling;
-	for (auto &x : ev) (void) hipEventDestroy(x);
-	if (V2M_OK != rc) return rc;
-	bool const stream(t[1] < t[0]);
-	ctx->transpose_choice.push_back({n_rows, n_cols, stream});
-	char buf[160];
-	std::snprintf(buf, sizeof(buf), "transpose %llux%llu bits: %s kernel (panel 8x8 %.3f ms, streaming 16x16 %.3f ms)",
-		(unsigned long long) n_rows, (unsigned long long) n_cols, stream ? "streaming" : "panel", t[0], t[1]);
+	if (names.empty()) names.assign(std::begin(kTransposeCandidates), std::end(kTransposeCandidates));
+
+	std::vector<float> best(names.size(), 1e30f);
+	{
+		scoped_events ev;
+		V2M_HIP_TRY(ctx, ev.create(names.size() + 1));
+		scoped_profiling_off const quiet(ctx);   // the calibration launches are not the caller's
+		for (int rep(0); rep < 2; ++rep) {        // the second round's times count (the first touches the pages)
+			V2M_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+			for (std::size_t k(0); k < names.size(); ++k) {
+				if (int const rc = launch_transpose_named(ctx, names[k], d_src, SW, DW, d_dst)) return rc;
+				V2M_HIP_TRY(ctx, hipEventRecord(ev[k + 1], ctx->stream));
+			}
+			V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			for (std::size_t k(0); k < names.size(); ++k) {
+				float ms(0);
+				V2M_HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
+				if (rep) best[k] = ms;
+			}
+		}
+	}
+	std::size_t const pick(std::size_t(std::min_element(best.begin(), best.end()) - best.begin()));
+	ctx->transpose_choice.push_back({n_rows, n_cols, names[pick]});
+	std::string note("transpose " + std::to_string(n_rows) + "x" + std::to_string(n_cols) + " bits: " + names[pick] + " (");
+	for (std::size_t k(0); k < names.size(); ++k) {
+		char buf[64];
+		std::snprintf(buf, sizeof(buf), "%s%s %.3f ms", k ? ", " : "", names[k].c_str(), best[k]);
+		note += buf;
+	}
+	note += ")";
 	if (ctx->info.size() > 2000) ctx->info.clear();
 	if (!ctx->info.empty()) ctx->info += "; ";
-	ctx->info += buf;
+	ctx->info += note;
 	// the calibration already produced the result; run the chosen kernel once more under the caller's profiling so
 	// that its launch is accounted for like any other
-	return launch_transpose_named(ctx, stream ? "stream16" : "8x8", d_src, SW, DW, d_dst);
+	return launch_transpose_named(ctx, names[pick], d_src, SW, DW, d_dst);
 }
 
 
