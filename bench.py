@@ -14,10 +14,14 @@ Haplotypes shard across ranks in blocks of 8 chromosome copies (whole bytes of t
 reference and graph replicated; there is no collective on the data path.  The total work is the
 named config's and is fixed as N grows, hence "scaling": "strong".
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).  Besides the contract's fields it carries
+`roofline` (the dominant kernel, splice_aligned_kernel), `roofline_transpose` (the transpose at the reference's own
+64-bit padding, forward inside the timed region; inverse and a 1024-bit-padded matrix measured after it), `unaligned`
+(a second, separately timed leg: the same rows without '-' padding), `parity` and `cpu_baseline`.
 """
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -31,10 +35,22 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+KERNEL_SOURCES = ("vcf2multialign_amd/csrc/kernels.hpp", "vcf2multialign_amd/csrc/v2m_hip.hip")
 
 
 def log(*a):
 	print(*a, file=sys.stderr, flush=True)
+
+
+def git_blob_hash(path):
+	"""What `git hash-object` prints for the file: the stamp that ties a PMC traffic figure to the kernel sources it was measured on."""
+	with open(path, "rb") as f:
+		data = f.read()
+	return hashlib.sha1(b"blob %d\0" % len(data) + data).hexdigest()
+
+
+def kernel_source_stamp():
+	return {p: git_blob_hash(os.path.join(ROOT, p)) for p in KERNEL_SOURCES}
 
 
 def _hip_runtime():
@@ -51,7 +67,7 @@ def _hip_memset(torch, ptr, nbytes):
 	assert rc == 0, "hipMemsetAsync failed"
 
 
-def _device_bytes(torch, ptr, nbytes):
+def _device_bytes(ptr, nbytes):
 	import ctypes
 	rt = _hip_runtime()
 	rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
@@ -71,9 +87,11 @@ def main():
 	ap.add_argument("--batch-gb", type=float, default=64.0, help="size of the reused device output buffer when --batch-rows is 0: launches that write a ~64-GB address range reach the full HBM write rate (DESIGN.md section 4)")
 	ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal of N > 1)")
 	ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this HIP device")
-	ap.add_argument("--output-candidates", type=int, default=4, help="device buffers v2m_alloc_output may hold at once to choose the output buffer from (as many as fit are tried; 1 = plain allocation)")
+	ap.add_argument("--output-candidates", type=int, default=3, help="only where the output buffer cannot be mapped from physical chunks: hipMalloc'ed buffers v2m_alloc_output may hold at once to choose from")
 	ap.add_argument("--cpu-baseline-rows", type=int, default=320, help="haplotypes (plus REF) the CPU oracle is timed on (320 rows of config 3 = 32 Gbases, about 11 s on one core); 0 disables")
-	ap.add_argument("--verify-rows", type=int, default=3, help="rows of the last batch checked against the CPU oracle after timing; 0 disables")
+	ap.add_argument("--verify-rows", type=int, default=1, help="after timing: rows per batch (every batch) checked against the CPU oracle, plus REF and the last batch's ragged final group; 0 disables")
+	ap.add_argument("--unaligned-rows", type=int, default=256, help="rows of the separately timed --unaligned leg (rank 0, after the main timing); 0 disables")
+	ap.add_argument("--transpose-extras", type=int, default=1, help="after timing, also measure the inverse transpose and a 1024-bit-padded matrix (rank 0); 0 disables")
 	args = ap.parse_args()
 
 	rank = int(os.environ.get("RANK", "0"))
@@ -114,7 +132,7 @@ def main():
 	g = ds.graph
 	L, R, NN, E = g.aligned_length, len(ds.reference), g.node_count, g.edge_count
 	H = ds.n_copies
-	Ep = ds.path_rows
+	Ep = ds.path_rows          # 64 * ceil(E / 64): the reference's own padding (variant_graph.cc:449)
 	if rank == 0:
 		log("[bench] %s: R=%d variants/edges=%d nodes=%d L=%d copies=%d (generated in %.1fs)" % (args.config, R, E, NN, L, H, time.time() - t0))
 
@@ -122,34 +140,33 @@ def main():
 	ctx.upload_graph(g, ds.reference)
 	pitch = ctx.min_row_pitch
 
+	# this rank's copies, zero-padded to a multiple of 64 rows of the transpose input (variant_graph.cc:277) -- nothing more
 	c0, c1, hp_local = shard_copies(H, world, rank)
-	# Matrix dimensions padded to multiples of 1024 bits: every column then starts on a 128-B line and the transpose moves
-	# whole lines (0.31 ms instead of 0.43 ms on the config-3 matrix).  The reference pads to 64 (variant_graph.cc:277,449);
-	# the ABI takes any multiple of 64, padding rows and columns are zero.
-	pad1024 = lambda n: (n + 1023) // 1024 * 1024
-	hp_local = pad1024(hp_local) if hp_local else 0
-	Ep_alg = Ep            # 64 * ceil(E / 64): what the algorithmic-byte formula and the CPU oracle use
-	Ep = pad1024(Ep)
 	n_local_copies = c1 - c0
 	rows = ([v2m.PLOIDY_MAX] if rank == 0 else []) + list(range(n_local_copies))   # local copy indices into this rank's matrix
 	n_rows = len(rows)
 	total_rows = H + 1
 
-	# equal-sized batches of at most --batch-rows rows (5009 rows -> 10 x 501 rather than 9 x 512 + 401)
+	# equal-sized batches of at most --batch-rows rows (5009 rows -> 8 x 627 rather than 7 x 640 + 529)
 	max_batch_rows = args.batch_rows if args.batch_rows > 0 else max(1, int(args.batch_gb * 1e9) // pitch)
 	n_batches = max(1, -(-n_rows // max(1, max_batch_rows)))
 	batch_rows = max(1, -(-n_rows // n_batches))
-	# Output buffer: placement matters on this hardware, so the library picks it by measurement.
 	out_bytes = batch_rows * pitch
-	out_ptr = ctx.alloc_output(out_bytes, candidates=args.output_candidates)
+	out_ptr = ctx.alloc_output(out_bytes, candidates=args.output_candidates)   # mapped from 512-MB physical chunks
+
+	def make_paths(n_rows_bits, n_cols_bits, copy_base, copy_end):
+		"""paths_by_edge_and_chrom_copy of the given copies in HBM (+ an equally sized destination)."""
+		words = n_cols_bits // 64 * n_rows_bits
+		src = torch.empty(max(words, 1), dtype=torch.int64, device=dev)
+		dst = torch.empty(max(words, 1), dtype=torch.int64, device=dev)
+		torch.cuda.synchronize()
+		if n_rows_bits:
+			ds.fill_paths_device(ctx.stream, src.data_ptr(), thr.data_ptr(), copy_base=copy_base, n_rows=n_rows_bits, n_cols=n_cols_bits, copy_end=copy_end)
+		ctx.synchronize()
+		return src, dst
+
 	thr = torch.from_numpy(ds.edge_thresholds.astype(np.int64)).to(torch.int32).to(dev) if E else torch.zeros(1, dtype=torch.int32, device=dev)
-	words = Ep // 64 * hp_local
-	paths_src = torch.empty(max(words, 1), dtype=torch.int64, device=dev)   # paths_by_edge_and_chrom_copy (this rank's copies x Ep)
-	paths_dst = torch.empty(max(words, 1), dtype=torch.int64, device=dev)   # paths_by_chrom_copy_and_edge (Ep x this rank's copies)
-	torch.cuda.synchronize()
-	if hp_local:
-		ds.fill_paths_device(ctx.stream, paths_src.data_ptr(), thr.data_ptr(), copy_base=c0, n_rows=hp_local, n_cols=Ep, copy_end=c1)
-	ctx.synchronize()
+	paths_src, paths_dst = make_paths(hp_local, Ep, c0, c1)
 
 	batches = [v2m.RowBatch(rows[i:i + batch_rows]) for i in range(0, n_rows, batch_rows)]
 
@@ -160,15 +177,12 @@ def main():
 		for b in batches:
 			ctx.splice_rows_device(b, out_ptr, pitch)
 
-	def fence():
-		ctx.synchronize()
-		torch.cuda.synchronize()
-		if world > 1:
-			dist.barrier()
-
 	for _ in range(args.warmup):
 		step()
-	fence()
+	ctx.synchronize()
+	torch.cuda.synchronize()
+	if world > 1:
+		dist.barrier()
 	ctx.profile_enable(True)
 	ctx.profile_reset()
 	t_begin = time.perf_counter()
@@ -188,13 +202,12 @@ def main():
 	if rank == 0 and os.environ.get("V2M_BENCH_LOG_LAUNCHES"):
 		log("[bench] splice launches (ms): " + " ".join("%.2f" % x for x in per_launch))
 	_, resolve_ms = ctx.profile_get(N.KERNEL_RESOLVE)
-	_, transpose_ms = ctx.profile_get(N.KERNEL_TRANSPOSE)
+	transpose_launches, transpose_ms = ctx.profile_get(N.KERNEL_TRANSPOSE)
 	label_bytes = len(g.label_bytes)
 	# algorithmic bytes of one launch over Hb rows (SURVEY.md 8d / BASELINE.md):
 	#   Hb*L + Hb*Ep/8 + R + 24*N + 8*E + sum|label|
-	alg_bytes_total = 0
-	for b in batches:
-		alg_bytes_total += b.n_rows * L + b.n_rows * Ep_alg // 8 + R + 24 * NN + 8 * E + label_bytes
+	shared_bytes = R + 24 * NN + 8 * E + label_bytes
+	alg_bytes_total = sum(b.n_rows * L + b.n_rows * Ep // 8 + shared_bytes for b in batches)
 	alg_bytes_per_launch = alg_bytes_total / max(1, len(batches))
 	avg_launch_s = (splice_ms / 1e3) / max(1, launches)
 	achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
@@ -202,13 +215,17 @@ def main():
 	value = total_rows * L * args.steps / elapsed / 1e9
 
 	# HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
-	# (profiles/pmc_traffic.json); it is only quoted when the run matches the profiled configuration.
+	# (profiles/pmc_traffic.json).  It is quoted only for the run it was measured on: same config, rows per launch and GPU
+	# count, and the kernel sources (git blob hashes) unchanged since.
 	traffic, traffic_source = None, None
 	try:
 		with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
 			rec = json.load(f).get(args.config)
 		if rec and rec["batch_rows"] == batch_rows and rec["n_gpus"] == world:
-			traffic, traffic_source = rec["hbm_bytes_per_launch"], rec["source"]
+			if rec.get("kernel_sources") == kernel_source_stamp():
+				traffic, traffic_source = rec["hbm_bytes_per_launch"], rec["source"]
+			else:
+				traffic_source = "stale: %s was measured on other kernel sources" % rec["source"]
 	except (OSError, ValueError, KeyError):
 		pass
 
@@ -229,6 +246,7 @@ def main():
 			"workload": "%s: synthetic %d bp reference, %d variant records (%d ALT edges), %d diploid samples = %d haplotype rows + REF, --haplotypes aligned A2M, L=%d"
 				% (args.config, R, ds.n_variants, E, ds.samples, H, L),
 			"rows_total": total_rows, "aligned_length": L, "batch_rows": batch_rows,
+			"path_matrix": "%d x %d bits per rank: this rank's copies x ALT edges, both padded to multiples of 64 as in the reference (variant_graph.cc:277,449), nothing more" % (hp_local, Ep),
 			"sharding": "contiguous chromosome copies per rank (multiples of 8), graph + reference replicated, no collective",
 			"tuning": ctx.info,
 		},
@@ -240,6 +258,48 @@ def main():
 			"other_kernels_ms_per_step": {"resolve_effective_edges_kernel": round(resolve_ms / args.steps, 3), "transpose_bits_kernel": round(transpose_ms / args.steps, 3)},
 		},
 	}
+
+	# ---- the transpose, at the reference's padding: algorithmic 2 * Hp * Ep / 8 bytes per call -----------------------
+	tr_bytes = 2 * hp_local * Ep // 8
+	if transpose_launches:
+		t_ms = transpose_ms / transpose_launches
+		result["roofline_transpose"] = {
+			"bound": "hbm", "kernel": "transpose_bits (v2m_transpose_bits_device; the kernel is chosen per matrix shape by measurement, see config.tuning)",
+			"matrix_bits": [hp_local, Ep], "algorithmic_bytes": tr_bytes, "launches": transpose_launches,
+			"avg_launch_ms": round(t_ms, 4), "achieved": round(tr_bytes / t_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+			"frac": round(tr_bytes / t_ms / 1e6 / HBM_PEAK_GBS, 4),
+		}
+
+	def time_transpose(src_ptr, n_r, n_c, dst_ptr, reps=5):
+		ctx.transpose_bits_device(src_ptr, n_r, n_c, dst_ptr)   # first call of a shape: the library times its candidates
+		ctx.synchronize()
+		ctx.profile_enable(True)
+		ctx.profile_reset()
+		for _ in range(reps):
+			ctx.transpose_bits_device(src_ptr, n_r, n_c, dst_ptr)
+		n, ms = ctx.profile_get(N.KERNEL_TRANSPOSE)
+		ctx.profile_enable(False)
+		return ms / max(1, n)
+
+	if rank == 0 and args.transpose_extras and hp_local:
+		back = torch.empty_like(paths_src)
+		inv_ms = time_transpose(paths_dst.data_ptr(), Ep, hp_local, back.data_ptr())
+		involution = bool(torch.equal(back, paths_src))
+		del back
+		pad1024 = lambda n: (n + 1023) // 1024 * 1024
+		hp_p, ep_p = pad1024(hp_local), pad1024(Ep)
+		p_src, p_dst = make_paths(hp_p, ep_p, c0, c1)
+		fwd_p = time_transpose(p_src.data_ptr(), hp_p, ep_p, p_dst.data_ptr())
+		inv_p = time_transpose(p_dst.data_ptr(), ep_p, hp_p, p_src.data_ptr())
+		del p_src, p_dst
+		gbs = lambda nbytes, ms: round(nbytes / ms / 1e6, 1)
+		result.setdefault("roofline_transpose", {})["after_timing"] = {
+			"inverse_ms": round(inv_ms, 4), "inverse_GBs": gbs(tr_bytes, inv_ms), "inverse_frac": round(tr_bytes / inv_ms / 1e6 / HBM_PEAK_GBS, 4), "involution_bit_exact": involution,
+			"padded_1024": {"matrix_bits": [hp_p, ep_p], "forward_ms": round(fwd_p, 4), "forward_GBs": gbs(2 * hp_p * ep_p // 8, fwd_p), "inverse_ms": round(inv_p, 4), "inverse_GBs": gbs(2 * hp_p * ep_p // 8, inv_p)},
+		}
+		if not involution:
+			log("[bench] PARITY FAILURE: transpose(transpose(m)) != m")
+		ctx.set_paths_device(paths_dst.data_ptr(), Ep, hp_local)
 
 	# Context for the roofline number: what a plain device memset of the very same output buffer reaches in this
 	# process (the achievable write rate varies by +-10 % between processes / boxes).
@@ -254,39 +314,111 @@ def main():
 			fills.append(ev0.elapsed_time(ev1))
 		result["roofline"]["memset_same_buffer_GBs"] = round(out_bytes / (min(fills) * 1e-3) / 1e9, 1)
 
-	# ---- CPU oracle: every rank checks sampled rows of its own shard; rank 0 at N=1 times the baseline ----
+	# ---- CPU oracle: every rank checks rows of every batch of its own shard; rank 0 at N=1 times the baseline ----
 	def oracle_graph(copies):
 		"""Oracle graph whose path matrix holds the CPU re-derivation (genotype hash) of the given global copies."""
 		import oracle
 		n_cols = 64 * ((len(copies) + 63) // 64)
-		cols = [ds.copy_column(c) for c in copies] + [np.zeros(Ep_alg // 64, np.uint64)] * (n_cols - len(copies))
+		cols = [ds.copy_column(c) for c in copies] + [np.zeros(Ep // 64, np.uint64)] * (n_cols - len(copies))
 		return oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
-			g.label_offsets, g.label_bytes, np.concatenate(cols) if Ep_alg else np.zeros(0, np.uint64), Ep_alg, n_cols,
+			g.label_offsets, g.label_bytes, np.concatenate(cols) if Ep else np.zeros(0, np.uint64), Ep, n_cols,
 			["S%d" % i for i in range(n_cols // ds.ploidy)], np.arange(n_cols // ds.ploidy + 1, dtype=np.uint32) * ds.ploidy)
 
-	if args.verify_rows:
-		k = min(args.verify_rows, batches[0].n_rows) if batches else 0
-		ok = True
-		if k:
-			# re-run the first batch of this rank and compare device checksums + one full row with the oracle
-			ctx.splice_rows_device(batches[0], out_ptr, pitch)
-			sums = ctx.checksum_rows_device(out_ptr, pitch, k, length=L)
-			local = rows[:k]
-			copies = [c0 + r for r in local if r != v2m.PLOIDY_MAX]
-			og = oracle_graph(copies)
-			col_of = {c: i for i, c in enumerate(copies)}
-			bodies = [og.output_sequence(ds.reference) if r == v2m.PLOIDY_MAX else og.output_sequence(ds.reference, copy_index=col_of[c0 + r]) for r in local]
-			ok = bool(np.array_equal(sums, v2m.checksum_rows_host(bodies))) and _device_bytes(torch, out_ptr + (k - 1) * pitch, L) == bodies[k - 1]
-		checked = k
+	if args.verify_rows and batches:
+		import oracle
+		# which rows: per batch `verify_rows` rows spread over the batch (the first batch's includes row 0: REF on rank 0), and
+		# every row of the last batch's final, ragged 16-row group (the rows a wrong grid or tile bound would lose first)
+		picks = []   # (batch index, row within batch)
+		for bi, b in enumerate(batches):
+			for k in range(args.verify_rows):
+				picks.append((bi, (k * b.n_rows // args.verify_rows + 37 * bi) % b.n_rows if (bi or k) else 0))
+		last = batches[-1]
+		tail = last.n_rows % 16 or min(16, last.n_rows)
+		picks += [(len(batches) - 1, r) for r in range(last.n_rows - min(tail, 4), last.n_rows)]
+		picks = sorted(set(picks))
+		local_of = lambda bi, r: rows[bi * batch_rows + r]
+		copies = sorted({c0 + local_of(bi, r) for bi, r in picks if local_of(bi, r) != v2m.PLOIDY_MAX})
+		og = oracle_graph(copies)
+		col_of = {c: i for i, c in enumerate(copies)}
+		want_rows = [oracle.PLOIDY_MAX if local_of(bi, r) == v2m.PLOIDY_MAX else col_of[c0 + local_of(bi, r)] for bi, r in picks]
+		t_o = time.time()
+		want_sums, want_len = og.row_checksums(ds.reference, want_rows, threads=min(16, os.cpu_count() or 1, len(want_rows)))
+		ok = bool((want_len == L).all())
+		got_sums = np.zeros(len(picks), dtype=np.uint64)
+		full_compare = None
+		for bi, b in enumerate(batches):          # re-run every batch of this rank's step and look at the picked rows on the device
+			mine = [i for i, (pb, _) in enumerate(picks) if pb == bi]
+			if not mine:
+				continue
+			ctx.splice_rows_device(b, out_ptr, pitch)
+			for i in mine:
+				got_sums[i] = ctx.checksum_rows_device(out_ptr + picks[i][1] * pitch, pitch, 1, length=L)[0]
+			if bi == len(batches) - 1:            # one row of the last batch byte for byte: its very last row
+				i = mine[-1]
+				body = og.output_sequence(ds.reference, copy_index=want_rows[i]) if want_rows[i] != oracle.PLOIDY_MAX else og.output_sequence(ds.reference)
+				full_compare = _device_bytes(out_ptr + picks[i][1] * pitch, L) == body
+		ok = ok and bool(np.array_equal(got_sums, want_sums)) and full_compare is not False
+		checked = len(picks)
+		if rank == 0:
+			log("[bench] parity: %d rows of %d batches against the oracle in %.1f s: %s" % (checked, len(batches), time.time() - t_o, "bit-exact" if ok else "MISMATCH"))
 		if world > 1:
 			flags = torch.tensor([1 if ok else 0, checked], dtype=torch.int64, device=red_dev)
 			lo = flags.clone()
 			dist.all_reduce(lo, op=dist.ReduceOp.MIN)
 			dist.all_reduce(flags, op=dist.ReduceOp.SUM)
 			ok, checked = bool(lo[0].item()), int(flags[1].item())
-		result["parity"] = {"rows_checked": checked, "bit_exact": ok, "method": "per rank: device row checksums + one full row of its first batch vs the CPU oracle"}
+		result["parity"] = {"rows_checked": checked, "batches_covered": len(batches) * world if world > 1 else len(batches), "bit_exact": ok,
+			"method": "per rank, after timing: every batch of the step re-run; device checksums (v2m_checksum_rows_device) of %d row(s) per batch, REF and the last batch's final ragged group against the CPU oracle's rows, plus the last row of the last batch byte for byte" % args.verify_rows}
 		if not ok:
 			log("[bench] PARITY FAILURE against the CPU oracle")
+
+	# ---- second leg, timed on its own: --unaligned (sequence_writer.cc:80: no '-' padding) -----------------------------
+	if rank == 0 and args.unaligned_rows and n_rows > 1:
+		import oracle
+		upitch = (ctx.max_unaligned_length + 255) // 256 * 256
+		n_u = max(1, min(args.unaligned_rows, out_bytes // upitch, n_rows))
+		ub = v2m.RowBatch(rows[:n_u])
+		ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True)      # warm-up (builds the second template)
+		ctx.synchronize()
+		ctx.profile_enable(True)
+		ctx.profile_reset()
+		reps = 3
+		t_u = time.perf_counter()
+		for _ in range(reps):
+			lengths = ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True, want_lengths=True)
+		ctx.synchronize()
+		wall_u = (time.perf_counter() - t_u) / reps
+		_, u_count = ctx.profile_get(N.KERNEL_UNALIGNED_COUNT)
+		_, u_splice = ctx.profile_get(N.KERNEL_SPLICE_UNALIGNED)
+		_, u_resolve = ctx.profile_get(N.KERNEL_RESOLVE)
+		ctx.profile_enable(False)
+		u_count, u_splice, u_resolve = u_count / reps, u_splice / reps, u_resolve / reps
+		bases_u = int(lengths.sum())
+		n_tiles = -(-L // 16384)
+		# pass 2 (splice_unaligned_kernel): row bytes out + the rows' bit columns + the shared inputs + one tile offset per (row, tile);
+		# pass 1 (count + scan): the shared inputs + bit columns in, the tile counts out and in and out again (scan in place)
+		alg_u = bases_u + n_u * Ep // 8 + shared_bytes + 4 * n_u * n_tiles
+		alg_c = n_u * Ep // 8 + shared_bytes + 3 * 4 * n_u * n_tiles
+		usample = sorted({0, 1, n_u // 2, n_u - 1})
+		ucopies = [c0 + rows[i] for i in usample if rows[i] != v2m.PLOIDY_MAX]
+		uog = oracle_graph(ucopies)
+		ucol = {c: i for i, c in enumerate(ucopies)}
+		uwant, ulen = uog.row_checksums(ds.reference, [oracle.PLOIDY_MAX if rows[i] == v2m.PLOIDY_MAX else ucol[c0 + rows[i]] for i in usample], unaligned=True, threads=len(usample))
+		ugot = np.array([ctx.checksum_rows_device(out_ptr + i * upitch, upitch, 1, length=int(lengths[i]))[0] for i in usample], dtype=np.uint64)
+		u_ok = bool(np.array_equal(ulen, lengths[usample])) and bool(np.array_equal(ugot, uwant))
+		result["unaligned"] = {
+			"metric": "unaligned (--unaligned) Gbases/sec, one batch, kernels only", "rows": n_u, "bases": bases_u,
+			"value": round(bases_u / (u_resolve + u_count + u_splice) / 1e6, 1), "unit": "Gbases/s", "wall_ms_per_batch": round(1e3 * wall_u, 3),
+			"kernels_ms": {"resolve_effective_edges_kernel": round(u_resolve, 3), "count_unaligned_kernel+scan_tile_counts_kernel": round(u_count, 3), "splice_unaligned_kernel": round(u_splice, 3)},
+			"roofline": {"bound": "hbm", "kernel": "splice_unaligned_kernel", "algorithmic_bytes_per_launch": int(alg_u), "achieved": round(alg_u / u_splice / 1e6, 1), "peak": HBM_PEAK_GBS,
+				"unit": "GB/s", "frac": round(alg_u / u_splice / 1e6 / HBM_PEAK_GBS, 4)},
+			"roofline_count_pass": {"bound": "hbm", "kernel": "count_unaligned_kernel+scan_tile_counts_kernel", "algorithmic_bytes_per_launch": int(alg_c), "achieved": round(alg_c / u_count / 1e6, 1),
+				"unit": "GB/s", "note": "reads the shared inputs and the rows' effective-edge bits, writes 4 bytes per (row, 16-KiB tile); builds no row"},
+			"parity": {"rows_checked": len(usample), "bit_exact": u_ok, "method": "row lengths and device checksums against the CPU oracle's unaligned rows"},
+		}
+		if not u_ok:
+			log("[bench] PARITY FAILURE (unaligned leg) against the CPU oracle")
+			result.setdefault("parity", {})["bit_exact"] = False
 
 	if rank == 0 and world == 1 and args.cpu_baseline_rows:
 		nb = min(args.cpu_baseline_rows, H)

@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define V2M_ABI_VERSION 1
+#define V2M_ABI_VERSION 2
 
 enum {
 	V2M_OK = 0,
@@ -137,8 +137,22 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *graph, const char *ref_
 int v2m_set_paths_device(v2m_ctx *ctx, const void *d_words, uint64_t path_rows, uint64_t path_cols);
 
 /* aligned_positions.back(): the length of every aligned row. 0 before an upload. */
+/* One GPU's share of the path matrix when chromosome copies are sharded over several GPUs (rows are independent,
+ * haplotype_output.cc:62-81; the graph and reference are replicated with v2m_upload_graph, the matrix is not).
+ * `paths_by_edge_and_chrom_copy` is the WHOLE host-resident transpose input (variant_graph.hh:62: n_rows = chromosome
+ * copies, n_cols = ALT edges, both multiples of 64, column-major as above) as build_variant_graph leaves it just before
+ * its transpose_matrix call (variant_graph.cc:453).  Only the bits of copies [first_copy, first_copy + n_copies) are
+ * moved to this GPU -- bytes [first_copy / 8, ..) of every column, a strided 2-D copy; first_copy must be a multiple
+ * of 8 -- zero-padded to a multiple of 64 copies, transposed THERE (the same kernels as v2m_transpose_bits_device) and
+ * bound as paths_by_chrom_copy_and_edge of the uploaded graph: n_cols rows (edges) x 64 * ceil(n_copies / 64) columns,
+ * column j = copy first_copy + j.  Row batches for this ctx then use copy indices relative to first_copy.
+ * first_copy = 0, n_copies = n_rows is the unsharded case: upload + transpose + bind without the matrix ever coming
+ * back to the host.  The result is owned by the ctx.  Synchronous. */
+int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *paths_by_edge_and_chrom_copy, uint64_t n_rows, uint64_t n_cols, uint64_t first_copy, uint64_t n_copies);
+
 uint64_t v2m_aligned_length(const v2m_ctx *ctx);
-/* Smallest row pitch v2m_splice_rows_device accepts in aligned mode (aligned length rounded up to 256). */
+/* The row pitch the library itself uses in aligned mode (aligned length rounded up to 256: rows then start on
+ * 256-B boundaries).  v2m_splice_rows_device accepts any multiple of 16 that is >= the aligned length rounded up to 16. */
 uint64_t v2m_min_row_pitch(const v2m_ctx *ctx);
 
 /* ---- rows -------------------------------------------------------------------------------- */
@@ -172,20 +186,23 @@ typedef int (*v2m_sink_fn)(void *user, uint64_t row_index, const char *bytes, ui
 int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m_sink_fn sink, void *user);
 
 /* Device-resident form: row i is written to d_out + i * row_pitch and stays in HBM.
- * Aligned mode: every row has v2m_aligned_length() bytes; row_pitch >= v2m_min_row_pitch()
- * and a multiple of 16; d_out 16-byte aligned; the bytes between the row's end and the next
- * multiple of 16 are clobbered.  Unaligned mode: row_pitch must be >= the longest row
+ * Aligned mode: every row has v2m_aligned_length() bytes; row_pitch a multiple of 16 and >= the aligned length
+ * rounded up to 16 (v2m_min_row_pitch() is what the library uses itself); d_out 16-byte aligned; the bytes between
+ * the row's end and the next multiple of 16 are clobbered.  Unaligned mode: row_pitch must be >= the longest row
  * (reference length + total label bytes is always enough; see v2m_max_unaligned_length()).
  * row_lengths_out (host, optional, [n_rows]) receives each row's length.
- * Asynchronous on the ctx's stream unless row_lengths_out is non-NULL in unaligned mode. */
+ * The call returns once the kernels are QUEUED on the ctx's stream, after a host-side wait for the upload of the
+ * batch's (small) row tables; the first >= 1 GiB launch of a ctx also times both store flavours, synchronously.
+ * With row_lengths_out in unaligned mode the call waits for the kernels.  Use v2m_ctx_synchronize() before reading d_out. */
 int v2m_splice_rows_device(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, void *d_out, uint64_t row_pitch, uint64_t *row_lengths_out);
 
-/* Device memory for row output (the d_out of v2m_splice_rows_device), chosen by measurement: on MI355X the
- * write rate the splice's store pattern reaches differs by ~25 % between allocations, depending on how
- * fragmented their physical backing is (tools/vmm_probe2.hip), which a caller cannot see from a pointer.
- * Allocates up to `candidates` buffers of `bytes` (fewer if HBM runs out -- all of them are held until the
- * choice is made), times the store pattern on each, keeps the fastest and frees the others.
- * candidates <= 1 is a plain allocation.  Free with v2m_free_output().  Synchronous. */
+/* Device memory for row output (the d_out of v2m_splice_rows_device).  On MI355X the write rate the splice's
+ * store pattern reaches on a plain hipMalloc'ed buffer differs by ~25 % between allocations, depending on how
+ * fragmented their physical backing is (tools/vmm_probe2.hip), which a caller cannot see from a pointer.  Buffers
+ * of at least 2 GiB are therefore mapped from physically contiguous 512-MB chunks (hipMemCreate / hipMemMap), which
+ * reach the full rate every time; v2m_ctx_info() says so.  Where that is not available (or for small buffers) the
+ * buffer comes from hipMalloc, and with candidates > 1 up to that many are held at once, the store pattern is timed on
+ * each and the fastest is kept.  Free with v2m_free_output() (or with the ctx).  Synchronous. */
 int v2m_alloc_output(v2m_ctx *ctx, uint64_t bytes, int candidates, void **d_out);
 int v2m_free_output(v2m_ctx *ctx, void *d_ptr);
 
@@ -195,9 +212,10 @@ uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx);
 /* ---- verification helper ------------------------------------------------------------------ */
 
 /* 64-bit position-sensitive checksum of each of n_rows device rows (row i = d_rows + i*row_pitch,
- * lengths[i] bytes, or `length` for all rows when lengths == NULL):
- *   sum over byte positions p of  mix64((p + 1) * 0x9E3779B97F4A7C15 ^ byte[p])  (mod 2^64),
- *   mix64 = the splitmix64 finaliser.
+ * lengths[i] bytes, or `length` for all rows when lengths == NULL; d_rows and row_pitch multiples of 8):
+ *   the row is read as 8-byte little-endian words w[0 .. ceil(len/8)), the last one zero-padded past the row's end;
+ *   checksum = sum over k of mix64((k + 1) * 0x9E3779B97F4A7C15 ^ w[k])  +  mix64(len)   (mod 2^64),
+ *   mix64 = the splitmix64 finaliser (z ^= z >> 30; z *= 0xBF58476D1CE4E5B9; z ^= z >> 27; z *= 0x94D049BB133111EB; z ^= z >> 31).
  * Used to check full-size outputs against the CPU without moving them.  Synchronous. */
 int v2m_checksum_rows_device(v2m_ctx *ctx, const void *d_rows, uint64_t row_pitch, uint64_t n_rows, uint64_t length, const uint64_t *lengths, uint64_t *checksums_out);
 
@@ -207,9 +225,10 @@ enum {
 	V2M_KERNEL_TRANSPOSE = 0,       /* transpose_bits_kernel */
 	V2M_KERNEL_RESOLVE = 1,         /* resolve_effective_edges_kernel (per-row skip-rule scan) */
 	V2M_KERNEL_SPLICE_ALIGNED = 2,  /* splice_aligned_kernel (dominant) */
-	V2M_KERNEL_SPLICE_UNALIGNED = 3,
+	V2M_KERNEL_SPLICE_UNALIGNED = 3, /* splice_unaligned_kernel (pass 2 of unaligned mode: build + compact the tiles) */
 	V2M_KERNEL_TEMPLATE = 4,        /* expand_reference_row_kernel (once per upload) */
-	V2M_KERNEL_COUNT = 5
+	V2M_KERNEL_UNALIGNED_COUNT = 5, /* count_unaligned_kernel + scan_tile_counts_kernel (pass 1 of unaligned mode) */
+	V2M_KERNEL_COUNT = 6
 };
 
 /* When enabled, every launch of the kernels above is bracketed by HIP events on the ctx's

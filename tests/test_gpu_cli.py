@@ -138,6 +138,21 @@ def test_sharded_output_over_several_contexts(tmp_path):
 	exp = tmp_path / "exp.a2m"
 	g.haplotype_output_a2m(g.ref, str(exp))
 	assert one.read_bytes() == exp.read_bytes() == three.read_bytes()
+	# each context received only its own chromosome copies: 25 diploid samples = 50 copies in blocks of
+	# 8, the blocks that do not divide go to the last contexts -- the same boundaries as sharding.py
+	from vcf2multialign_amd.sharding import shard_copies
+	r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(three), "--device=0,0,0", "--verbose"])
+	assert r.returncode == 0, r.stderr.decode()
+	for k in range(3):
+		c0, c1, _ = shard_copies(50, 3, k)
+		assert ("GPU context %d (device 0): chromosome copies [%d, %d)" % (k, c0, c1)).encode() in r.stderr, r.stderr.decode()
+	assert three.read_bytes() == exp.read_bytes()
+	# more contexts than blocks of copies: some contexts own nothing
+	r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(three), "--device=0,0,0,0,0,0,0,0,0", "--omit-reference"])
+	assert r.returncode == 0, r.stderr.decode()
+	g.haplotype_output_a2m(g.ref, str(exp), output_reference=False)
+	assert three.read_bytes() == exp.read_bytes()
+	g.haplotype_output_a2m(g.ref, str(exp))
 	assert run(["-F", "7", "-r", fa, "-a", vcf, "-c", "1", "-s", str(one), "--dst-chromosome=chrQ"]).returncode == 0
 	r = run(["-F", "7", "-r", fa, "-a", vcf, "-c", "1", "-s", str(three), "--dst-chromosome=chrQ", "--device=0,0"])
 	assert r.returncode == 0, r.stderr.decode()

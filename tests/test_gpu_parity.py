@@ -516,3 +516,91 @@ def test_precondition_errors(v2m, ctx, tmp_path):
 	assert e.value.code == 2
 	ctx.upload_graph(vg, g.ref)   # the context stays usable
 	assert ctx.splice_rows([0]) == _oracle_rows(g, [0])
+
+
+# ---- v2m_upload_path_slice: one GPU's share of the path matrix ---------------------------
+
+@pytest.mark.parametrize("world", [1, 2, 3, 5])
+def test_path_slices_reproduce_every_row(ctx, v2m, tmp_path, world):
+	"""Every rank uploads only its own copies out of the host-resident transpose input, transposes them on the GPU and
+	splices its rows with copy indices relative to its shard; together the ranks produce exactly the oracle's file."""
+	from vcf2multialign_amd.sharding import local_rows, shard_copies
+	g = synth.build_case(tmp_path, 91, 50000, 700, 21, long_every=150)          # 42 copies: uneven shards, a ragged last block
+	hp, ep = g.paths_by_edge_and_chrom_copy_dims
+	n_copies = g.total_chromosome_copies
+	vg = v2m.VariantGraph.from_object(g)
+	vg.paths_by_chrom_copy_and_edge = None
+	expected = [g.output_sequence(g.ref)] + [g.output_sequence(g.ref, copy_index=c) for c in range(n_copies)]
+	got = {}
+	for rank in range(world):
+		ctx.upload_graph(vg, g.ref)
+		c0, c1, hp_local = shard_copies(n_copies, world, rank)
+		ctx.upload_path_slice(g.paths_by_edge_and_chrom_copy, hp, ep, c0, c1 - c0)
+		rows = local_rows(n_copies, world, rank)
+		for (global_row, _), body in zip(rows, ctx.splice_rows([local for _, local in rows])):
+			got[global_row] = body
+		if c1 > c0:
+			with pytest.raises(v2m.V2MError):                                 # the context holds hp_local columns and no more
+				ctx.splice_rows([hp_local])
+			if hp_local > c1 - c0:                                            # padding copies of the shard carry no bits, whatever the next shard holds
+				assert ctx.splice_rows([hp_local - 1])[0] == expected[0]
+	assert [got[r] for r in range(n_copies + 1)] == expected
+
+
+def test_path_slice_edges(ctx, v2m, tmp_path):
+	g = synth.build_case(tmp_path, 92, 20000, 300, 40)
+	hp, ep = g.paths_by_edge_and_chrom_copy_dims
+	vg = v2m.VariantGraph.from_object(g)
+	vg.paths_by_chrom_copy_and_edge = None
+	ctx.upload_graph(vg, g.ref)
+	ref_row = g.output_sequence(g.ref)
+	# a slice that ends in the middle of a byte: the bits of the following copies must not leak into the padding
+	ctx.upload_path_slice(g.paths_by_edge_and_chrom_copy, hp, ep, 8, 13)
+	bodies = ctx.splice_rows(list(range(64)))
+	for local, body in enumerate(bodies):
+		assert body == (g.output_sequence(g.ref, copy_index=8 + local) if local < 13 else ref_row), local
+	# the whole matrix in one piece == upload_graph with the (oracle-)transposed matrix
+	ctx.upload_path_slice(g.paths_by_edge_and_chrom_copy, hp, ep)
+	assert ctx.splice_rows([0, 5, 79]) == [g.output_sequence(g.ref, copy_index=c) for c in (0, 5, 79)]
+	# an empty shard binds nothing: only REF rows can be asked for
+	ctx.upload_path_slice(g.paths_by_edge_and_chrom_copy, hp, ep, 16, 0)
+	assert ctx.splice_rows([v2m.PLOIDY_MAX]) == [ref_row]
+	with pytest.raises(v2m.V2MError):
+		ctx.splice_rows([0])
+	for bad in ((4, 8), (0, hp + 1), (hp, 8)):
+		with pytest.raises(v2m.V2MError):
+			ctx.upload_path_slice(g.paths_by_edge_and_chrom_copy, hp, ep, *bad)
+	with pytest.raises(v2m.V2MError):
+		ctx.upload_path_slice(g.paths_by_edge_and_chrom_copy[:hp // 64 * 64], hp, 64, 0, hp)   # fewer edge columns than the graph has edges
+
+
+def test_output_buffer_is_ordinary_device_memory(ctx, v2m, tmp_path):
+	"""v2m_alloc_output's chunk-mapped buffers behave like any other device pointer: kernels write rows into them, interior
+	ranges that cross chunk boundaries copy back with hipMemcpy, alloc / free / alloc again works."""
+	import ctypes
+	import torch
+	g = synth.build_case(tmp_path, 93, 3_000_000, 2000, 3)
+	vg = v2m.VariantGraph.from_object(g)
+	ctx.upload_graph(vg, g.ref)
+	L, pitch = g.aligned_length, ctx.min_row_pitch
+	n_rows = (3 << 30) // pitch + 1                                           # > 2 GiB: the chunk-mapped path, several 512-MB chunks
+	rows = [v2m.PLOIDY_MAX if i % 7 == 0 else i % 6 for i in range(n_rows)]
+	expected = {r: g.output_sequence(g.ref, copy_index=r) for r in set(rows)}
+	rt = ctypes.CDLL("libamdhip64.so.7")
+	rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+	for _ in range(2):
+		out = ctx.alloc_output(n_rows * pitch, 1)
+		assert "mapped from" in ctx.info and "512 MB" in ctx.info, ctx.info
+		ctx.splice_rows_device(rows, out, pitch)
+		sums = ctx.checksum_rows_device(out, pitch, n_rows, length=L)
+		want = {r: v2m.checksum_rows_host([body])[0] for r, body in expected.items()}
+		assert np.array_equal(sums, np.array([want[r] for r in rows], dtype=np.uint64))
+		chunk_rows = [(k << 29) // pitch for k in range(1, (n_rows * pitch) >> 29)]   # rows that straddle a chunk boundary
+		assert chunk_rows
+		for r in chunk_rows[:3] + [n_rows - 1]:
+			buf = ctypes.create_string_buffer(L)
+			assert rt.hipMemcpy(buf, out + r * pitch, L, 2) == 0
+			assert buf.raw == expected[rows[r]], r
+		ctx.free_output(out)
+	small = ctx.alloc_output(1 << 20, 1)                                       # small buffers stay plain allocations
+	ctx.free_output(small)

@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(v2m):
 	for name in declared:
 		assert hasattr(lib, name), name + " is declared in include/v2m_hip.h but not exported"
 	assert set(declared) == set(_native.SIGNATURES), "ctypes signatures and header disagree"
-	assert lib.v2m_abi_version() == 1
+	assert lib.v2m_abi_version() == 2
 
 
 def test_no_device_means_loud_failure(v2m):
@@ -165,3 +165,40 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
 	subprocess.check_call([gcc, "-std=c99", "-I" + os.path.join(root, "include"), src, "-L" + build.PKG_DIR, "-lv2m_hip",
 		"-Wl,-rpath," + build.PKG_DIR, "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)])
 	assert exe.exists()
+
+
+def test_cxx_and_python_sharding_agree():
+	"""The command-line driver (csrc/host/gpu_path.cc) and bench.py / sharding.py cut the chromosome copies at the same places."""
+	from vcf2multialign_amd import host
+	from vcf2multialign_amd.sharding import shard_copies
+	for n_copies in (0, 1, 7, 8, 9, 63, 64, 65, 200, 2000, 5008, 20000, 20001):
+		for world in (1, 2, 3, 4, 7, 8, 16):
+			covered = 0
+			for rank in range(world):
+				c0, c1, hp = shard_copies(n_copies, world, rank)
+				assert host.shard_copies(n_copies, world, rank) == (c0, c1), (n_copies, world, rank)
+				assert c0 == covered and c0 % 8 == 0 or c0 == n_copies
+				assert hp % 64 == 0 and hp >= c1 - c0
+				covered = c1
+			assert covered == n_copies
+
+
+def test_traffic_is_quoted_only_for_the_sources_it_was_measured_on():
+	"""roofline.traffic comes from profiles/pmc_traffic.json and must disappear when the kernel sources have changed since."""
+	import subprocess
+	import sys
+	ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	sys.path.insert(0, ROOT)
+	import bench
+	stamp = bench.kernel_source_stamp()
+	assert set(stamp) == set(bench.KERNEL_SOURCES) and all(len(h) == 40 for h in stamp.values())
+	out = subprocess.run(["git", "hash-object", os.path.join(ROOT, bench.KERNEL_SOURCES[0])], stdout=subprocess.PIPE, cwd=ROOT)
+	if out.returncode == 0:
+		assert out.stdout.decode().strip() == stamp[bench.KERNEL_SOURCES[0]]
+	# the committed record carries a stamp, and bench.py's rule is "equal stamps or no traffic figure"
+	import json
+	with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+		rec = json.load(f)
+	for name, r in rec.items():
+		if not name.startswith("_"):
+			assert set(r["kernel_sources"]) == set(bench.KERNEL_SOURCES), name

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Summarises rocprofv3 --pmc passes (counter_collection.csv files) into HBM bytes per launch per kernel.
 
-    python tools/pmc_summary.py OUT.json NOTE  WRITE_SIZE=<dir-or-csv>  FETCH_SIZE=<dir-or-csv>
+    python tools/pmc_summary.py OUT.json NOTE  WRITE_SIZE=<dir-or-csv>  FETCH_SIZE=<dir-or-csv>  [record=<config>,<batch_rows>,<n_gpus>,<source path>]
+
+With record=..., the splice figure is also written into profiles/pmc_traffic.json, stamped with the git blob hashes of the
+kernel sources as they are now (bench.py prints roofline.traffic only while those hashes still match).
 
 Counter unit is KiB.  On gfx950 FETCH_SIZE reports half of what wide coalesced reads move
 (/opt/skills/guides/MI355X_MICROARCH.md, HBM section): hbm_bytes = 1024 * (WRITE_SIZE + 2 * FETCH_SIZE)."""
@@ -25,8 +28,12 @@ def short(name):
 def main():
 	out_path, note = sys.argv[1], sys.argv[2]
 	kernels = defaultdict(dict)
+	record = None
 	for arg in sys.argv[3:]:
 		counter, path = arg.split("=", 1)
+		if counter == "record":
+			record = path.split(",", 3)
+			continue
 		per_dispatch = defaultdict(float)     # (dispatch id, kernel) -> value summed over the counter's instances
 		with open(find_csv(path)) as f:
 			for row in csv.DictReader(f):
@@ -50,6 +57,17 @@ def main():
 		result["splice_aligned_kernel_hbm_bytes_per_launch"] = sum(v["hbm_bytes_per_launch"] * v["launches"] for v in splice) / n
 	with open(out_path, "w") as f:
 		json.dump(result, f, indent=1)
+	if record and "splice_aligned_kernel_hbm_bytes_per_launch" in result:
+		root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+		sys.path.insert(0, root)
+		import bench
+		path = os.path.join(root, "profiles", "pmc_traffic.json")
+		with open(path) as f:
+			rec = json.load(f)
+		rec[record[0]] = {"batch_rows": int(record[1]), "n_gpus": int(record[2]), "hbm_bytes_per_launch": result["splice_aligned_kernel_hbm_bytes_per_launch"],
+			"source": record[3], "kernel_sources": bench.kernel_source_stamp()}
+		with open(path, "w") as f:
+			json.dump(rec, f, indent=1)
 	print(json.dumps({k: v for k, v in result.items() if k != "kernels"}))
 
 

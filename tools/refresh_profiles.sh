@@ -14,10 +14,14 @@ echo "bench done"
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 echo "trace done"
-timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -o w -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline-rows 0 --verify-rows 0 > $OUT/pmc_w.json 2> $OUT/pmc_w.err
+# the counter passes run with the store flavour fixed, so that every splice launch they see is one of the step's own
+# (the flavour calibration would add four same-size launches, two of them with plain stores)
+export V2M_NT_STORES=1
+timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -o w -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline-rows 0 --verify-rows 0 --unaligned-rows 0 --transpose-extras 0 > $OUT/pmc_w.json 2> $OUT/pmc_w.err
 echo "pmc write done"
-timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -o f -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline-rows 0 --verify-rows 0 > $OUT/pmc_f.json 2> $OUT/pmc_f.err
+timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -o f -- python3 bench.py --steps 1 --warmup 0 --cpu-baseline-rows 0 --verify-rows 0 --unaligned-rows 0 --transpose-extras 0 > $OUT/pmc_f.json 2> $OUT/pmc_f.err
 echo "pmc fetch done"
-python3 tools/pmc_summary.py $OUT/pmc_hbm.json "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE (separate passes, one step of bench.py's default run each; counter unit KiB; hbm_bytes = 1024*(WRITE_SIZE + 2*FETCH_SIZE), the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md). The splice average covers the step's launches plus the same-size calibration launches of the store flavour." WRITE_SIZE=$OUT/pmc_w FETCH_SIZE=$OUT/pmc_f
+python3 tools/pmc_summary.py $OUT/pmc_hbm.json "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE (separate passes, one step of bench.py's default run each; counter unit KiB; hbm_bytes = 1024*(WRITE_SIZE + 2*FETCH_SIZE), the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md). Store flavour fixed (V2M_NT_STORES=1): the splice average covers the step's own launches only." WRITE_SIZE=$OUT/pmc_w FETCH_SIZE=$OUT/pmc_f "record=config3,$(python3 -c "import json;print(json.load(open('$OUT/bench.json'))['config']['batch_rows'])"),1,${PROFILE_DEST:-profiles/r02}/config3_1gpu_pmc_hbm.json"
+cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 rm -rf $OUT/trace $OUT/pmc_w $OUT/pmc_f
 tail -1 $OUT/bench.json | cut -c1-300

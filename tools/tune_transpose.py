@@ -15,11 +15,11 @@ import torch  # noqa: E402
 import vcf2multialign_amd as v2m  # noqa: E402
 from vcf2multialign_amd import _native as N  # noqa: E402
 
-QUICK = ["8x8/rr", "8x8", "stream16/rr", "stream16",
-	"ring:16,8,8,4,64", "ring:16,8,8,4,64,slow", "ring:16,8,8,4,64/rr", "ring:16,8,8,4,128", "ring:16,8,8,4,256",
-	"ring:16,4,8,4,64", "ring:16,16,8,4,64", "ring:16,16,8,8,64", "ring:16,8,8,8,64",
-	"ring:16,8,4,4,64", "ring:16,8,16,4,64", "ring:8,4,8,4,64", "ring:8,8,8,4,64", "ring:8,4,8,8,64", "ring:8,8,4,8,64"]
-FULL = QUICK + ["4x16", "16x4", "ring:8,4,8,4,128", "ring:8,8,8,4,128", "ring:16,8,4,4,128", "ring:16,16,8,4,128", "ring:8,4,8,8,256"]
+QUICK = ["8x8", "8x8/pf", "8x8/sf", "stream16", "stream16/pf", "stream16/sf",
+	"ring:8,8,8,4,64", "ring:8,8,8,4,64/pf", "ring:8,8,8,4,64/sf", "ring:8,8,8,4,32", "ring:8,8,8,4,48", "ring:8,8,8,4,96", "ring:8,8,8,4,128",
+	"ring:8,8,8,2,64", "ring:8,8,8,8,64", "ring:8,4,8,8,64", "ring:16,16,8,4,64/sf", "ring:16,16,8,4,64/pf"]
+FULL = QUICK + ["8x8/rr", "stream16/rr", "4x16", "16x4", "ring:16,8,8,4,64", "ring:16,8,8,4,64,slow", "ring:16,4,8,4,64", "ring:16,16,8,8,64",
+	"ring:16,8,4,4,64", "ring:16,8,16,4,64", "ring:8,4,8,4,64", "ring:8,8,4,8,64"]
 
 args = sys.argv[1:]
 names_set = QUICK
@@ -61,5 +61,12 @@ for name in names:
 	if want_dst is None:
 		want_dst = dst.clone()
 	ok = torch.equal(back, src) and torch.equal(dst, want_dst)
+	if not ok:
+		for label, got, want in (("forward", dst, want_dst), ("inverse", back, src)):
+			bad = (got != want).nonzero().flatten()
+			if bad.numel():
+				i = int(bad[0].item())
+				print("    %s: %d of %d words differ; first at word %d (column %d, word %d of it): got %016x want %016x" % (label, bad.numel(), n, i,
+					i // ((ep if label == "forward" else hp) // 64), i % ((ep if label == "forward" else hp) // 64), got[i].item() & (2**64 - 1), want[i].item() & (2**64 - 1)), flush=True)
 	t1, t2 = min(a for a, _ in ts), min(b for _, b in ts)
 	print("%-26s forward %.3f ms = %5.0f GB/s   inverse %.3f ms = %5.0f GB/s   %s" % (name, t1, 2 * n * 8 / t1 / 1e6, t2, 2 * n * 8 / t2 / 1e6, "ok" if ok else "WRONG RESULT"), flush=True)

@@ -21,8 +21,9 @@ V2M_ERR_HIP, V2M_ERR_OUT_OF_MEMORY, V2M_ERR_SINK, V2M_ERR_STATE = 5, 6, 7, 8
 V2M_PLOIDY_MAX = 0xFFFFFFFF
 V2M_SPLICE_UNALIGNED = 0x1
 
-KERNEL_TRANSPOSE, KERNEL_RESOLVE, KERNEL_SPLICE_ALIGNED, KERNEL_SPLICE_UNALIGNED, KERNEL_TEMPLATE = range(5)
-KERNEL_NAMES = ["transpose_bits_kernel", "resolve_effective_edges_kernel", "splice_aligned_kernel", "splice_unaligned_kernel", "expand_reference_row_kernel"]
+KERNEL_TRANSPOSE, KERNEL_RESOLVE, KERNEL_SPLICE_ALIGNED, KERNEL_SPLICE_UNALIGNED, KERNEL_TEMPLATE, KERNEL_UNALIGNED_COUNT = range(6)
+KERNEL_NAMES = ["transpose_bits_kernel", "resolve_effective_edges_kernel", "splice_aligned_kernel", "splice_unaligned_kernel", "expand_reference_row_kernel", "count_unaligned_kernel"]
+ABI_VERSION = 2
 
 
 class GraphView(C.Structure):
@@ -57,6 +58,7 @@ SIGNATURES = {
 	"v2m_transpose_bits_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p]),
 	"v2m_upload_graph": (C.c_int, [C.c_void_p, C.POINTER(GraphView), C.c_void_p, C.c_uint64]),
 	"v2m_set_paths_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
+	"v2m_upload_path_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
 	"v2m_aligned_length": (C.c_uint64, [C.c_void_p]),
 	"v2m_min_row_pitch": (C.c_uint64, [C.c_void_p]),
 	"v2m_max_unaligned_length": (C.c_uint64, [C.c_void_p]),

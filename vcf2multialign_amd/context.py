@@ -121,6 +121,14 @@ class Context:
 	def set_paths_device(self, d_words, path_rows, path_cols):
 		self._check(self._lib.v2m_set_paths_device(self._h, d_words, path_rows, path_cols))
 
+	def upload_path_slice(self, paths_by_edge_and_chrom_copy, n_rows, n_cols, first_copy=0, n_copies=None):
+		"""v2m_upload_path_slice: this GPU's chromosome copies [first_copy, first_copy + n_copies) out of the whole host-resident
+		transpose input (n_rows copies x n_cols edges), transposed on the GPU and bound as the uploaded graph's path matrix."""
+		words = np.ascontiguousarray(paths_by_edge_and_chrom_copy, dtype=np.uint64)
+		assert words.size == n_rows // 64 * n_cols
+		n_copies = n_rows - first_copy if n_copies is None else n_copies
+		self._check(self._lib.v2m_upload_path_slice(self._h, words.ctypes.data if words.size else None, n_rows, n_cols, first_copy, n_copies))
+
 	@property
 	def aligned_length(self):
 		return self._lib.v2m_aligned_length(self._h)

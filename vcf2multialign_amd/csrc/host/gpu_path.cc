@@ -1,5 +1,7 @@
 #include "gpu_path.hh"
 
+#include <algorithm>
+
 namespace v2m::host {
 
 gpu_context::gpu_context(int device)
@@ -31,7 +33,25 @@ void transpose_paths(gpu_context &gpu, variant_graph &graph)
 }
 
 
-void upload_graph(gpu_context &gpu, sequence_type const &ref_seq, variant_graph const &g)
+copy_shard shard_copies(u64 n_copies, u32 world, u32 rank)
+{
+	constexpr u64 granule(8);
+	u64 const n_blocks((n_copies + granule - 1) / granule), base(n_blocks / world), extra(n_blocks % world);
+	u64 const first_heavy(world - extra);
+	u64 const b0(rank * base + (rank > first_heavy ? rank - first_heavy : 0));
+	u64 const b1(b0 + base + (rank >= first_heavy ? 1 : 0));
+	return {std::min(n_copies, granule * b0), std::min(n_copies, granule * b1)};
+}
+
+
+void upload_path_slice(gpu_context &gpu, variant_graph const &g, copy_shard shard)
+{
+	auto const &m(g.paths_by_edge_and_chrom_copy);
+	gpu.check(v2m_upload_path_slice(gpu.get(), m.words.empty() ? nullptr : m.words.data(), m.rows, m.cols, shard.first, shard.end - shard.first));
+}
+
+
+void upload_graph(gpu_context &gpu, sequence_type const &ref_seq, variant_graph const &g, bool with_paths)
 {
 	v2m_graph_view view{};
 	view.node_count = g.node_count();
@@ -43,9 +63,9 @@ void upload_graph(gpu_context &gpu, sequence_type const &ref_seq, variant_graph 
 	view.alt_edge_label_offsets = g.alt_edge_label_offsets.data();
 	view.alt_edge_label_bytes = g.alt_edge_label_bytes.data();
 	auto const &paths(g.paths_by_chrom_copy_and_edge);
-	view.paths_by_chrom_copy_and_edge = paths.words.empty() ? nullptr : paths.words.data();
-	view.path_rows = paths.rows;
-	view.path_cols = paths.cols;
+	view.paths_by_chrom_copy_and_edge = (!with_paths || paths.words.empty()) ? nullptr : paths.words.data();
+	view.path_rows = with_paths ? paths.rows : 0;
+	view.path_cols = with_paths ? paths.cols : 0;
 	gpu.check(v2m_upload_graph(gpu.get(), &view, ref_seq.data(), ref_seq.size()));
 }
 

@@ -33,7 +33,19 @@ private:
 // The last step of build_variant_graph (variant_graph.cc:453).
 void transpose_paths(gpu_context &gpu, variant_graph &graph);
 
-// Makes `graph` + `ref_seq` the resident graph of the context.
-void upload_graph(gpu_context &gpu, sequence_type const &ref_seq, variant_graph const &graph);
+// Makes `graph` + `ref_seq` the resident graph of the context.  with_paths = false leaves the path matrix out (it then
+// comes from upload_path_slice()).
+void upload_graph(gpu_context &gpu, sequence_type const &ref_seq, variant_graph const &graph, bool with_paths = true);
+
+// The chromosome copies [first, end) a GPU owns when `n_copies` copies are sharded over `world` GPUs (SURVEY.md section 8e;
+// the same rule as vcf2multialign_amd/sharding.py:shard_copies): contiguous blocks of whole bytes of the bit-packed path
+// matrix (8 copies), the blocks that do not divide evenly go to the last GPUs because the first one also carries the REF row.
+struct copy_shard { u64 first{}, end{}; };
+copy_shard shard_copies(u64 n_copies, u32 world, u32 rank);
+
+// This GPU's copies [first, end) of graph.paths_by_edge_and_chrom_copy: uploaded (only those bytes), transposed on the
+// GPU and bound as the resident graph's path matrix (v2m_upload_path_slice).  Row batches for this context then use copy
+// indices relative to `first`.  Nothing comes back to the host.
+void upload_path_slice(gpu_context &gpu, variant_graph const &graph, copy_shard shard);
 
 } // namespace v2m::host

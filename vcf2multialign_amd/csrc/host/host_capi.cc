@@ -7,6 +7,7 @@
 #include <string>
 
 #include "founder.hh"
+#include "gpu_path.hh"
 #include "graph_file.hh"
 #include "readers.hh"
 
@@ -199,6 +200,15 @@ int v2mh_read_cut_positions(char const *path, uint64_t *cuts_out, uint64_t *n_cu
 		if (err && errlen) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
 		return 1;
 	}
+}
+
+
+// shard_copies() of gpu_path.hh, for the test that it and vcf2multialign_amd/sharding.py agree on every boundary.
+void v2mh_shard_copies(uint64_t n_copies, uint32_t world, uint32_t rank, uint64_t *first, uint64_t *end)
+{
+	auto const s(vh::shard_copies(n_copies, world, rank));
+	*first = s.first;
+	*end = s.end;
 }
 
 } // extern "C"

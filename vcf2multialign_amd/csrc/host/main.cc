@@ -296,8 +296,10 @@ int main(int argc, char **argv)
 			}
 			std::cerr << "Building the variant graph...\n";
 			vh::build_graph_statistics stats;
-			vh::build_variant_graph(ref_seq, opt.input_variants, opt.chromosome, graph, stats, delegate, 0, 1024);   // 1024-bit matrix padding: whole 128-B lines for the GPU transpose
-			vh::transpose_paths(gpu, graph);   // variant_graph.cc:453, on the GPU
+			vh::build_variant_graph(ref_seq, opt.input_variants, opt.chromosome, graph, stats, delegate, 0, 64);   // the reference's padding (variant_graph.cc:277,449)
+			// variant_graph.cc:453 (the transpose) happens on the GPU(s) below; the transposed matrix only comes back to the host
+			// when something on the host reads it: the founder search and the graph checkpoint.
+			if (opt.founder_mode || opt.output_graph) vh::transpose_paths(gpu, graph);
 			std::cerr << "Done. Handled variants: " << stats.handled_variants << " Chromosome ID mismatches: " << stats.chr_id_mismatches << '\n';
 			if (0 == stats.handled_variants) std::cerr << "WARNING: no variants matched the chromosome identifier \"" << opt.chromosome << "\".\n";
 		}
@@ -324,8 +326,29 @@ int main(int argc, char **argv)
 			std::cout << "Total ploidy: " << graph.total_chromosome_copies() << '\n';
 		}
 
-		vh::upload_graph(gpu, ref_seq, graph);
-		for (auto &g : more_gpus) vh::upload_graph(*g, ref_seq, graph);   // graph and reference replicated on every GPU
+		// Graph and reference are replicated on every GPU; the path matrix is not: with several GPUs
+		// and an aligned A2M file as the only output, GPU k receives the bits of its own chromosome copies only, transposes
+		// them itself and splices the rows of those copies.  Every other combination (one GPU, pipes, unaligned or separate
+		// output) needs the whole matrix on the GPU that writes a row; founder rows read copies all over the matrix.
+		std::vector<vh::gpu_context *> all_gpus{&gpu};
+		for (auto &g : more_gpus) all_gpus.push_back(g.get());
+		bool const sharded(opt.haplotypes && all_gpus.size() > 1 && opt.output_sequences_a2m && !opt.pipe && !opt.unaligned && !opt.output_sequences_separate);
+		std::vector<vh::copy_shard> shards;
+		for (std::size_t k(0); k < all_gpus.size(); ++k) {
+			if (opt.founder_mode) {
+				vh::upload_graph(*all_gpus[k], ref_seq, graph, true);      // the host-transposed matrix (the search needs it on the host anyway)
+				continue;
+			}
+			vh::upload_graph(*all_gpus[k], ref_seq, graph, false);
+			vh::copy_shard const shard(sharded
+				? vh::shard_copies(graph.total_chromosome_copies(), vh::u32(all_gpus.size()), vh::u32(k))
+				: vh::copy_shard{0, graph.paths_by_edge_and_chrom_copy.rows});
+			vh::upload_path_slice(*all_gpus[k], graph, shard);
+			if (sharded) {
+				shards.push_back(shard);
+				if (opt.verbose) std::cerr << "GPU context " << k << " (device " << opt.devices[k] << "): chromosome copies [" << shard.first << ", " << shard.end << ")\n";
+			}
+		}
 		progress_delegate delegate;
 		delegate.verbose = opt.verbose;
 		auto const do_output([&](vh::output &output) {   // main.cc:456-473
@@ -344,6 +367,7 @@ int main(int argc, char **argv)
 		if (opt.haplotypes) {
 			vh::haplotype_output output(gpu, opt.pipe, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
 			for (auto &g : more_gpus) output.add_gpu(*g);
+			if (sharded) output.set_copy_shards(shards);
 			do_output(output);
 		} else {                                            // main.cc:487-550
 			vh::founder_sequence_greedy_output output(gpu, opt.pipe, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);

@@ -163,12 +163,31 @@ void output::splice(row_set const &rows, v2m_sink_fn sink, void *user)
 	v2m_row_batch batch{};
 	batch.n_rows = rows.copy_index.size();
 	batch.copy_index = rows.copy_index.data();
+	std::vector<std::uint32_t> rebased;
+	if (!m_copy_shards.empty() && 0 != m_copy_shards.front().first) {       // the first context's matrix starts at another copy
+		rebased = rebased_copies(rows, 0, rows.copy_index.size(), m_copy_shards.front());
+		batch.copy_index = rebased.data();
+	}
 	if (rows.any_cuts) {
 		batch.cut_offsets = rows.cut_offsets.data();
 		batch.cut_nodes = rows.cut_nodes.data();
 		batch.cut_copies = rows.cut_copies.data();
 	}
 	m_gpu.check(v2m_splice_rows(m_gpu.get(), &batch, m_should_output_unaligned ? V2M_SPLICE_UNALIGNED : 0u, sink, user));
+}
+
+
+// Copy indices of rows [first, last) relative to the shard that holds them.
+std::vector<std::uint32_t> output::rebased_copies(row_set const &rows, std::uint64_t first, std::uint64_t last, copy_shard shard)
+{
+	if (rows.any_cuts) throw std::runtime_error("rows that switch copies need the whole path matrix on their GPU");
+	std::vector<std::uint32_t> out(rows.copy_index.begin() + first, rows.copy_index.begin() + last);
+	for (auto &c : out) {
+		if (V2M_PLOIDY_MAX == c) continue;
+		if (c < shard.first || c >= shard.end) throw std::runtime_error("row of chromosome copy " + std::to_string(c) + " was given to a GPU that does not hold it");
+		c -= std::uint32_t(shard.first);
+	}
+	return out;
 }
 
 
@@ -291,16 +310,39 @@ void output::write_a2m_sharded(row_set const &rows, char const *dst_name)
 	if (0 != ::ftruncate(fd, off_t(offsets[n]))) { /* not all targets can be sized (e.g. /dev/null); pwrite extends regular files anyway */ }
 
 	std::size_t const g(gpus.size());
+	// Which rows go to which context: with a sharded path matrix, the rows whose copy the context holds (REF: the first
+	// context); otherwise equal contiguous blocks.  Rows are in copy order (haplotype_output.cc:62-65), so either way a
+	// context's rows are one contiguous block of the file.
+	std::vector<std::uint64_t> bounds(g + 1, n);
+	bounds[0] = 0;
+	bool const sharded(!m_copy_shards.empty());
+	if (sharded) {
+		if (m_copy_shards.size() != g) throw std::runtime_error("one copy shard per GPU context is needed");
+		if (rows.any_cuts) throw std::runtime_error("rows that switch copies need the whole path matrix on every GPU");
+		std::uint64_t i(0);
+		for (std::size_t k(0); k < g; ++k) {
+			while (i < n && (V2M_PLOIDY_MAX == rows.copy_index[i] ? 0 == k : rows.copy_index[i] < m_copy_shards[k].end)) ++i;
+			bounds[k + 1] = i;
+		}
+		if (bounds[g] != n) throw std::runtime_error("a row's chromosome copy lies outside every GPU's shard");
+	} else {
+		for (std::size_t k(0); k <= g; ++k) bounds[k] = n * k / g;
+	}
 	std::vector<std::exception_ptr> errors(g);
 	std::vector<std::thread> threads;
 	for (std::size_t k(0); k < g; ++k) {
-		std::uint64_t const first(n * k / g), last(n * (k + 1) / g);
+		std::uint64_t const first(bounds[k]), last(bounds[k + 1]);
 		threads.emplace_back([&, k, first, last] {
 			try {
 				if (first == last) return;
 				v2m_row_batch batch{};
 				batch.n_rows = last - first;
 				batch.copy_index = rows.copy_index.data() + first;
+				std::vector<std::uint32_t> rebased;
+				if (sharded) {
+					rebased = rebased_copies(rows, first, last, m_copy_shards[k]);
+					batch.copy_index = rebased.data();
+				}
 				std::vector<std::uint64_t> cut_offsets;
 				if (rows.any_cuts) {   // re-base the CSR offsets of the shard
 					cut_offsets.assign(rows.cut_offsets.begin() + first, rows.cut_offsets.begin() + last + 1);

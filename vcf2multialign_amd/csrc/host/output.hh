@@ -44,6 +44,12 @@ public:
 	// up front; there is no collective and no reordering buffer -- SURVEY.md section 8e).  Unaligned output and
 	// std::ostream targets use the first context only.
 	void add_gpu(gpu_context &gpu) { m_more_gpus.push_back(&gpu); }
+
+	// The chromosome copies each context's path matrix holds (one entry per context, the first context first), when the
+	// matrix was sharded with upload_path_slice(): rows of a plain haplotype batch then go to the context that owns their
+	// copy, with the copy index re-based to the shard (the REF row to the first context).  Without shards every context is
+	// expected to hold the whole matrix and rows are split evenly.
+	void set_copy_shards(std::vector<copy_shard> shards) { m_copy_shards = std::move(shards); }
 	virtual void output_a2m(variant_graph const &graph, std::ostream &stream) = 0;
 
 protected:
@@ -55,6 +61,7 @@ protected:
 		bool any_cuts{};
 	};
 	void splice(row_set const &rows, v2m_sink_fn sink, void *user);
+	static std::vector<std::uint32_t> rebased_copies(row_set const &rows, std::uint64_t first, std::uint64_t last, copy_shard shard);
 	void write_a2m(row_set const &rows, std::ostream &stream);
 	void write_a2m_sharded(row_set const &rows, char const *dst_name);
 	virtual row_set a2m_rows(variant_graph const &graph) = 0;
@@ -63,6 +70,7 @@ protected:
 
 	gpu_context &m_gpu;
 	std::vector<gpu_context *> m_more_gpus;
+	std::vector<copy_shard> m_copy_shards;
 	char const *m_pipe_cmd{};
 	char const *m_chromosome_id{};
 	output_delegate *m_delegate{};

@@ -138,7 +138,7 @@ __device__ __forceinline__ bool xcd_chunked_item(u32 block, u64 n_items, u32 ite
 // 8*kR contiguous bytes, every destination column receives 8*kC contiguous bytes.
 template <int kR, int kC>
 __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
-	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd)
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
 {
 	static_assert(kR % 4 == 0, "each of the 4 waves owns kR / 4 row-words");
 	// phase 1 view: [source column within panel = 64*kC][kR + 1]; phase 2 view: [destination column = 64*kR][kC + 1].
@@ -151,8 +151,8 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 	int const wave = t >> 6;
 	u64 item;
 	if (!xcd_chunked_item(blockIdx.x, (u64) n_row_panels * n_col_panels, items_per_xcd, item)) return;   // whole workgroup
-	// the shorter dimension runs fastest: both kinds of neighbours (sharing source lines / destination lines) stay close in time
-	bool const rows_fastest = n_row_panels <= n_col_panels;
+	// rows_fastest: vertically adjacent panels (which share source lines) are consecutive items; otherwise horizontally
+	// adjacent ones (which share destination lines).  The host picks per shape.
 	u64 const rw0 = (rows_fastest ? item % n_row_panels : item / n_col_panels) * kR;    // first source row-word
 	u64 const cg0 = (rows_fastest ? item / n_row_panels : item % n_col_panels) * kC;    // first source column group
 	u64 const n_cols = DW * 64;
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 constexpr int kTsR = 16, kTsC = 16;
 
 __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
-	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd)
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
 {
 	constexpr int kA = kTsR / 4;                         // row-words per wave
 	__shared__ u64 in[2][64][kTsR + 1];
@@ -217,7 +217,6 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 	int const wave = t >> 6;
 	u64 item;
 	if (!xcd_chunked_item(blockIdx.x, (u64) n_row_panels * n_col_panels, items_per_xcd, item)) return;   // whole workgroup
-	bool const rows_fastest = n_row_panels <= n_col_panels;
 	u64 const rw0 = (rows_fastest ? item % n_row_panels : item / n_col_panels) * kTsR;
 	u64 const cg0 = (rows_fastest ? item / n_row_panels : item % n_col_panels) * kTsC;
 	u64 const n_cols = DW * 64;

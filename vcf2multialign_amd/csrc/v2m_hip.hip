@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -92,10 +93,15 @@ struct v2m_ctx {
 	// paths_by_chrom_copy_and_edge
 	u64 const *d_paths{};
 	dev_buf owned_paths;
+	dev_buf d_slice_src;     // v2m_upload_path_slice: the un-transposed slice (released after the transpose)
 	u64 path_rows{}, path_cols{};
 
 	struct transpose_pick { u64 rows, cols; std::string kernel; };
 	std::vector<transpose_pick> transpose_choice;   // per matrix shape: which transpose kernel measured fastest
+
+	// output buffers handed out by v2m_alloc_output that are mapped from physical chunks (see there)
+	struct mapped_output { void *va; size_t bytes; size_t chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
+	std::vector<mapped_output> mapped_outputs;
 
 	// store flavour of the aligned splice: -1 = not calibrated yet, 0 = plain, 1 = nontemporal
 	int store_mode{-1};
@@ -205,8 +211,17 @@ bool make_xcd_grid(u64 n_items, bool xcd, xcd_grid &g)
 	return true;
 }
 
+// Which dimension of the panel grid runs fastest in item order: 0 = the shorter one (both kinds of neighbours stay close
+// in time), 1 = row panels, 2 = column panels / spans.
+u32 rows_fastest_for(int order, u64 n_row_panels, u64 n_col_panels)
+{
+	if (1 == order) return 1;
+	if (2 == order) return 0;
+	return n_row_panels <= n_col_panels ? 1u : 0u;
+}
+
 template <int kR, int kC>
-int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, bool xcd)
+int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, bool xcd, int order)
 {
 	u64 const P((SW + kR - 1) / kR), Q((DW + kC - 1) / kC);
 	xcd_grid g;
@@ -214,20 +229,20 @@ int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *
 		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch (%llu x %llu bits)", (unsigned long long) (SW * 64), (unsigned long long) (DW * 64));
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL((v2m::transpose_bits_kernel<kR, kC>), dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, u32(P), u32(Q), g.items_per_xcd);
+		hipLaunchKernelGGL((v2m::transpose_bits_kernel<kR, kC>), dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
 }
 
-int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, bool xcd)
+int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, bool xcd, int order)
 {
 	u64 const P((SW + v2m::kTsR - 1) / v2m::kTsR), Q((DW + v2m::kTsC - 1) / v2m::kTsC);
 	xcd_grid g;
 	if (P > 0xFFFFFFFFull || Q > 0xFFFFFFFFull || !make_xcd_grid(P * Q, xcd, g)) return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL(v2m::transpose_bits_stream_kernel, dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, u32(P), u32(Q), g.items_per_xcd);
+		hipLaunchKernelGGL(v2m::transpose_bits_stream_kernel, dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
@@ -236,7 +251,7 @@ int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 
 // The sector-aligned streaming kernel: kR row-words per workgroup on kW waves, kS-word sectors, kD steps of prefetch,
 // spans of `span_groups` column groups (0 = default).
 template <int kR, int kW, int kS, int kD, bool kFast>
-int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, u64 span_groups, bool xcd)
+int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, u64 span_groups, bool xcd, int order)
 {
 	if (0 == span_groups) span_groups = 64;
 	span_groups = (span_groups + kS - 1) / kS * kS;
@@ -247,18 +262,28 @@ int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
 		hipLaunchKernelGGL((v2m::transpose_bits_ring_kernel<kR, kW, kS, kD, kFast>), dim3(g.blocks), dim3(64 * kW), 0, ctx->stream,
-			d_src, d_dst, SW, DW, u32(P), u32(NS), u32(span_groups), g.items_per_xcd, u32(P <= NS ? 1 : 0));
+			d_src, d_dst, SW, DW, u32(P), u32(NS), u32(span_groups), g.items_per_xcd, rows_fastest_for(order, P, NS));
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
 }
 
 // Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "ring:R,W,S,D[,K[,slow]]" (slow = ds_bpermute
-// butterfly); a trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks.
+// butterfly); trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks, "/pf" / "/sf" make the row
+// panels / the column panels (spans) run fastest in item order instead of the shorter dimension.
 int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
 {
 	bool xcd(true);
-	if (shape.size() > 3 && 0 == shape.compare(shape.size() - 3, 3, "/rr")) { xcd = false; shape.resize(shape.size() - 3); }
+	int order(0);
+	for (bool again(true); again && shape.size() > 3;) {
+		std::string const tail(shape.substr(shape.size() - 3));
+		again = true;
+		if (tail == "/rr") xcd = false;
+		else if (tail == "/pf") order = 1;
+		else if (tail == "/sf") order = 2;
+		else again = false;
+		if (again) shape.resize(shape.size() - 3);
+	}
 	if (0 == shape.compare(0, 5, "ring:")) {
 		int R(0), W(0), S(0), D(0), K(0);
 		char tail[16] = "";
@@ -267,28 +292,28 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		bool const fast(0 != std::strcmp(tail, "slow"));
 #define V2M_RING(r, w, s, d)                                                                                         \
 		if (R == r && W == w && S == s && D == d)                                                                    \
-			return fast ? launch_transpose_ring<r, w, s, d, true>(ctx, d_src, SW, DW, d_dst, u64(K), xcd)              \
-			            : launch_transpose_ring<r, w, s, d, false>(ctx, d_src, SW, DW, d_dst, u64(K), xcd);
+			return fast ? launch_transpose_ring<r, w, s, d, true>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order)       \
+			            : launch_transpose_ring<r, w, s, d, false>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order);
 		V2M_RING(16, 8, 8, 4) V2M_RING(16, 4, 8, 4) V2M_RING(16, 16, 8, 4) V2M_RING(16, 8, 8, 8) V2M_RING(16, 16, 8, 8)
-		V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4) V2M_RING(8, 4, 8, 4) V2M_RING(8, 8, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 4, 8)
+		V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4) V2M_RING(8, 4, 8, 4) V2M_RING(8, 8, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 4, 8) V2M_RING(8, 8, 8, 2) V2M_RING(8, 8, 8, 8)
 #undef V2M_RING
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not instantiated", shape.c_str());
 	}
-	if (shape == "stream16") return launch_transpose_stream(ctx, d_src, SW, DW, d_dst, xcd);
-	if (shape == "4x16") return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, d_dst, xcd);
-	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, d_dst, xcd);
-	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, d_dst, xcd);
-	if (shape == "4x8") return launch_transpose_shape<4, 8>(ctx, d_src, SW, DW, d_dst, xcd);
-	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, d_dst, xcd);
-	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, d_dst, xcd);
-	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, d_dst, xcd);
+	if (shape == "stream16") return launch_transpose_stream(ctx, d_src, SW, DW, d_dst, xcd, order);
+	if (shape == "4x16") return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, d_dst, xcd, order);
+	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, d_dst, xcd, order);
+	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, d_dst, xcd, order);
+	if (shape == "4x8") return launch_transpose_shape<4, 8>(ctx, d_src, SW, DW, d_dst, xcd, order);
+	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, d_dst, xcd, order);
+	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, d_dst, xcd, order);
+	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, d_dst, xcd, order);
 	return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "unknown transpose kernel '%s'", shape.c_str());
 }
 
 // Several kernels implement the transpose; which is fastest depends on the matrix shape, so matrices of at least 32 MiB
 // are timed once per shape and context with each candidate (the result is the same either way) and the fastest is
 // remembered.  V2M_TRANSPOSE_PANEL forces one; V2M_TRANSPOSE_CANDIDATES (comma-free list separated by ';') replaces the list.
-char const *const kTransposeCandidates[] = {"8x8", "stream16"};
+char const *const kTransposeCandidates[] = {"8x8", "stream16", "ring:8,8,8,4,64"};
 
 int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst)
 {
@@ -557,8 +582,8 @@ int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin,
 	int mode(forced_store_mode());
 	if (mode < 0) mode = ctx->store_mode;
 	if (mode < 0 && n_rows * ctx->aligned_len >= (u64(1) << 30)) {
-		hipEvent_t ev[5];
-		for (auto &e : ev) V2M_HIP_TRY(ctx, hipEventCreate(&e));
+		scoped_events ev;
+		V2M_HIP_TRY(ctx, ev.create(5));
 		V2M_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
 		for (int i(0); i < 4; ++i) {
 			launch(0 == (i & 1));   // nt, plain, nt, plain
@@ -567,7 +592,6 @@ int splice_aligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin,
 		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 		float t[4];
 		for (int i(0); i < 4; ++i) V2M_HIP_TRY(ctx, hipEventElapsedTime(&t[i], ev[i], ev[i + 1]));
-		for (auto &e : ev) (void) hipEventDestroy(e);
 		float const nt_ms(std::min(t[0], t[2])), plain_ms(std::min(t[1], t[3]));
 		ctx->store_mode = nt_ms <= plain_ms ? 1 : 0;
 		char buf[160];
@@ -617,12 +641,15 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 	V2M_HIP_TRY(ctx, ctx->d_tile_counts.ensure(n_rows * ctx->n_tiles * sizeof(u32)));
 	v2m::tile_tables tt{ctx->d_tile_edge_begin.as<u32>(), ctx->d_cross_offsets.as<u32>(), ctx->d_cross_edges.as<u32>()};
 	{
-		timed_launch tl(ctx, V2M_KERNEL_SPLICE_UNALIGNED);
+		timed_launch tl(ctx, V2M_KERNEL_UNALIGNED_COUNT);
 		hipLaunchKernelGGL(v2m::count_unaligned_kernel, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 			ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
 			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
 		hipLaunchKernelGGL(v2m::scan_tile_counts_kernel, dim3(unsigned(n_rows)), dim3(256), 0, ctx->stream,
 			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, ctx->d_row_lengths.as<u64>());
+	}
+	{
+		timed_launch tl(ctx, V2M_KERNEL_SPLICE_UNALIGNED);
 		char const *const mode_env(std::getenv("V2M_UNALIGNED_STORE"));   // tuning knob: plain | nt (default)
 		bool const plain(mode_env && 0 == std::strcmp(mode_env, "plain"));
 		auto const launch([&](auto kernel) {
@@ -635,6 +662,58 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
+}
+
+
+// An output buffer mapped from physically contiguous chunks (hipMemCreate / hipMemMap).  Why: the rate the splice's
+// store pattern reaches on a hipMalloc'ed buffer depends on how fragmented its physical backing happens to be (5.4 - 7.0
+// TB/s, fixed for the life of the allocation); buffers put together from 512-MB chunks reach 6.9 - 7.0 TB/s every time
+// (profiles/r01/output_buffer_physical_backing.txt, profiles/r02/vmm_probe2.txt).  Chunks of 2 GB are NOT used: mapped
+// into an address range that smaller chunks had occupied before, they left unmapped holes on this stack (the probe's
+// fault, placed in profiles/r02/vmm_probe2.txt); 512-MB chunks never did, address reuse included.
+constexpr size_t kOutputChunkDefault = size_t(512) << 20;
+
+void release_mapped(v2m_ctx::mapped_output &m, size_t n_mapped)
+{
+	for (size_t i(0); i < n_mapped; ++i) (void) hipMemUnmap(static_cast<char *>(m.va) + i * m.chunk, m.chunk);   // chunk by chunk, as mapped
+	if (m.va) (void) hipMemAddressFree(m.va, m.bytes);
+	for (auto h : m.handles) (void) hipMemRelease(h);                                                             // after the range is gone
+	m = {};
+}
+
+// Returns hipSuccess and fills `out`, or an error with nothing left allocated.
+hipError_t map_output(v2m_ctx *ctx, size_t bytes, size_t chunk, v2m_ctx::mapped_output &out)
+{
+	hipMemAllocationProp prop{};
+	prop.type = hipMemAllocationTypePinned;
+	prop.location.type = hipMemLocationTypeDevice;
+	prop.location.id = ctx->device;
+	size_t gran(0);
+	hipError_t st(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+	if (hipSuccess != st) return st;
+	if (0 == gran || chunk % gran) return hipErrorInvalidValue;
+	v2m_ctx::mapped_output m{};
+	m.chunk = chunk;
+	size_t const n((bytes + chunk - 1) / chunk);
+	m.bytes = n * chunk;
+	for (size_t i(0); i < n; ++i) {
+		hipMemGenericAllocationHandle_t h{};
+		if (hipSuccess != (st = hipMemCreate(&h, chunk, &prop, 0))) { release_mapped(m, 0); return st; }
+		m.handles.push_back(h);
+	}
+	if (hipSuccess != (st = hipMemAddressReserve(&m.va, m.bytes, chunk, nullptr, 0))) { m.va = nullptr; release_mapped(m, 0); return st; }
+	size_t mapped(0);
+	for (; mapped < n; ++mapped)
+		if (hipSuccess != (st = hipMemMap(static_cast<char *>(m.va) + mapped * chunk, chunk, 0, m.handles[mapped], 0))) break;
+	if (hipSuccess == st) {
+		hipMemAccessDesc access{};
+		access.location = prop.location;
+		access.flags = hipMemAccessFlagsProtReadWrite;
+		st = hipMemSetAccess(m.va, m.bytes, &access, 1);
+	}
+	if (hipSuccess != st) { release_mapped(m, mapped); return st; }
+	out = std::move(m);
+	return hipSuccess;
 }
 
 
@@ -684,9 +763,14 @@ int v2m_ctx_create(int device_id, v2m_ctx **ctx_out)
 		delete ctx;
 		return fail(nullptr, V2M_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(st));
 	}
-	for (int i(0); i < 2; ++i) {
-		(void) hipEventCreateWithFlags(&ctx->ev_compute[i], hipEventDisableTiming);
-		(void) hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
+	for (int i(0); i < 2 && hipSuccess == st; ++i) {
+		st = hipEventCreateWithFlags(&ctx->ev_compute[i], hipEventDisableTiming);
+		if (hipSuccess == st) st = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
+	}
+	if (hipSuccess != st) {
+		std::string const what(hipGetErrorString(st));
+		v2m_ctx_destroy(ctx);   // destroys whatever was created
+		return fail(nullptr, V2M_ERR_HIP, "hipEventCreateWithFlags: %s", what.c_str());
 	}
 	*ctx_out = ctx;
 	return V2M_OK;
@@ -698,6 +782,9 @@ void v2m_ctx_destroy(v2m_ctx *ctx)
 	(void) hipSetDevice(ctx->device);
 	(void) hipStreamSynchronize(ctx->stream);
 	(void) hipStreamSynchronize(ctx->copy_stream);
+	if (!ctx->mapped_outputs.empty()) (void) hipDeviceSynchronize();
+	for (auto &m : ctx->mapped_outputs) release_mapped(m, m.handles.size());
+	ctx->mapped_outputs.clear();
 	for (auto &v : ctx->events) for (auto &e : v) { (void) hipEventDestroy(e.begin); (void) hipEventDestroy(e.end); }
 	for (auto &e : ctx->free_events) { (void) hipEventDestroy(e.begin); (void) hipEventDestroy(e.end); }
 	for (int i(0); i < 2; ++i) {
@@ -920,6 +1007,70 @@ int v2m_set_paths_device(v2m_ctx *ctx, const void *d_words, uint64_t path_rows, 
 	return V2M_OK;
 }
 
+int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_rows, uint64_t n_cols, uint64_t first_copy, uint64_t n_copies)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (!ctx->has_graph) return fail(ctx, V2M_ERR_STATE, "no graph uploaded");
+	if (n_rows % 64 || n_cols % 64)                            // transpose_matrix.cc:53-54
+		return fail(ctx, V2M_ERR_PRECONDITION, "matrix dimensions must be multiples of 64 (got %llu x %llu)", (unsigned long long) n_rows, (unsigned long long) n_cols);
+	if (n_cols < ctx->n_edges) return fail(ctx, V2M_ERR_PRECONDITION, "path matrix has %llu edge columns, the graph %llu edges", (unsigned long long) n_cols, (unsigned long long) ctx->n_edges);
+	if (first_copy % 8) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "first_copy must be a multiple of 8 (whole bytes of the bit-packed columns)");
+	if (first_copy > n_rows || n_copies > n_rows - first_copy) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "copies [%llu, %llu) are outside the matrix (%llu rows)", (unsigned long long) first_copy, (unsigned long long) (first_copy + n_copies), (unsigned long long) n_rows);
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ctx->d_paths = nullptr;
+	ctx->path_rows = ctx->path_cols = 0;
+	if (0 == n_copies || 0 == n_cols) return V2M_OK;              // nothing to bind: rows of this ctx can only be REF rows
+	if (!src_words) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL matrix pointer");
+
+	u64 const hp((n_copies + 63) / 64 * 64);                      // the slice's row count: this GPU's copies, padded
+	size_t const col_bytes(hp / 8), take((n_copies + 7) / 8), src_col_bytes(n_rows / 8), bytes(col_bytes * n_cols);
+	V2M_HIP_TRY(ctx, ctx->d_slice_src.ensure(bytes));
+	V2M_HIP_TRY(ctx, ctx->owned_paths.ensure(bytes));
+	char const *const src(reinterpret_cast<char const *>(src_words) + first_copy / 8);
+	if (take == src_col_bytes) {
+		// the whole matrix: one contiguous copy
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slice_src.p, src_words, bytes, hipMemcpyHostToDevice, ctx->stream));
+	} else {
+		// bytes [first_copy / 8, +take) of every column, packed into pinned slots by a few host threads and sent slot by slot
+		unsigned char const tail_mask((n_copies % 8) ? (unsigned char) ((1u << (n_copies % 8)) - 1) : (unsigned char) 0xFF);
+		size_t const slot_cols(std::max<size_t>(1, std::min<size_t>(n_cols, (size_t(64) << 20) / col_bytes)));
+		for (int i(0); i < 2; ++i) V2M_HIP_TRY(ctx, ctx->host_ring[i].ensure(slot_cols * col_bytes));
+		scoped_events sent;
+		V2M_HIP_TRY(ctx, sent.create(2));
+		size_t slot_index(0);
+		for (size_t c0(0); c0 < n_cols; c0 += slot_cols, ++slot_index) {
+			size_t const nc(std::min(slot_cols, size_t(n_cols) - c0));
+			int const b(int(slot_index & 1));
+			if (slot_index >= 2) V2M_HIP_TRY(ctx, hipEventSynchronize(sent[b]));   // the slot's previous upload has left the host buffer
+			char *const stage(static_cast<char *>(ctx->host_ring[b].p));
+			auto const pack([&](size_t lo, size_t hi) {
+				for (size_t c(lo); c < hi; ++c) {
+					char *const d(stage + c * col_bytes);
+					std::memcpy(d, src + (c0 + c) * src_col_bytes, take);
+					d[take - 1] = char((unsigned char) d[take - 1] & tail_mask);   // bits of copies past the slice are the next GPU's
+					if (take < col_bytes) std::memset(d + take, 0, col_bytes - take);
+				}
+			});
+			unsigned const n_threads(unsigned(std::max<size_t>(1, std::min<size_t>(8, nc * col_bytes >> 22))));
+			if (n_threads <= 1) pack(0, nc);
+			else {
+				std::vector<std::thread> pool;
+				for (unsigned t(0); t < n_threads; ++t) pool.emplace_back(pack, nc * t / n_threads, nc * (t + 1) / n_threads);
+				for (auto &t : pool) t.join();
+			}
+			V2M_HIP_TRY(ctx, hipMemcpyAsync(static_cast<char *>(ctx->d_slice_src.p) + c0 * col_bytes, stage, nc * col_bytes, hipMemcpyHostToDevice, ctx->stream));
+			V2M_HIP_TRY(ctx, hipEventRecord(sent[b], ctx->stream));
+		}
+	}
+	if (int const rc = launch_transpose(ctx, ctx->d_slice_src.as<u64>(), hp, n_cols, ctx->owned_paths.as<u64>())) return rc;
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->d_slice_src.reset();
+	ctx->d_paths = ctx->owned_paths.as<u64>();
+	ctx->path_rows = n_cols;
+	ctx->path_cols = hp;
+	return V2M_OK;
+}
+
 uint64_t v2m_aligned_length(const v2m_ctx *ctx) { return (ctx && ctx->has_graph) ? ctx->aligned_len : 0; }
 uint64_t v2m_min_row_pitch(const v2m_ctx *ctx) { return (ctx && ctx->has_graph) ? ((ctx->aligned_len + 255) & ~u64(255)) : 0; }
 uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx) { return (ctx && ctx->has_graph) ? ctx->ref_len + ctx->label_bytes : 0; }
@@ -1019,7 +1170,30 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 }
 
 
-// ---- placement-probed output buffers -----------------------------------------------------------
+// ---- output buffers ------------------------------------------------------------------------------
+
+namespace {
+
+// ms of the probe pattern on a buffer (best of two after a warm-up that populates the page tables)
+int probe_output(v2m_ctx *ctx, void *p, u64 pitch, u32 n_groups, float &ms_out)
+{
+	scoped_events ev;
+	V2M_HIP_TRY(ctx, ev.create(2));
+	u32 const n_tiles(u32(pitch / v2m::kTileBytes));
+	ms_out = 1e30f;
+	for (int rep(0); rep < 3; ++rep) {
+		V2M_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+		hipLaunchKernelGGL(v2m::probe_write_kernel, dim3(n_tiles * n_groups), dim3(v2m::kSpliceThreads), 0, ctx->stream, static_cast<char *>(p), pitch, n_groups);
+		V2M_HIP_TRY(ctx, hipEventRecord(ev[1], ctx->stream));
+		V2M_HIP_TRY(ctx, hipEventSynchronize(ev[1]));
+		float t(0);
+		V2M_HIP_TRY(ctx, hipEventElapsedTime(&t, ev[0], ev[1]));
+		if (rep) ms_out = std::min(ms_out, t);
+	}
+	return V2M_OK;
+}
+
+} // namespace
 
 int v2m_alloc_output(v2m_ctx *ctx, uint64_t bytes, int candidates, void **d_out)
 {
@@ -1027,60 +1201,87 @@ int v2m_alloc_output(v2m_ctx *ctx, uint64_t bytes, int candidates, void **d_out)
 	if (!d_out || 0 == bytes) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad v2m_alloc_output arguments");
 	*d_out = nullptr;
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
 	// the probe writes n_groups x 16 pseudo-rows of whole tiles; too small a buffer cannot be probed meaningfully
 	u32 const n_groups(32);
 	u64 const pitch((bytes / (n_groups * 16)) & ~u64(v2m::kTileBytes - 1));
-	bool const probe(candidates > 1 && pitch >= u64(64) * v2m::kTileBytes);
-	std::vector<void *> bufs;
-	std::vector<float> ms;
+	bool const can_probe(pitch >= u64(64) * v2m::kTileBytes);
+	auto const note([&](std::string const &text) {
+		if (ctx->info.size() > 2000) ctx->info.clear();   // keep the note bounded over many allocations
+		if (!ctx->info.empty()) ctx->info += "; ";
+		ctx->info += text;
+	});
+
+	// 1. a buffer mapped from 512-MB physical chunks (V2M_OUTPUT_CHUNK_MB: another size, 0 = off); worth it from a few chunks up
+	char const *const chunk_env(std::getenv("V2M_OUTPUT_CHUNK_MB"));
+	size_t const chunk((chunk_env && *chunk_env) ? size_t(std::strtoull(chunk_env, nullptr, 10)) << 20 : kOutputChunkDefault);
+	if (chunk && chunk < (size_t(2) << 30) && bytes >= 4 * chunk) {
+		v2m_ctx::mapped_output m;
+		hipError_t const st(map_output(ctx, bytes, chunk, m));
+		if (hipSuccess == st) {
+			char buf[200];
+			float ms(0);
+			if (can_probe && V2M_OK == probe_output(ctx, m.va, pitch, n_groups, ms))
+				std::snprintf(buf, sizeof(buf), "output buffer mapped from %zu physical chunks of %zu MB, probe write rate %.0f GB/s", m.handles.size(), chunk >> 20, double(pitch) * n_groups * 16 / (ms * 1e6));
+			else
+				std::snprintf(buf, sizeof(buf), "output buffer mapped from %zu physical chunks of %zu MB", m.handles.size(), chunk >> 20);
+			note(buf);
+			*d_out = m.va;
+			ctx->mapped_outputs.push_back(std::move(m));
+			return V2M_OK;
+		}
+		(void) hipGetLastError();
+		note(std::string("chunk-mapped output buffer not available (") + hipGetErrorString(st) + "), using hipMalloc");
+	}
+
+	// 2. hipMalloc; with candidates > 1 several are held at once, the store pattern is timed on each and the fastest kept
+	struct candidate_set {
+		std::vector<void *> bufs;
+		void *keep{};
+		~candidate_set() { for (void *p : bufs) if (p != keep) (void) hipFree(p); }
+	} cs;
+	bool const probe(candidates > 1 && can_probe);
 	for (int c(0); c < (probe ? candidates : 1); ++c) {
 		void *p(nullptr);
 		hipError_t const st(hipMalloc(&p, bytes));
 		if (hipSuccess != st) {
 			(void) hipGetLastError();
-			if (bufs.empty()) return fail(ctx, V2M_ERR_OUT_OF_MEMORY, "hipMalloc of %llu bytes failed: %s", (unsigned long long) bytes, hipGetErrorString(st));
+			if (cs.bufs.empty()) return fail(ctx, V2M_ERR_OUT_OF_MEMORY, "hipMalloc of %llu bytes failed: %s", (unsigned long long) bytes, hipGetErrorString(st));
 			break;   // keep what fits
 		}
-		bufs.push_back(p);
+		cs.bufs.push_back(p);
 	}
 	std::size_t best(0);
-	if (probe && bufs.size() > 1) {
-		hipEvent_t a, b;
-		V2M_HIP_TRY(ctx, hipEventCreate(&a));
-		V2M_HIP_TRY(ctx, hipEventCreate(&b));
-		u32 const n_tiles(u32(pitch / v2m::kTileBytes));
-		for (void *p : bufs) {
-			float t_best(1e30f);
-			for (int rep(0); rep < 3; ++rep) {
-				V2M_HIP_TRY(ctx, hipEventRecord(a, ctx->stream));
-				hipLaunchKernelGGL(v2m::probe_write_kernel, dim3(n_tiles * n_groups), dim3(v2m::kSpliceThreads), 0, ctx->stream, static_cast<char *>(p), pitch, n_groups);
-				V2M_HIP_TRY(ctx, hipEventRecord(b, ctx->stream));
-				V2M_HIP_TRY(ctx, hipEventSynchronize(b));
-				float t(0);
-				V2M_HIP_TRY(ctx, hipEventElapsedTime(&t, a, b));
-				if (rep) t_best = std::min(t_best, t);   // first run is a warm-up (page-table population)
-			}
-			ms.push_back(t_best);
+	if (probe && cs.bufs.size() > 1) {
+		std::vector<float> ms;
+		for (void *p : cs.bufs) {
+			float t(0);
+			if (int const rc = probe_output(ctx, p, pitch, n_groups, t)) return rc;   // cs frees every candidate
+			ms.push_back(t);
 		}
-		(void) hipEventDestroy(a);
-		(void) hipEventDestroy(b);
 		best = std::size_t(std::min_element(ms.begin(), ms.end()) - ms.begin());
-		std::string note("output buffer chosen among " + std::to_string(bufs.size()) + " candidates by probe write rate (GB/s):");
-		for (float const t : ms) { char b2[32]; std::snprintf(b2, sizeof(b2), " %.0f", double(pitch) * n_groups * 16 / (t * 1e6)); note += b2; }
-		if (ctx->info.size() > 2000) ctx->info.clear();   // keep the note bounded over many allocations
-		if (!ctx->info.empty()) ctx->info += "; ";
-		ctx->info += note;
+		std::string text("output buffer chosen among " + std::to_string(cs.bufs.size()) + " hipMalloc candidates by probe write rate (GB/s):");
+		for (float const t : ms) { char b2[32]; std::snprintf(b2, sizeof(b2), " %.0f", double(pitch) * n_groups * 16 / (t * 1e6)); text += b2; }
+		note(text);
 	}
-	for (std::size_t i(0); i < bufs.size(); ++i)
-		if (i != best) (void) hipFree(bufs[i]);
-	*d_out = bufs[best];
+	cs.keep = cs.bufs[best];
+	*d_out = cs.keep;
 	return V2M_OK;
 }
 
 int v2m_free_output(v2m_ctx *ctx, void *d_ptr)
 {
 	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
-	if (d_ptr) V2M_HIP_TRY(ctx, hipFree(d_ptr));
+	if (!d_ptr) return V2M_OK;
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	for (auto it(ctx->mapped_outputs.begin()); it != ctx->mapped_outputs.end(); ++it) {
+		if (it->va != d_ptr) continue;
+		V2M_HIP_TRY(ctx, hipDeviceSynchronize());   // nothing may still be writing when the pages go away
+		release_mapped(*it, it->handles.size());
+		ctx->mapped_outputs.erase(it);
+		return V2M_OK;
+	}
+	V2M_HIP_TRY(ctx, hipFree(d_ptr));
 	return V2M_OK;
 }
 

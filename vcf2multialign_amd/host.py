@@ -51,12 +51,20 @@ def _load():
 		L.v2mh_find_founders_mt.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_uint]
 		L.v2mh_set_paths_by_chrom_copy_and_edge.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]
 		L.v2mh_overlap_get.argtypes = [C.c_void_p, C.c_uint64, _u64p, _u64p, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+		L.v2mh_shard_copies.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, _u64p, _u64p]
 		L.v2mh_write_cut_positions.restype = C.c_int
 		L.v2mh_write_cut_positions.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_char_p, C.c_size_t]
 		L.v2mh_read_cut_positions.restype = C.c_int
 		L.v2mh_read_cut_positions.argtypes = [C.c_char_p, C.c_void_p, _u64p, _u64p, C.POINTER(C.c_uint32), C.c_char_p, C.c_size_t]
 		_lib = L
 	return _lib
+
+
+def shard_copies(n_copies, world, rank):
+	"""The C++ driver's copy range of GPU `rank` of `world` (csrc/host/gpu_path.cc: shard_copies)."""
+	a, b = C.c_uint64(), C.c_uint64()
+	_load().v2mh_shard_copies(n_copies, world, rank, C.byref(a), C.byref(b))
+	return a.value, b.value
 
 
 def write_cut_positions(path, cut_positions, min_distance, score):
