@@ -468,14 +468,20 @@ def test_unaligned_keeps_dashes_and_case_of_the_reference(v2m, ctx, tmp_path):
 	assert ctx.splice_rows([v2m.PLOIDY_MAX], unaligned=True) == [ref]
 
 
-def test_alloc_output(v2m, ctx):
-	"""v2m_alloc_output: plain allocation for small sizes, measured choice among candidates for large ones."""
+def test_alloc_output(v2m, ctx, monkeypatch):
+	"""v2m_alloc_output: plain allocation for small sizes; from 2 GiB up a buffer mapped from 512-MB physical chunks; where
+	that is switched off, a measured choice among hipMalloc'ed candidates."""
 	p = ctx.alloc_output(1 << 20, candidates=3)
 	assert p and p % 256 == 0
 	ctx.free_output(p)
 	before = ctx.info
+	p = ctx.alloc_output(3 << 30, candidates=3)
+	assert p and p % (512 << 20) == 0 and "mapped from 6 physical chunks of 512 MB" in ctx.info[len(before):], ctx.info
+	ctx.free_output(p)
+	monkeypatch.setenv("V2M_OUTPUT_CHUNK_MB", "0")
+	before = ctx.info
 	p = ctx.alloc_output(3 << 30, candidates=3)          # 3 x 3 GiB candidates, probed
-	assert p and "output buffer chosen among" in ctx.info[len(before):]
+	assert p and "output buffer chosen among 3 hipMalloc candidates" in ctx.info[len(before):], ctx.info
 	ctx.free_output(p)
 	with pytest.raises(v2m.V2MError):
 		ctx.alloc_output(0)

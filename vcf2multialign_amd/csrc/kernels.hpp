@@ -326,26 +326,31 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 	u32 const cg_lo = first_span ? 0u : (u32) span_begin - (kS - 1);
 	u32 const n_steps = (u32) span_end - cg_lo;
 
-	// source words of this thread: column (t + kT * k) / kR of the group, row-word (t + kT * k) % kR of the panel
+	// Source words of this thread: column (t + kT * k) / kR of the group, row-word (t + kT * k) % kR of the panel.
+	// Every fetch is issued unconditionally, from an address clamped into the matrix (row-words past the matrix become
+	// zeros at the stash, steps past the span re-read its last group): the number of loads between a fetch and its use is
+	// then a compile-time constant and the compiler can wait with a counted s_waitcnt vmcnt(n) instead of vmcnt(0) --
+	// with loads under branches it drained the whole queue every step and the kernel ran at one memory latency per step.
 	u64 src_off[kA];
 	bool src_ok[kA];
 #pragma unroll
 	for (int k = 0; k < kA; ++k) {
 		int const idx = t + kT * k;
-		src_off[k] = (u64) (idx / kR) * SW + rw0 + idx % kR;
 		src_ok[k] = rw0 + idx % kR < SW;
+		src_off[k] = (u64) (idx / kR) * SW + (src_ok[k] ? rw0 + idx % kR : SW - 1);
 	}
+	u32 const cg_last = (u32) span_end - 1;
 	u64 pf[kD][kA];
 	auto const fetch = [&](u64 (&r)[kA], u32 cg) {
-		u64 const *const base = src + (u64) cg * 64 * SW;
+		u64 const *const base = src + (u64) (cg < cg_last ? cg : cg_last) * 64 * SW;
 #pragma unroll
-		for (int k = 0; k < kA; ++k) r[k] = src_ok[k] ? base[src_off[k]] : 0;
+		for (int k = 0; k < kA; ++k) r[k] = base[src_off[k]];
 	};
 	auto const stash = [&](int buf, u64 const (&r)[kA]) {
 #pragma unroll
 		for (int k = 0; k < kA; ++k) {
 			int const idx = t + kT * k;
-			stage[buf][idx / kR][idx % kR] = r[k];
+			stage[buf][idx / kR][idx % kR] = src_ok[k] ? r[k] : 0;
 		}
 	};
 
@@ -395,8 +400,7 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 	};
 
 #pragma unroll
-	for (int j = 0; j < kD; ++j)
-		if ((u32) j < n_steps) fetch(pf[j], cg_lo + j);
+	for (int j = 0; j < kD; ++j) fetch(pf[j], cg_lo + j);
 	stash(0, pf[0]);
 	for (u32 base = 0; base < n_steps; base += kD) {
 #pragma unroll
@@ -404,9 +408,9 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 			u32 const st = base + j;
 			if (st >= n_steps) break;
 			__syncthreads();                       // stage[j & 1] is complete; everyone is done with the other buffer
-			if (st + kD < n_steps) fetch(pf[j], cg_lo + st + kD);   // pf[j] was stashed during the previous step
+			fetch(pf[j], cg_lo + st + kD);         // pf[j] was stashed during the previous step
 			compute(cg_lo + st, j & 1);
-			if (st + 1 < n_steps) stash((j + 1) & 1, pf[(j + 1) % kD]);
+			stash((j + 1) & 1, pf[(j + 1) % kD]);  // (after the last step: a stash nobody reads)
 		}
 	}
 }

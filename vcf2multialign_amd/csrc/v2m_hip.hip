@@ -295,7 +295,7 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 			return fast ? launch_transpose_ring<r, w, s, d, true>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order)       \
 			            : launch_transpose_ring<r, w, s, d, false>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order);
 		V2M_RING(16, 8, 8, 4) V2M_RING(16, 4, 8, 4) V2M_RING(16, 16, 8, 4) V2M_RING(16, 8, 8, 8) V2M_RING(16, 16, 8, 8)
-		V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4) V2M_RING(8, 4, 8, 4) V2M_RING(8, 8, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 4, 8) V2M_RING(8, 8, 8, 2) V2M_RING(8, 8, 8, 8)
+		V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4) V2M_RING(8, 4, 8, 4) V2M_RING(8, 8, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 4, 8) V2M_RING(8, 8, 8, 2) V2M_RING(8, 8, 8, 8) V2M_RING(8, 8, 8, 16) V2M_RING(16, 16, 8, 16) V2M_RING(8, 4, 8, 16)
 #undef V2M_RING
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not instantiated", shape.c_str());
 	}
