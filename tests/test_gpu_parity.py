@@ -70,7 +70,7 @@ def test_transpose_fixed(ctx, case):   # tests/transpose_matrix.cc:188-251
 	assert np.array_equal(ctx.transpose_matrix(src, case["rows"], case["cols"]), exp)
 
 
-TRANSPOSE_KERNELS = ["8x8", "stream16", "4x16", "8x8/rr", "ring:16,8,8,4,16", "ring:16,8,8,4,64,slow", "ring:8,4,8,4,8", "ring:16,8,4,4,64", "ring:16,8,16,4,32", "ring:16,16,8,8,64/rr"]
+TRANSPOSE_KERNELS = ["8x8", "stream16", "4x16", "8x8/rr", "ring:16,8,8,4,16", "ring:16,8,8,4,64,slow", "ring:8,4,8,4,8", "ring:16,8,4,4,64", "ring:16,8,16,4,32", "ring:16,16,8,8,64/rr", "ring:8,8,8,8,64", "ring:8,8,8,8,128,nt", "ring:8,8,8,16,24/sf"]
 
 
 @pytest.mark.parametrize("kernel", TRANSPOSE_KERNELS)

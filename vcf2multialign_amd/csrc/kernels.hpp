@@ -300,7 +300,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 // shared lines are fetched from HBM once.  Source words are prefetched kD steps ahead in registers and staged through
 // a double-buffered LDS tile (one barrier per step); the ring needs no barrier (LDS operations of one wave execute in order).
 // ---------------------------------------------------------------------------------------------
-template <int kR, int kW, int kS, int kD, bool kFastLanes>
+template <int kR, int kW, int kS, int kD, bool kFastLanes, bool kNonTemporal>
 __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW,
 	u32 n_panels, u32 n_spans, u32 span_groups /* multiple of kS */, u32 items_per_xcd, u32 panel_fastest)
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 	auto const fetch = [&](u64 (&r)[kA], u32 cg) {
 		u64 const *const base = src + (u64) (cg < cg_last ? cg : cg_last) * 64 * SW;
 #pragma unroll
-		for (int k = 0; k < kA; ++k) r[k] = base[src_off[k]];
+		for (int k = 0; k < kA; ++k) r[k] = kNonTemporal ? __builtin_nontemporal_load(base + src_off[k]) : base[src_off[k]];
 	};
 	auto const stash = [&](int buf, u64 const (&r)[kA]) {
 #pragma unroll
@@ -394,7 +394,11 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 				bool ok = w <= slot && g0 + w >= row_base;                             // row end / row start: the rest belongs to the neighbouring rows
 				if (!first_span) ok = ok && g0 >= ((row_base + span_begin) & ~(u64) (kS - 1));
 				if (!last_span) ok = ok && g0 < ((row_base + span_end) & ~(u64) (kS - 1));
-				if (ok) dst[g0 + w] = ring[wave][a][row][w];
+				if (ok) {
+					u64 const v = ring[wave][a][row][w];
+					if (kNonTemporal) __builtin_nontemporal_store(v, dst + g0 + w);
+					else dst[g0 + w] = v;
+				}
 			}
 		}
 	};
@@ -407,6 +411,10 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 		for (int j = 0; j < kD; ++j) {
 			u32 const st = base + j;
 			if (st >= n_steps) break;
+			// The stash of the previous step must have landed in LDS before anyone passes the barrier.  __syncthreads() implies
+			// that wait, but hipcc (ROCm 7.2) drops it on the loop's back edge here (the header's s_barrier came out with no
+			// s_waitcnt lgkmcnt(0) on the path from the last step's ds_write): a few hundred wrong words per 79 M, now and then.
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			__syncthreads();                       // stage[j & 1] is complete; everyone is done with the other buffer
 			fetch(pf[j], cg_lo + st + kD);         // pf[j] was stashed during the previous step
 			compute(cg_lo + st, j & 1);

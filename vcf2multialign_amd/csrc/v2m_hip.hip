@@ -250,7 +250,7 @@ int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 
 
 // The sector-aligned streaming kernel: kR row-words per workgroup on kW waves, kS-word sectors, kD steps of prefetch,
 // spans of `span_groups` column groups (0 = default).
-template <int kR, int kW, int kS, int kD, bool kFast>
+template <int kR, int kW, int kS, int kD, bool kFast, bool kNT>
 int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, u64 span_groups, bool xcd, int order)
 {
 	if (0 == span_groups) span_groups = 64;
@@ -261,15 +261,15 @@ int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d
 		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL((v2m::transpose_bits_ring_kernel<kR, kW, kS, kD, kFast>), dim3(g.blocks), dim3(64 * kW), 0, ctx->stream,
+		hipLaunchKernelGGL((v2m::transpose_bits_ring_kernel<kR, kW, kS, kD, kFast, kNT>), dim3(g.blocks), dim3(64 * kW), 0, ctx->stream,
 			d_src, d_dst, SW, DW, u32(P), u32(NS), u32(span_groups), g.items_per_xcd, rows_fastest_for(order, P, NS));
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
 }
 
-// Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "ring:R,W,S,D[,K[,slow]]" (slow = ds_bpermute
-// butterfly); trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks, "/pf" / "/sf" make the row
+// Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "ring:R,W,S,D[,K[,slow|nt]]" (slow = ds_bpermute
+// butterfly, nt = nontemporal loads and stores); trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks, "/pf" / "/sf" make the row
 // panels / the column panels (spans) run fastest in item order instead of the shorter dimension.
 int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
 {
@@ -289,13 +289,14 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		char tail[16] = "";
 		int const got(std::sscanf(shape.c_str() + 5, "%d,%d,%d,%d,%d,%15s", &R, &W, &S, &D, &K, tail));
 		if (got < 4) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
-		bool const fast(0 != std::strcmp(tail, "slow"));
+		bool const fast(0 != std::strcmp(tail, "slow")), nt(0 == std::strcmp(tail, "nt"));
 #define V2M_RING(r, w, s, d)                                                                                         \
 		if (R == r && W == w && S == s && D == d)                                                                    \
-			return fast ? launch_transpose_ring<r, w, s, d, true>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order)       \
-			            : launch_transpose_ring<r, w, s, d, false>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order);
-		V2M_RING(16, 8, 8, 4) V2M_RING(16, 4, 8, 4) V2M_RING(16, 16, 8, 4) V2M_RING(16, 8, 8, 8) V2M_RING(16, 16, 8, 8)
-		V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4) V2M_RING(8, 4, 8, 4) V2M_RING(8, 8, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 4, 8) V2M_RING(8, 8, 8, 2) V2M_RING(8, 8, 8, 8) V2M_RING(8, 8, 8, 16) V2M_RING(16, 16, 8, 16) V2M_RING(8, 4, 8, 16)
+			return !fast ? launch_transpose_ring<r, w, s, d, false, false>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order) \
+				: nt ? launch_transpose_ring<r, w, s, d, true, true>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order)      \
+				     : launch_transpose_ring<r, w, s, d, true, false>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order);
+		V2M_RING(16, 8, 8, 4) V2M_RING(16, 16, 8, 8) V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4)
+		V2M_RING(8, 4, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 8, 4) V2M_RING(8, 8, 8, 8) V2M_RING(8, 8, 8, 16)
 #undef V2M_RING
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not instantiated", shape.c_str());
 	}
@@ -313,7 +314,7 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 // Several kernels implement the transpose; which is fastest depends on the matrix shape, so matrices of at least 32 MiB
 // are timed once per shape and context with each candidate (the result is the same either way) and the fastest is
 // remembered.  V2M_TRANSPOSE_PANEL forces one; V2M_TRANSPOSE_CANDIDATES (comma-free list separated by ';') replaces the list.
-char const *const kTransposeCandidates[] = {"8x8", "stream16", "ring:8,8,8,4,64"};
+char const *const kTransposeCandidates[] = {"8x8", "stream16", "ring:8,8,8,8,64", "ring:8,8,8,8,128"};
 
 int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst)
 {
