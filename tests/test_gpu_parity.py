@@ -476,7 +476,7 @@ def test_alloc_output(v2m, ctx, monkeypatch):
 	ctx.free_output(p)
 	before = ctx.info
 	p = ctx.alloc_output(3 << 30, candidates=3)
-	assert p and p % (512 << 20) == 0 and "mapped from 6 physical chunks of 512 MB" in ctx.info[len(before):], ctx.info
+	assert p and p % (2 << 20) == 0 and "mapped from 6 physical chunks of 512 MB" in ctx.info[len(before):], ctx.info
 	ctx.free_output(p)
 	monkeypatch.setenv("V2M_OUTPUT_CHUNK_MB", "0")
 	before = ctx.info
