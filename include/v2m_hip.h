@@ -196,13 +196,12 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
  * With row_lengths_out in unaligned mode the call waits for the kernels.  Use v2m_ctx_synchronize() before reading d_out. */
 int v2m_splice_rows_device(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, void *d_out, uint64_t row_pitch, uint64_t *row_lengths_out);
 
-/* Device memory for row output (the d_out of v2m_splice_rows_device).  On MI355X the write rate the splice's
- * store pattern reaches on a plain hipMalloc'ed buffer differs by ~25 % between allocations, depending on how
- * fragmented their physical backing is (tools/vmm_probe2.hip), which a caller cannot see from a pointer.  Buffers
- * of at least 2 GiB are therefore mapped from physically contiguous 512-MB chunks (hipMemCreate / hipMemMap), which
- * reach the full rate every time; v2m_ctx_info() says so.  Where that is not available (or for small buffers) the
- * buffer comes from hipMalloc, and with candidates > 1 up to that many are held at once, the store pattern is timed on
- * each and the fastest is kept.  Free with v2m_free_output() (or with the ctx).  Synchronous. */
+/* Device memory for row output (the d_out of v2m_splice_rows_device), chosen by measurement: on MI355X the write rate
+ * the splice's store pattern reaches differs by up to ~25 % between hipMalloc'ed buffers, depending on how fragmented
+ * their physical backing is, which a caller cannot see from a pointer.  Allocates up to `candidates` buffers of
+ * `bytes` (fewer if HBM runs out -- all of them are held until the choice is made), times the store pattern on each,
+ * keeps the fastest and frees the others; v2m_ctx_info() reports the rates.  candidates <= 1 (or a buffer too small to
+ * probe) is a plain allocation.  Free with v2m_free_output().  Synchronous. */
 int v2m_alloc_output(v2m_ctx *ctx, uint64_t bytes, int candidates, void **d_out);
 int v2m_free_output(v2m_ctx *ctx, void *d_ptr);
 

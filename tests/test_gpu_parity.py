@@ -468,17 +468,11 @@ def test_unaligned_keeps_dashes_and_case_of_the_reference(v2m, ctx, tmp_path):
 	assert ctx.splice_rows([v2m.PLOIDY_MAX], unaligned=True) == [ref]
 
 
-def test_alloc_output(v2m, ctx, monkeypatch):
-	"""v2m_alloc_output: plain allocation for small sizes; from 2 GiB up a buffer mapped from 512-MB physical chunks; where
-	that is switched off, a measured choice among hipMalloc'ed candidates."""
+def test_alloc_output(v2m, ctx):
+	"""v2m_alloc_output: plain allocation for small sizes, measured choice among candidates for large ones."""
 	p = ctx.alloc_output(1 << 20, candidates=3)
 	assert p and p % 256 == 0
 	ctx.free_output(p)
-	before = ctx.info
-	p = ctx.alloc_output(3 << 30, candidates=3)
-	assert p and p % (2 << 20) == 0 and "mapped from 6 physical chunks of 512 MB" in ctx.info[len(before):], ctx.info
-	ctx.free_output(p)
-	monkeypatch.setenv("V2M_OUTPUT_CHUNK_MB", "0")
 	before = ctx.info
 	p = ctx.alloc_output(3 << 30, candidates=3)          # 3 x 3 GiB candidates, probed
 	assert p and "output buffer chosen among 3 hipMalloc candidates" in ctx.info[len(before):], ctx.info
@@ -580,33 +574,30 @@ def test_path_slice_edges(ctx, v2m, tmp_path):
 		ctx.upload_path_slice(g.paths_by_edge_and_chrom_copy[:hp // 64 * 64], hp, 64, 0, hp)   # fewer edge columns than the graph has edges
 
 
-def test_output_buffer_is_ordinary_device_memory(ctx, v2m, tmp_path):
-	"""v2m_alloc_output's chunk-mapped buffers behave like any other device pointer: kernels write rows into them, interior
-	ranges that cross chunk boundaries copy back with hipMemcpy, alloc / free / alloc again works."""
+def test_output_buffer_allocate_free_allocate(ctx, v2m, tmp_path):
+	"""Every row lands in a buffer from v2m_alloc_output, also in one allocated right after another one was freed (the
+	address range is typically handed out again).  Round 2 tried buffers mapped from physical chunks (hipMemCreate /
+	hipMemMap) here: in the re-mapped buffer 115 of 1074 rows stayed zero on the first launch -- stale address
+	translations (profiles/r02/output_buffer_vmm_reuse.txt) -- which is why the library allocates with hipMalloc only."""
 	import ctypes
-	import torch
 	g = synth.build_case(tmp_path, 93, 3_000_000, 2000, 3)
 	vg = v2m.VariantGraph.from_object(g)
 	ctx.upload_graph(vg, g.ref)
 	L, pitch = g.aligned_length, ctx.min_row_pitch
-	n_rows = (3 << 30) // pitch + 1                                           # > 2 GiB: the chunk-mapped path, several 512-MB chunks
+	n_rows = (3 << 30) // pitch + 1
 	rows = [v2m.PLOIDY_MAX if i % 7 == 0 else i % 6 for i in range(n_rows)]
 	expected = {r: g.output_sequence(g.ref, copy_index=r) for r in set(rows)}
+	want = {r: v2m.checksum_rows_host([body])[0] for r, body in expected.items()}
+	want = np.array([want[r] for r in rows], dtype=np.uint64)
 	rt = ctypes.CDLL("libamdhip64.so.7")
 	rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-	for _ in range(2):
-		out = ctx.alloc_output(n_rows * pitch, 1)
-		assert "mapped from" in ctx.info and "512 MB" in ctx.info, ctx.info
+	for _ in range(3):
+		out = ctx.alloc_output(n_rows * pitch, 2)
 		ctx.splice_rows_device(rows, out, pitch)
 		sums = ctx.checksum_rows_device(out, pitch, n_rows, length=L)
-		want = {r: v2m.checksum_rows_host([body])[0] for r, body in expected.items()}
-		assert np.array_equal(sums, np.array([want[r] for r in rows], dtype=np.uint64))
-		chunk_rows = [(k << 29) // pitch for k in range(1, (n_rows * pitch) >> 29)]   # rows that straddle a chunk boundary
-		assert chunk_rows
-		for r in chunk_rows[:3] + [n_rows - 1]:
+		assert np.array_equal(sums, want), np.nonzero(sums != want)[0][:20]
+		for r in (0, n_rows // 2, n_rows - 1):
 			buf = ctypes.create_string_buffer(L)
 			assert rt.hipMemcpy(buf, out + r * pitch, L, 2) == 0
 			assert buf.raw == expected[rows[r]], r
 		ctx.free_output(out)
-	small = ctx.alloc_output(1 << 20, 1)                                       # small buffers stay plain allocations
-	ctx.free_output(small)

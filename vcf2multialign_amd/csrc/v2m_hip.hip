@@ -99,10 +99,6 @@ struct v2m_ctx {
 	struct transpose_pick { u64 rows, cols; std::string kernel; };
 	std::vector<transpose_pick> transpose_choice;   // per matrix shape: which transpose kernel measured fastest
 
-	// output buffers handed out by v2m_alloc_output that are mapped from physical chunks (see there)
-	struct mapped_output { void *va; size_t bytes; size_t chunk; std::vector<hipMemGenericAllocationHandle_t> handles; };
-	std::vector<mapped_output> mapped_outputs;
-
 	// store flavour of the aligned splice: -1 = not calibrated yet, 0 = plain, 1 = nontemporal
 	int store_mode{-1};
 	std::string info;
@@ -666,58 +662,6 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 }
 
 
-// An output buffer mapped from physically contiguous chunks (hipMemCreate / hipMemMap).  Why: the rate the splice's
-// store pattern reaches on a hipMalloc'ed buffer depends on how fragmented its physical backing happens to be (5.4 - 7.0
-// TB/s, fixed for the life of the allocation); buffers put together from 512-MB chunks reach 6.9 - 7.0 TB/s every time
-// (profiles/r01/output_buffer_physical_backing.txt, profiles/r02/vmm_probe2.txt).  Chunks of 2 GB are NOT used: mapped
-// into an address range that smaller chunks had occupied before, they left unmapped holes on this stack (the probe's
-// fault, placed in profiles/r02/vmm_probe2.txt); 512-MB chunks never did, address reuse included.
-constexpr size_t kOutputChunkDefault = size_t(512) << 20;
-
-void release_mapped(v2m_ctx::mapped_output &m, size_t n_mapped)
-{
-	for (size_t i(0); i < n_mapped; ++i) (void) hipMemUnmap(static_cast<char *>(m.va) + i * m.chunk, m.chunk);   // chunk by chunk, as mapped
-	if (m.va) (void) hipMemAddressFree(m.va, m.bytes);
-	for (auto h : m.handles) (void) hipMemRelease(h);                                                             // after the range is gone
-	m = {};
-}
-
-// Returns hipSuccess and fills `out`, or an error with nothing left allocated.
-hipError_t map_output(v2m_ctx *ctx, size_t bytes, size_t chunk, v2m_ctx::mapped_output &out)
-{
-	hipMemAllocationProp prop{};
-	prop.type = hipMemAllocationTypePinned;
-	prop.location.type = hipMemLocationTypeDevice;
-	prop.location.id = ctx->device;
-	size_t gran(0);
-	hipError_t st(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
-	if (hipSuccess != st) return st;
-	if (0 == gran || chunk % gran) return hipErrorInvalidValue;
-	v2m_ctx::mapped_output m{};
-	m.chunk = chunk;
-	size_t const n((bytes + chunk - 1) / chunk);
-	m.bytes = n * chunk;
-	for (size_t i(0); i < n; ++i) {
-		hipMemGenericAllocationHandle_t h{};
-		if (hipSuccess != (st = hipMemCreate(&h, chunk, &prop, 0))) { release_mapped(m, 0); return st; }
-		m.handles.push_back(h);
-	}
-	if (hipSuccess != (st = hipMemAddressReserve(&m.va, m.bytes, chunk, nullptr, 0))) { m.va = nullptr; release_mapped(m, 0); return st; }
-	size_t mapped(0);
-	for (; mapped < n; ++mapped)
-		if (hipSuccess != (st = hipMemMap(static_cast<char *>(m.va) + mapped * chunk, chunk, 0, m.handles[mapped], 0))) break;
-	if (hipSuccess == st) {
-		hipMemAccessDesc access{};
-		access.location = prop.location;
-		access.flags = hipMemAccessFlagsProtReadWrite;
-		st = hipMemSetAccess(m.va, m.bytes, &access, 1);
-	}
-	if (hipSuccess != st) { release_mapped(m, mapped); return st; }
-	out = std::move(m);
-	return hipSuccess;
-}
-
-
 int check_batch(v2m_ctx *ctx, v2m_row_batch const *rows, u32 flags)
 {
 	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
@@ -783,9 +727,6 @@ void v2m_ctx_destroy(v2m_ctx *ctx)
 	(void) hipSetDevice(ctx->device);
 	(void) hipStreamSynchronize(ctx->stream);
 	(void) hipStreamSynchronize(ctx->copy_stream);
-	if (!ctx->mapped_outputs.empty()) (void) hipDeviceSynchronize();
-	for (auto &m : ctx->mapped_outputs) release_mapped(m, m.handles.size());
-	ctx->mapped_outputs.clear();
 	for (auto &v : ctx->events) for (auto &e : v) { (void) hipEventDestroy(e.begin); (void) hipEventDestroy(e.end); }
 	for (auto &e : ctx->free_events) { (void) hipEventDestroy(e.begin); (void) hipEventDestroy(e.end); }
 	for (int i(0); i < 2; ++i) {
@@ -1213,29 +1154,11 @@ int v2m_alloc_output(v2m_ctx *ctx, uint64_t bytes, int candidates, void **d_out)
 		ctx->info += text;
 	});
 
-	// 1. a buffer mapped from 512-MB physical chunks (V2M_OUTPUT_CHUNK_MB: another size, 0 = off); worth it from a few chunks up
-	char const *const chunk_env(std::getenv("V2M_OUTPUT_CHUNK_MB"));
-	size_t const chunk((chunk_env && *chunk_env) ? size_t(std::strtoull(chunk_env, nullptr, 10)) << 20 : kOutputChunkDefault);
-	if (chunk && chunk < (size_t(2) << 30) && bytes >= 4 * chunk) {
-		v2m_ctx::mapped_output m;
-		hipError_t const st(map_output(ctx, bytes, chunk, m));
-		if (hipSuccess == st) {
-			char buf[200];
-			float ms(0);
-			if (can_probe && V2M_OK == probe_output(ctx, m.va, pitch, n_groups, ms))
-				std::snprintf(buf, sizeof(buf), "output buffer mapped from %zu physical chunks of %zu MB, probe write rate %.0f GB/s", m.handles.size(), chunk >> 20, double(pitch) * n_groups * 16 / (ms * 1e6));
-			else
-				std::snprintf(buf, sizeof(buf), "output buffer mapped from %zu physical chunks of %zu MB", m.handles.size(), chunk >> 20);
-			note(buf);
-			*d_out = m.va;
-			ctx->mapped_outputs.push_back(std::move(m));
-			return V2M_OK;
-		}
-		(void) hipGetLastError();
-		note(std::string("chunk-mapped output buffer not available (") + hipGetErrorString(st) + "), using hipMalloc");
-	}
-
-	// 2. hipMalloc; with candidates > 1 several are held at once, the store pattern is timed on each and the fastest kept
+	// hipMalloc; with candidates > 1 several are held at once, the store pattern is timed on each and the fastest kept.
+	// (Buffers mapped from physically contiguous chunks with hipMemCreate / hipMemMap write at the same rate as the best
+	// hipMalloc'ed ones, but that API is not used: on this stack (ROCm 7.2) a range that is unmapped, freed and mapped again
+	// keeps stale address translations -- rows written into a re-mapped buffer were silently lost, and the round-1 probe's
+	// GPU memory access fault was the same thing -- see profiles/r02/output_buffer_vmm_reuse.txt.)
 	struct candidate_set {
 		std::vector<void *> bufs;
 		void *keep{};
@@ -1275,13 +1198,6 @@ int v2m_free_output(v2m_ctx *ctx, void *d_ptr)
 	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
 	if (!d_ptr) return V2M_OK;
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
-	for (auto it(ctx->mapped_outputs.begin()); it != ctx->mapped_outputs.end(); ++it) {
-		if (it->va != d_ptr) continue;
-		V2M_HIP_TRY(ctx, hipDeviceSynchronize());   // nothing may still be writing when the pages go away
-		release_mapped(*it, it->handles.size());
-		ctx->mapped_outputs.erase(it);
-		return V2M_OK;
-	}
 	V2M_HIP_TRY(ctx, hipFree(d_ptr));
 	return V2M_OK;
 }
