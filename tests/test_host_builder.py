@@ -187,3 +187,13 @@ def test_graph_file_round_trip(HostGraph, tmp_path):
 	bad.write_bytes(b"not a graph file at all, just text\n" * 10)
 	with pytest.raises(ValueError, match="V2MGRAF1"):
 		HostGraph.read(bad)
+	# counts that do not fit the file are refused before anything is allocated from them (here: 2^39 edges claimed)
+	good = path.read_bytes()
+	huge = bytearray(good)
+	huge[8 + 8:8 + 16] = (1 << 39).to_bytes(8, "little")
+	bad.write_bytes(bytes(huge))
+	with pytest.raises(ValueError, match="do not match the size of the file"):
+		HostGraph.read(bad)
+	bad.write_bytes(good + b"\0" * 8)
+	with pytest.raises(ValueError, match="do not match the size of the file"):
+		HostGraph.read(bad)

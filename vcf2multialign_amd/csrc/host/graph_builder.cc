@@ -126,6 +126,16 @@ bool graph_builder::add_record(u64 ref_pos, u64 ref_allele_length, alt_allele co
 }
 
 
+void graph_builder::add_record_node_only(u64 ref_pos)
+{
+	if (ref_pos < m_prev_ref_pos) return;
+	flush_targets(ref_pos);                                           // :300
+	m_aln_pos += ref_pos - m_prev_ref_pos;                            // :303-304
+	add_or_update_node(ref_pos, m_aln_pos);                           // :305; :427 (prev_ref_pos = ref_pos) is not reached
+	m_edges_by_alt.clear();
+}
+
+
 void graph_builder::set_genotype(u32 copy_row, u32 alt_number)
 {
 	if (0 == alt_number || m_edges_by_alt.size() < alt_number) return;

@@ -51,6 +51,11 @@ public:
 	bool add_record(u64 ref_pos, u64 ref_allele_length, alt_allele const *alts, std::size_t n_alts);
 	u64 edge_for_alt(std::size_t alt_idx) const { return m_edges_by_alt[alt_idx]; }
 
+	// What the reference has done with a record when its delegate's ref_column_mismatch() returns false and parsing stops
+	// (variant_graph.cc:300-313): the pending targets up to ref_pos and the record's own node exist, none of its edges, and
+	// the previous record's position is still the "previous position" that finish() measures the sink's distance from.
+	void add_record_node_only(u64 ref_pos);
+
 	// Genotype of one chromosome copy for the record just added: alt_number is the 1-based GT value
 	// (0 and missing are not passed).  Sets the path bit, reporting an overlap first when the copy is
 	// still inside an earlier ALT (variant_graph.cc:399-424 -- the bit is set even then).

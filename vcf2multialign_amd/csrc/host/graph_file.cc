@@ -101,6 +101,17 @@ void read_graph(char const *path, variant_graph &g)
 	u64 const limit(u64(1) << 40);
 	for (u64 const v : c) if (v > limit) throw std::runtime_error("implausible counts in graph file");
 	if (c[6] % 64 || c[7] % 64 || c[8] % 64 || c[9] % 64) throw std::runtime_error("path matrix dimensions must be multiples of 64");
+	// the counts must agree with each other and with the size of the file before anything is allocated from them
+	if (c[3] && c[5] != c[3] + 1) throw std::runtime_error("graph file: ploidy_csum must have one entry more than there are samples");
+	{
+		long const at(std::ftell(f));
+		if (at < 0 || 0 != std::fseek(f, 0, SEEK_END)) throw std::runtime_error(std::string("unable to size ") + path);
+		long const end(std::ftell(f));
+		if (end < 0 || 0 != std::fseek(f, at, SEEK_SET)) throw std::runtime_error(std::string("unable to size ") + path);
+		auto const pad8([](u64 n) { return (n + 7) & ~u64(7); });   // every block is padded to whole 8-byte words
+		u64 const payload(8 * (2 * c[0] + c[1] + (c[0] + 1) + (c[1] + 1)) + c[6] / 64 * c[7] * 8 + c[8] / 64 * c[9] * 8 + pad8(4 * c[5]) + pad8(c[2]) + pad8(c[4]) + 8);
+		if (payload != u64(end - at)) throw std::runtime_error(std::string(path) + ": the counts in the header do not match the size of the file (truncated or corrupted graph file)");
+	}
 	g = variant_graph{};
 	g.reference_positions.resize(c[0]);
 	g.aligned_positions.resize(c[0]);
@@ -132,6 +143,15 @@ void read_graph(char const *path, variant_graph &g)
 	}
 	if (g.sample_names.size() != c[3]) throw std::runtime_error("sample name block does not match the sample count");
 	if (g.alt_edge_label_offsets.back() != c[2]) throw std::runtime_error("label offsets do not match the label block");
+	// what the readers of these arrays index with (variant_graph::label(), sample_ploidy(), the edge ranges of a node)
+	auto const monotone([](auto const &v) { for (std::size_t i(1); i < v.size(); ++i) if (v[i] < v[i - 1]) return false; return true; });
+	if (0 != g.alt_edge_label_offsets.front() || !monotone(g.alt_edge_label_offsets)) throw std::runtime_error("graph file: label offsets must start at 0 and not decrease");
+	if (!monotone(g.ploidy_csum) || (!g.ploidy_csum.empty() && 0 != g.ploidy_csum.front())) throw std::runtime_error("graph file: ploidy_csum must start at 0 and not decrease");
+	if (0 != g.alt_edge_count_csum.front() || !monotone(g.alt_edge_count_csum) || g.alt_edge_count_csum.back() != c[1]) throw std::runtime_error("graph file: alt_edge_count_csum must run from 0 to the edge count");
+	for (u64 const t : g.alt_edge_targets) if (t >= c[0]) throw std::runtime_error("graph file: edge target outside the node range");
+	// either path matrix may be absent (0 x 0); one that is there must cover every edge and every chromosome copy
+	if ((c[6] || c[7]) && (c[6] < c[1] || c[7] < g.total_chromosome_copies())) throw std::runtime_error("graph file: paths_by_chrom_copy_and_edge is smaller than the graph");
+	if ((c[8] || c[9]) && (c[9] < c[1] || c[8] < g.total_chromosome_copies())) throw std::runtime_error("graph file: paths_by_edge_and_chrom_copy is smaller than the graph");
 }
 
 } // namespace v2m::host

@@ -405,8 +405,12 @@ void build_variant_graph(
 			u64 const this_var(var_idx + rec.data_line_in_chunk);
 			{                                                                            // :307-314
 				std::string_view const expected(rec.ref_pos <= ref_sv.size() ? ref_sv.substr(rec.ref_pos, rec.ref.size()) : std::string_view{});
-				if (rec.ref != expected && !delegate.ref_column_mismatch(this_var, rec.ref_pos, rec.ref, expected))
+				if (rec.ref != expected && !delegate.ref_column_mismatch(this_var, rec.ref_pos, rec.ref, expected)) {
+					// the reference stops parsing here (variant_graph.cc:312-313) and still adds the sink node (:437-451)
+					builder.add_record_node_only(rec.ref_pos);
+					builder.finish(ref_seq.size());
 					return;
+				}
 			}
 			if (!builder.add_record(rec.ref_pos, rec.ref.size(), chunk.alts.data() + rec.alt_begin, rec.n_alts))
 				throw std::runtime_error("variant " + std::to_string(this_var) + " has non-increasing position");   // :293-297
