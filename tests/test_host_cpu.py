@@ -202,3 +202,14 @@ def test_traffic_is_quoted_only_for_the_sources_it_was_measured_on():
 	for name, r in rec.items():
 		if not name.startswith("_"):
 			assert set(r["kernel_sources"]) == set(bench.KERNEL_SOURCES), name
+
+
+def test_ring_transpose_indexing_model():
+	"""tools/ring_transpose_model.py: the ring transpose kernel's slot / flush / window indexing, replayed on the CPU, writes
+	every destination word exactly once with the right value on awkward shapes (the GPU suite then checks the real kernel)."""
+	import subprocess
+	import sys
+	ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ring_transpose_model.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+	assert r.returncode == 0, r.stderr.decode()[-2000:]
+	assert b"cases ok" in r.stdout
