@@ -518,6 +518,23 @@ def test_precondition_errors(v2m, ctx, tmp_path):
 	assert ctx.splice_rows([0]) == _oracle_rows(g, [0])
 
 
+# ---- --unaligned: chunks with padding ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("mode", ["", "lanebytes", "plain"])
+def test_unaligned_rows_with_much_padding(ctx, v2m, tmp_path, monkeypatch, mode):
+	"""Graphs dense with insertions: most 16-byte chunks of a tile hold padding, so nearly every chunk takes the byte path
+	(the wave-cooperative one by default, round 1's per-lane loop with V2M_UNALIGNED_STORE=lanebytes)."""
+	monkeypatch.setenv("V2M_UNALIGNED_STORE", mode)
+	g = synth.build_case(tmp_path, 94, 120000, 9000, 6, mix=(0.2, 0.7, 0.1), max_indel=40)   # an insertion every ~20 bases
+	vg = v2m.VariantGraph.from_object(g)
+	ctx.upload_graph(vg, g.ref)
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies))
+	got = ctx.splice_rows(rows, unaligned=True)
+	for r, body in zip(rows, got):
+		assert body == g.output_sequence(g.ref, copy_index=r, unaligned=True), r
+	assert g.aligned_length > len(g.ref)                                     # there is padding to remove
+
+
 # ---- v2m_upload_path_slice: one GPU's share of the path matrix (SURVEY.md section 8e) ---------------------------
 
 @pytest.mark.parametrize("world", [1, 2, 3, 5])

@@ -22,9 +22,12 @@ upitch = (ctx.max_unaligned_length + 255) // 256 * 256
 out = ctx.alloc_output(rows * upitch, 3)
 batch = v2m.RowBatch(list(range(rows)))
 ctx.synchronize(); ctx.profile_enable(True)
-for name, un in (("aligned", False), ("unaligned", True), ("aligned", False), ("unaligned", True)):
+for name, un, mode in (("aligned", False, ""), ("unaligned", True, ""), ("unaligned", True, "lanebytes"), ("aligned", False, ""), ("unaligned", True, ""), ("unaligned", True, "lanebytes"), ("unaligned", True, "plain")):
+	os.environ["V2M_UNALIGNED_STORE"] = mode
 	ctx.profile_reset()
 	lengths = ctx.splice_rows_device(batch, out, upitch, unaligned=un, want_lengths=True)
 	k = N.KERNEL_SPLICE_UNALIGNED if un else N.KERNEL_SPLICE_ALIGNED
 	n, ms = ctx.profile_get(k)
-	print("%-10s %d rows, %.2f Gbases out: %.3f ms (%d launches incl. count+scan+compact) -> %.0f Gbases/s" % (name, rows, lengths.sum() / 1e9, ms, n, lengths.sum() / ms / 1e6))
+	_, ms_count = ctx.profile_get(N.KERNEL_UNALIGNED_COUNT)
+	sums = ctx.checksum_rows_device(out, upitch, rows, lengths=lengths)
+	print("%-10s %-10s %d rows, %.2f Gbases out: splice %.3f ms + count/scan %.3f ms -> %.0f Gbases/s   (checksum of checksums %016x)" % (name, mode, rows, lengths.sum() / 1e9, ms, ms_count if un else 0.0, lengths.sum() / (ms + (ms_count if un else 0)) / 1e6, int(np.bitwise_xor.reduce(sums))))

@@ -1079,7 +1079,19 @@ __global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
 
 typedef vec4u vec4u_unaligned __attribute__((aligned(1)));   // 16-B access at any byte address (gfx950 / HSA unaligned access mode; tools/unaligned_store_test.hip)
 
-template <bool kNonTemporal>
+// A chunk that contains padding goes out byte by byte.  Few chunks do (1.6 % at config 3), but a wave takes the slow path
+// as soon as ONE of its 64 lanes holds such a chunk -- two thirds of all wave-instructions -- so the bytes are not stored by
+// the owning lane in a 16-iteration loop (kWaveBytes = false, round 1's form) but by the whole wave: the lanes that hold a
+// partial chunk park it in a wave-private LDS slot (chunk, destination offset, map of surviving bytes), then 16 lanes
+// take one parked chunk each pass, one byte per lane, four chunks per store instruction.
+struct parked_chunk {
+	vec4u bytes;
+	u32 offset;      // where the chunk's first surviving byte goes, relative to the tile's start in the row
+	u32 survivors;   // bit b set = byte b is not padding
+	u32 pad[2];
+};
+
+template <bool kNonTemporal, bool kWaveBytes>
 __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
 	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
@@ -1089,6 +1101,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	__shared__ vec4u lds[kTileChunks];
 	__shared__ patch_cache pc;
 	__shared__ u32 wave_sums[kChunksPerThread][kSpliceThreads / 64];
+	__shared__ parked_chunk parked[kWaveBytes ? kSpliceThreads / 64 : 1][kWaveBytes ? 64 : 1];
 
 	int const t = threadIdx.x;
 	int const lane = t & 63, wave = t >> 6;
@@ -1155,7 +1168,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 				// 256 rows of config 3; the misalignment is not what this kernel is bound by)
 				if (kNonTemporal) __builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));
 				else *(vec4u_unaligned *) (dst + off) = v[k];
-			} else if (cnt[k]) {
+			} else if (!kWaveBytes && cnt[k]) {
 				u32 p = off;
 #pragma unroll
 				for (int d = 0; d < 4; ++d)
@@ -1164,6 +1177,35 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 						unsigned char const ch = (unsigned char) (v[k][d] >> (8 * bb));
 						if (ch) dst[p++] = (char) ch;
 					}
+			}
+			if (kWaveBytes) {
+				bool const partial = cnt[k] != 16 && cnt[k] != 0;
+				u64 const holders = __ballot(partial);
+				if (holders) {                                        // wave-uniform
+					if (partial) {
+						u32 survivors = 0;
+#pragma unroll
+						for (int d = 0; d < 4; ++d) {
+							u32 const nz = ~zero_bytes_mask(v[k][d]) & 0x80808080u;
+							survivors |= (((nz >> 7) & 1) | ((nz >> 14) & 2) | ((nz >> 21) & 4) | ((nz >> 28) & 8)) << (4 * d);
+						}
+						u32 const slot = __builtin_amdgcn_mbcnt_hi((u32) (holders >> 32), __builtin_amdgcn_mbcnt_lo((u32) holders, 0));
+						parked[wave][slot].bytes = v[k];
+						parked[wave][slot].offset = off;
+						parked[wave][slot].survivors = survivors;
+					}
+					__builtin_amdgcn_wave_barrier();                  // LDS operations of one wave execute in order
+					u32 const n_parked = (u32) __builtin_popcountll(holders);
+					for (u32 e0 = 0; e0 < n_parked; e0 += 4) {
+						u32 const e = e0 + (lane >> 4), b = lane & 15;
+						if (e < n_parked) {
+							u32 const survivors = parked[wave][e].survivors;
+							if ((survivors >> b) & 1)
+								dst[parked[wave][e].offset + __builtin_popcount(survivors & ((1u << b) - 1))] = ((char const *) &parked[wave][e].bytes)[b];
+						}
+					}
+					__builtin_amdgcn_wave_barrier();
+				}
 			}
 		}
 		// wave_sums is rewritten only after the next row's barriers
