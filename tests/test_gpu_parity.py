@@ -520,10 +520,10 @@ def test_precondition_errors(v2m, ctx, tmp_path):
 
 # ---- --unaligned: chunks with padding ------------------------------------------------------------------------------
 
-@pytest.mark.parametrize("mode", ["", "lanebytes", "plain"])
+@pytest.mark.parametrize("mode", ["", "plain"])
 def test_unaligned_rows_with_much_padding(ctx, v2m, tmp_path, monkeypatch, mode):
 	"""Graphs dense with insertions: most 16-byte chunks of a tile hold padding, so nearly every chunk takes the byte path
-	(the wave-cooperative one by default, round 1's per-lane loop with V2M_UNALIGNED_STORE=lanebytes)."""
+	instead of the single 16-byte store."""
 	monkeypatch.setenv("V2M_UNALIGNED_STORE", mode)
 	g = synth.build_case(tmp_path, 94, 120000, 9000, 6, mix=(0.2, 0.7, 0.1), max_indel=40)   # an insertion every ~20 bases
 	vg = v2m.VariantGraph.from_object(g)

@@ -204,6 +204,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 // bytes of it) and writes them out through a wave-private LDS slab, so that 16 consecutive lanes store one
 // destination column's 128 bytes.  Both HBM sides move whole 128-B runs.
 constexpr int kTsR = 16, kTsC = 16;
+constexpr int kTsDepth = 4;                          // source sub-panels in flight per workgroup (registers)
 
 __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
@@ -222,38 +223,42 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 	u64 const n_cols = DW * 64;
 
 	// one sub-panel = 64 columns x 16 row-words; 16 consecutive lanes fetch one column's 128 contiguous bytes.
-	// Two sub-panels are kept in flight in registers (the kernel is bound by bytes in flight, not by the shuffles).
+	// kTsDepth sub-panels are kept in flight in registers (the kernel is bound by bytes in flight, not by the shuffles).
+	// Every load is issued unconditionally from an address clamped into the matrix and zeroed at the stash where it lies
+	// outside: loads under branches made the compiler drain the whole load queue at every barrier (see the ring kernel).
 	constexpr int kPer = (64 * kTsR) / kTrThreads;
-	u64 stage[2][kPer];
+	u64 stage[kTsDepth][kPer];
+	u64 const last_col = n_cols - 1;
 	auto fetch = [&](int cg, u64 (&st)[kPer]) {
 #pragma unroll
 		for (int k = 0; k < kPer; ++k) {
 			int const idx = t + kTrThreads * k;
 			int const col = idx / kTsR, w = idx % kTsR;
 			u64 const gcol = (cg0 + cg) * 64 + col;
-			st[k] = (gcol < n_cols && rw0 + w < SW) ? src[gcol * SW + rw0 + w] : 0;
+			st[k] = src[(gcol < n_cols ? gcol : last_col) * SW + (rw0 + w < SW ? rw0 + w : SW - 1)];
 		}
 	};
-	auto stash = [&](int buf, u64 const (&st)[kPer]) {
+	auto stash = [&](int buf, int cg, u64 const (&st)[kPer]) {
 #pragma unroll
 		for (int k = 0; k < kPer; ++k) {
 			int const idx = t + kTrThreads * k;
-			in[buf][idx / kTsR][idx % kTsR] = st[k];
+			int const col = idx / kTsR, w = idx % kTsR;
+			in[buf][col][w] = ((cg0 + cg) * 64 + col < n_cols && rw0 + w < SW) ? st[k] : 0;
 		}
 	};
 
 	u64 y[kA][kTsC];
-	fetch(0, stage[0]);
-	fetch(1, stage[1]);
-	stash(0, stage[0]);
+#pragma unroll
+	for (int cg = 0; cg < kTsDepth; ++cg) fetch(cg, stage[cg]);
+	stash(0, 0, stage[0]);
 #pragma unroll
 	for (int cg = 0; cg < kTsC; ++cg) {
 		__syncthreads();                                 // in[cg & 1] is complete; everyone is done with in[(cg + 1) & 1]
-		if (cg + 2 < kTsC) fetch(cg + 2, stage[cg & 1]); // stage[cg & 1] was stashed for this group already
+		if (cg + kTsDepth < kTsC) fetch(cg + kTsDepth, stage[cg % kTsDepth]);   // stage[cg % kTsDepth] was stashed for this group already
 #pragma unroll
 		for (int a = 0; a < kA; ++a)
-			y[a][cg] = wave_transpose_64x64(in[cg & 1][lane][kA * wave + a], lane);
-		if (cg + 1 < kTsC) stash((cg + 1) & 1, stage[(cg + 1) & 1]);
+			y[a][cg] = wave_transpose_64x64_fast(in[cg & 1][lane][kA * wave + a], lane);
+		if (cg + 1 < kTsC) stash((cg + 1) & 1, cg + 1, stage[(cg + 1) % kTsDepth]);
 	}
 
 	// write-out, one row-word at a time through the wave's own slab (LDS operations of one wave execute in order)
@@ -1011,6 +1016,19 @@ __device__ __forceinline__ u32 zero_bytes_mask(u32 x)
 	return ~(((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x | 0x7F7F7F7Fu);
 }
 
+// Inclusive prefix sum across the wave in six DPP adds (four shifts inside each row of 16 lanes, then lane 15 of rows 0 / 2
+// added into rows 1 / 3 and lane 31 into rows 2 and 3): no LDS round trips, unlike the __shfl_up form (ds_bpermute).
+__device__ __forceinline__ u32 wave_inclusive_scan_u32(u32 v)
+{
+	v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x111, 0xf, 0xf, false);   // row_shr:1, zeros shifted in
+	v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x112, 0xf, 0xf, false);   // row_shr:2
+	v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x114, 0xf, 0xf, false);   // row_shr:4
+	v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x118, 0xf, 0xf, false);   // row_shr:8
+	v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x142, 0xa, 0xf, false);   // row_bcast:15 into rows 1 and 3
+	v += (u32) __builtin_amdgcn_update_dpp(0, (int) v, 0x143, 0xc, 0xf, false);   // row_bcast:31 into rows 2 and 3
+	return v;
+}
+
 // Non-zero bytes of tile[lo, hi).
 __device__ __forceinline__ u32 count_nonzero_bytes(unsigned char const *tile, u32 lo, u32 hi)
 {
@@ -1079,19 +1097,7 @@ __global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
 
 typedef vec4u vec4u_unaligned __attribute__((aligned(1)));   // 16-B access at any byte address (gfx950 / HSA unaligned access mode; tools/unaligned_store_test.hip)
 
-// A chunk that contains padding goes out byte by byte.  Few chunks do (1.6 % at config 3), but a wave takes the slow path
-// as soon as ONE of its 64 lanes holds such a chunk -- two thirds of all wave-instructions -- so the bytes are not stored by
-// the owning lane in a 16-iteration loop (kWaveBytes = false, round 1's form) but by the whole wave: the lanes that hold a
-// partial chunk park it in a wave-private LDS slot (chunk, destination offset, map of surviving bytes), then 16 lanes
-// take one parked chunk each pass, one byte per lane, four chunks per store instruction.
-struct parked_chunk {
-	vec4u bytes;
-	u32 offset;      // where the chunk's first surviving byte goes, relative to the tile's start in the row
-	u32 survivors;   // bit b set = byte b is not padding
-	u32 pad[2];
-};
-
-template <bool kNonTemporal, bool kWaveBytes>
+template <bool kNonTemporal>
 __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
 	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
@@ -1101,7 +1107,6 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	__shared__ vec4u lds[kTileChunks];
 	__shared__ patch_cache pc;
 	__shared__ u32 wave_sums[kChunksPerThread][kSpliceThreads / 64];
-	__shared__ parked_chunk parked[kWaveBytes ? kSpliceThreads / 64 : 1][kWaveBytes ? 64 : 1];
 
 	int const t = threadIdx.x;
 	int const lane = t & 63, wave = t >> 6;
@@ -1138,12 +1143,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 #pragma unroll
 			for (int d = 0; d < 4; ++d) zeros += __builtin_popcount(zero_bytes_mask(v[k][d]));
 			cnt[k] = 16 - zeros;
-			u32 s = cnt[k];
-#pragma unroll
-			for (int d = 1; d < 64; d <<= 1) {
-				u32 const o = __shfl_up(s, d, kWave);
-				if (lane >= d) s += o;
-			}
+			u32 const s = wave_inclusive_scan_u32(cnt[k]);
 			incl[k] = s;
 			if (lane == 63) wave_sums[k][wave] = s;
 		}
@@ -1168,7 +1168,9 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 				// 256 rows of config 3; the misalignment is not what this kernel is bound by)
 				if (kNonTemporal) __builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));
 				else *(vec4u_unaligned *) (dst + off) = v[k];
-			} else if (!kWaveBytes && cnt[k]) {
+			} else if (cnt[k]) {
+				// (few chunks hold padding -- 1.6 % at config 3 -- and parking them in LDS for the whole wave to store, one byte
+				// per lane, was 10 % slower than this predicated per-lane loop: profiles/r02/unaligned_byte_path_ab.txt)
 				u32 p = off;
 #pragma unroll
 				for (int d = 0; d < 4; ++d)
@@ -1177,35 +1179,6 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 						unsigned char const ch = (unsigned char) (v[k][d] >> (8 * bb));
 						if (ch) dst[p++] = (char) ch;
 					}
-			}
-			if (kWaveBytes) {
-				bool const partial = cnt[k] != 16 && cnt[k] != 0;
-				u64 const holders = __ballot(partial);
-				if (holders) {                                        // wave-uniform
-					if (partial) {
-						u32 survivors = 0;
-#pragma unroll
-						for (int d = 0; d < 4; ++d) {
-							u32 const nz = ~zero_bytes_mask(v[k][d]) & 0x80808080u;
-							survivors |= (((nz >> 7) & 1) | ((nz >> 14) & 2) | ((nz >> 21) & 4) | ((nz >> 28) & 8)) << (4 * d);
-						}
-						u32 const slot = __builtin_amdgcn_mbcnt_hi((u32) (holders >> 32), __builtin_amdgcn_mbcnt_lo((u32) holders, 0));
-						parked[wave][slot].bytes = v[k];
-						parked[wave][slot].offset = off;
-						parked[wave][slot].survivors = survivors;
-					}
-					__builtin_amdgcn_wave_barrier();                  // LDS operations of one wave execute in order
-					u32 const n_parked = (u32) __builtin_popcountll(holders);
-					for (u32 e0 = 0; e0 < n_parked; e0 += 4) {
-						u32 const e = e0 + (lane >> 4), b = lane & 15;
-						if (e < n_parked) {
-							u32 const survivors = parked[wave][e].survivors;
-							if ((survivors >> b) & 1)
-								dst[parked[wave][e].offset + __builtin_popcount(survivors & ((1u << b) - 1))] = ((char const *) &parked[wave][e].bytes)[b];
-						}
-					}
-					__builtin_amdgcn_wave_barrier();
-				}
 			}
 		}
 		// wave_sums is rewritten only after the next row's barriers
@@ -1224,12 +1197,7 @@ __global__ __launch_bounds__(256) void scan_tile_counts_kernel(u32 *__restrict__
 	for (u32 base = 0; base < n_tiles; base += 256) {
 		u32 const i = base + t;
 		u32 const mine = i < n_tiles ? row[i] : 0;
-		u32 incl = mine;
-#pragma unroll
-		for (int d = 1; d < 64; d <<= 1) {
-			u32 const o = __shfl_up(incl, d, kWave);
-			if (lane >= d) incl += o;
-		}
+		u32 const incl = wave_inclusive_scan_u32(mine);
 		if (lane == 63) wave_sums[wave] = incl;
 		__syncthreads();
 		u32 before = carry_s, total = 0;

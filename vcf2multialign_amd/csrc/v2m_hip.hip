@@ -647,16 +647,15 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 	}
 	{
 		timed_launch tl(ctx, V2M_KERNEL_SPLICE_UNALIGNED);
-		char const *const mode_env(std::getenv("V2M_UNALIGNED_STORE"));   // tuning knob: plain | nt (default) | lanebytes (round 1's per-lane byte loop for chunks with padding)
-		bool const plain(mode_env && 0 == std::strcmp(mode_env, "plain")), lane_bytes(mode_env && 0 == std::strcmp(mode_env, "lanebytes"));
+		char const *const mode_env(std::getenv("V2M_UNALIGNED_STORE"));   // tuning knob: plain | nt (default)
+		bool const plain(mode_env && 0 == std::strcmp(mode_env, "plain"));
 		auto const launch([&](auto kernel) {
 			hipLaunchKernelGGL(kernel, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 				ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
 				ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
 		});
-		if (plain) launch(v2m::splice_unaligned_kernel<false, true>);
-		else if (lane_bytes) launch(v2m::splice_unaligned_kernel<true, false>);
-		else launch(v2m::splice_unaligned_kernel<true, true>);
+		if (plain) launch(v2m::splice_unaligned_kernel<false>);
+		else launch(v2m::splice_unaligned_kernel<true>);
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
