@@ -15,8 +15,9 @@ reference and graph replicated; there is no collective on the data path (SURVEY.
 named config's and is fixed as N grows, hence "scaling": "strong".
 
 Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).  Besides the contract's fields it carries
-`roofline` (the dominant kernel, splice_aligned_kernel), `roofline_transpose` (the transpose at the reference's own
-64-bit padding, forward inside the timed region; inverse and a 1024-bit-padded matrix measured after it), `unaligned`
+`roofline` (the dominant kernel, splice_aligned_kernel), `roofline_transpose` (the transpose of a source at the reference's
+own 64-bit padding into the library's path matrix, inside the timed region; the ABI's dense form, forward and inverse, and a
+1024-bit-padded matrix measured after it), `unaligned`
 (a second, separately timed leg: the same rows without '-' padding), `parity` and `cpu_baseline`.
 """
 
@@ -173,8 +174,9 @@ def main():
 
 	def step():
 		if hp_local:
-			ctx.transpose_bits_device(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())
-			ctx.set_paths_device(paths_dst.data_ptr(), Ep, hp_local)
+			# transpose_matrix at its one call site (variant_graph.cc:453): the transpose input, in the reference's layout, into the
+			# library's own copy of paths_by_chrom_copy_and_edge (which only the GPU reads; its columns are line-aligned)
+			ctx.bind_path_matrix_device(paths_src.data_ptr(), hp_local, Ep)
 		for b in batches:
 			ctx.splice_rows_device(b, out_ptr, pitch)
 
@@ -265,7 +267,7 @@ def main():
 	if transpose_launches:
 		t_ms = transpose_ms / transpose_launches
 		result["roofline_transpose"] = {
-			"bound": "hbm", "kernel": "transpose_bits (v2m_transpose_bits_device; the kernel is chosen per matrix shape by measurement, see config.tuning)",
+			"bound": "hbm", "kernel": "transpose_bits (v2m_bind_path_matrix_device: source in the reference's layout and padding, destination the library's own line-aligned copy; the kernel is chosen per matrix shape by measurement, see config.tuning)",
 			"matrix_bits": [hp_local, Ep], "algorithmic_bytes": tr_bytes, "launches": transpose_launches,
 			"avg_launch_ms": round(t_ms, 4), "achieved": round(tr_bytes / t_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
 			"frac": round(tr_bytes / t_ms / 1e6 / HBM_PEAK_GBS, 4),
@@ -283,6 +285,8 @@ def main():
 		return ms / max(1, n)
 
 	if rank == 0 and args.transpose_extras and hp_local:
+		# the ABI's dense form (v2m_transpose_bits_device: caller-visible destination, so both sides at the reference's padding)
+		fwd_ms = time_transpose(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())
 		back = torch.empty_like(paths_src)
 		inv_ms = time_transpose(paths_dst.data_ptr(), Ep, hp_local, back.data_ptr())
 		involution = bool(torch.equal(back, paths_src))
@@ -295,12 +299,14 @@ def main():
 		del p_src, p_dst
 		gbs = lambda nbytes, ms: round(nbytes / ms / 1e6, 1)
 		result.setdefault("roofline_transpose", {})["after_timing"] = {
+			"dense_forward_ms": round(fwd_ms, 4), "dense_forward_GBs": gbs(tr_bytes, fwd_ms), "dense_forward_frac": round(tr_bytes / fwd_ms / 1e6 / HBM_PEAK_GBS, 4),
 			"inverse_ms": round(inv_ms, 4), "inverse_GBs": gbs(tr_bytes, inv_ms), "inverse_frac": round(tr_bytes / inv_ms / 1e6 / HBM_PEAK_GBS, 4), "involution_bit_exact": involution,
+			"note": "dense_forward / inverse: v2m_transpose_bits_device with a caller-visible destination (both sides at the reference's 64-bit padding); padded_1024: the same with both dimensions padded to 1024 bits",
 			"padded_1024": {"matrix_bits": [hp_p, ep_p], "forward_ms": round(fwd_p, 4), "forward_GBs": gbs(2 * hp_p * ep_p // 8, fwd_p), "inverse_ms": round(inv_p, 4), "inverse_GBs": gbs(2 * hp_p * ep_p // 8, inv_p)},
 		}
 		if not involution:
 			log("[bench] PARITY FAILURE: transpose(transpose(m)) != m")
-		ctx.set_paths_device(paths_dst.data_ptr(), Ep, hp_local)
+		ctx.bind_path_matrix_device(paths_src.data_ptr(), hp_local, Ep)
 
 	# Context for the roofline number: what a plain device memset of the very same output buffer reaches in this
 	# process (the achievable write rate varies by +-10 % between processes / boxes).

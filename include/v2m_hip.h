@@ -150,6 +150,14 @@ int v2m_set_paths_device(v2m_ctx *ctx, const void *d_words, uint64_t path_rows, 
  * back to the host.  The result is owned by the ctx.  Synchronous. */
 int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *paths_by_edge_and_chrom_copy, uint64_t n_rows, uint64_t n_cols, uint64_t first_copy, uint64_t n_copies);
 
+/* The same for a transpose input that already lives in HBM (n_rows copies x n_cols edges, dense column-major words as
+ * above, e.g. generated or assembled on the device): transposes it into a ctx-owned copy of paths_by_chrom_copy_and_edge and
+ * binds that -- the one-call form of v2m_transpose_bits_device() + v2m_set_paths_device().  The owned copy is laid out for
+ * the GPU (every chromosome copy's column starts on a 128-byte line), which a caller-visible destination cannot be, so
+ * this is the faster of the two ways.  Asynchronous on the ctx's stream; the source may be reused once the call's work
+ * has finished (v2m_ctx_synchronize()). */
+int v2m_bind_path_matrix_device(v2m_ctx *ctx, const void *d_paths_by_edge_and_chrom_copy, uint64_t n_rows, uint64_t n_cols);
+
 uint64_t v2m_aligned_length(const v2m_ctx *ctx);
 /* The row pitch the library itself uses in aligned mode (aligned length rounded up to 256: rows then start on
  * 256-B boundaries).  v2m_splice_rows_device accepts any multiple of 16 that is >= the aligned length rounded up to 16. */

@@ -39,7 +39,7 @@ def test_bench_line_has_the_contract_fields():
 	tr = d["roofline_transpose"]                    # the transpose at the reference's own 64-bit padding
 	assert tr["matrix_bits"][0] % 64 == 0 and tr["matrix_bits"][1] % 64 == 0 and tr["matrix_bits"][0] < 1024   # mini3: 200 copies -> 256, not 1024
 	assert tr["algorithmic_bytes"] == 2 * tr["matrix_bits"][0] * tr["matrix_bits"][1] // 8 and tr["achieved"] > 0
-	assert tr["after_timing"]["involution_bit_exact"] is True
+	assert tr["after_timing"]["involution_bit_exact"] is True and tr["after_timing"]["dense_forward_ms"] > 0
 	un = d["unaligned"]                             # the separately timed --unaligned leg
 	assert un["value"] > 0 and un["parity"]["bit_exact"] is True and un["roofline"]["kernel"] == "splice_unaligned_kernel"
 	assert set(un["kernels_ms"]) == {"resolve_effective_edges_kernel", "count_unaligned_kernel+scan_tile_counts_kernel", "splice_unaligned_kernel"}

@@ -564,6 +564,34 @@ def test_path_slices_reproduce_every_row(ctx, v2m, tmp_path, world):
 	assert [got[r] for r in range(n_copies + 1)] == expected
 
 
+@pytest.mark.parametrize("kernel", ["", "8x8", "stream16", "ring:8,8,8,8,64", "ring:8,8,8,8,128/sf", "ring:16,8,8,4,16"])
+def test_bind_path_matrix_device(ctx, v2m, tmp_path, monkeypatch, kernel):
+	"""v2m_bind_path_matrix_device: a device-resident transpose input becomes the context's own (line-aligned) path matrix;
+	every transpose kernel with a destination pitch that differs from the word count."""
+	import torch
+	if kernel:
+		monkeypatch.setenv("V2M_TRANSPOSE_PANEL", kernel)
+	g = synth.build_case(tmp_path, 95, 40000, 1300, 37, long_every=250)           # 74 copies -> 128 rows; 1300+ edges: 21 words, pitch 32
+	hp, ep = g.paths_by_edge_and_chrom_copy_dims
+	assert (ep // 64) % 16 != 0
+	vg = v2m.VariantGraph.from_object(g)
+	vg.paths_by_chrom_copy_and_edge = None
+	ctx.upload_graph(vg, g.ref)
+	d_src = torch.from_numpy(g.paths_by_edge_and_chrom_copy.view(np.int64)).cuda()
+	torch.cuda.synchronize()
+	ctx.bind_path_matrix_device(d_src.data_ptr(), hp, ep)
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies)) + [hp - 1]
+	got = ctx.splice_rows(rows)
+	assert got[:-1] == [g.output_sequence(g.ref, copy_index=r) for r in rows[:-1]]
+	assert got[-1] == got[0]                                                      # a padding copy: REF
+	got = ctx.splice_rows(rows[:9], unaligned=True)
+	assert got == [g.output_sequence(g.ref, copy_index=r, unaligned=True) for r in rows[:9]]
+	with pytest.raises(v2m.V2MError):
+		ctx.bind_path_matrix_device(d_src.data_ptr(), hp, 64)                     # fewer edge columns than the graph has edges
+	with pytest.raises(v2m.V2MError):
+		ctx.bind_path_matrix_device(d_src.data_ptr(), hp - 1, ep)
+
+
 def test_path_slice_edges(ctx, v2m, tmp_path):
 	g = synth.build_case(tmp_path, 92, 20000, 300, 40)
 	hp, ep = g.paths_by_edge_and_chrom_copy_dims

@@ -59,6 +59,7 @@ SIGNATURES = {
 	"v2m_upload_graph": (C.c_int, [C.c_void_p, C.POINTER(GraphView), C.c_void_p, C.c_uint64]),
 	"v2m_set_paths_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
 	"v2m_upload_path_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+	"v2m_bind_path_matrix_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
 	"v2m_aligned_length": (C.c_uint64, [C.c_void_p]),
 	"v2m_min_row_pitch": (C.c_uint64, [C.c_void_p]),
 	"v2m_max_unaligned_length": (C.c_uint64, [C.c_void_p]),

@@ -121,6 +121,11 @@ class Context:
 	def set_paths_device(self, d_words, path_rows, path_cols):
 		self._check(self._lib.v2m_set_paths_device(self._h, d_words, path_rows, path_cols))
 
+	def bind_path_matrix_device(self, d_paths_by_edge_and_chrom_copy, n_rows, n_cols):
+		"""v2m_bind_path_matrix_device: transposes a device-resident transpose input (n_rows copies x n_cols edges) into the
+		context's own, line-aligned path matrix and binds it.  Asynchronous."""
+		self._check(self._lib.v2m_bind_path_matrix_device(self._h, d_paths_by_edge_and_chrom_copy, n_rows, n_cols))
+
 	def upload_path_slice(self, paths_by_edge_and_chrom_copy, n_rows, n_cols, first_copy=0, n_copies=None):
 		"""v2m_upload_path_slice: this GPU's chromosome copies [first_copy, first_copy + n_copies) out of the whole host-resident
 		transpose input (n_rows copies x n_cols edges), transposed on the GPU and bound as the uploaded graph's path matrix."""

@@ -138,7 +138,8 @@ __device__ __forceinline__ bool xcd_chunked_item(u32 block, u64 n_items, u32 ite
 // 8*kR contiguous bytes, every destination column receives 8*kC contiguous bytes.
 template <int kR, int kC>
 __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
-	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,
+	u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
 {
 	static_assert(kR % 4 == 0, "each of the 4 waves owns kR / 4 row-words");
 	// phase 1 view: [source column within panel = 64*kC][kR + 1]; phase 2 view: [destination column = 64*kR][kC + 1].
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 		u64 const gcol = cg0 * 64 + col;
 		u64 v = 0;
 		if (gcol < n_cols && rw0 + w < SW)
-			v = src[gcol * SW + rw0 + w];
+			v = src[gcol * src_pitch + rw0 + w];
 		panel[col * (kR + 1) + w] = v;
 	}
 	__syncthreads();
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 		int const dcol = idx / kC, cw = idx % kC;
 		u64 const grow = rw0 * 64 + dcol;          // destination column = source row
 		if (grow < SW * 64 && cg0 + cw < DW)
-			dst[grow * DW + cg0 + cw] = panel[dcol * (kC + 1) + cw];
+			dst[grow * dst_pitch + cg0 + cw] = panel[dcol * (kC + 1) + cw];
 	}
 }
 
@@ -207,7 +208,8 @@ constexpr int kTsR = 16, kTsC = 16;
 constexpr int kTsDepth = 4;                          // source sub-panels in flight per workgroup (registers)
 
 __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
-	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,
+	u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
 {
 	constexpr int kA = kTsR / 4;                         // row-words per wave
 	__shared__ u64 in[2][64][kTsR + 1];
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 			int const idx = t + kTrThreads * k;
 			int const col = idx / kTsR, w = idx % kTsR;
 			u64 const gcol = (cg0 + cg) * 64 + col;
-			st[k] = src[(gcol < n_cols ? gcol : last_col) * SW + (rw0 + w < SW ? rw0 + w : SW - 1)];
+			st[k] = src[(gcol < n_cols ? gcol : last_col) * src_pitch + (rw0 + w < SW ? rw0 + w : SW - 1)];
 		}
 	};
 	auto stash = [&](int buf, int cg, u64 const (&st)[kPer]) {
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 				int const idx = lane + 64 * k;
 				int const dcol = idx / kTsC, cw = idx % kTsC;
 				if (cg0 + cw < DW)
-					dst[(rw * 64 + dcol) * DW + cg0 + cw] = slab[wave][dcol][cw];
+					dst[(rw * 64 + dcol) * dst_pitch + cg0 + cw] = slab[wave][dcol][cw];
 			}
 		}
 	}
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 // ---------------------------------------------------------------------------------------------
 template <int kR, int kW, int kS, int kD, bool kFastLanes, bool kNonTemporal>
 __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
-	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW,
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,
 	u32 n_panels, u32 n_spans, u32 span_groups /* multiple of kS */, u32 items_per_xcd, u32 panel_fastest)
 {
 	static_assert(kR % kW == 0 && (kS & (kS - 1)) == 0 && kS >= 2 && kS <= 16 && kD % 2 == 0, "geometry");
@@ -342,12 +344,12 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 	for (int k = 0; k < kA; ++k) {
 		int const idx = t + kT * k;
 		src_ok[k] = rw0 + idx % kR < SW;
-		src_off[k] = (u64) (idx / kR) * SW + (src_ok[k] ? rw0 + idx % kR : SW - 1);
+		src_off[k] = (u64) (idx / kR) * src_pitch + (src_ok[k] ? rw0 + idx % kR : SW - 1);
 	}
 	u32 const cg_last = (u32) span_end - 1;
 	u64 pf[kD][kA];
 	auto const fetch = [&](u64 (&r)[kA], u32 cg) {
-		u64 const *const base = src + (u64) (cg < cg_last ? cg : cg_last) * 64 * SW;
+		u64 const *const base = src + (u64) (cg < cg_last ? cg : cg_last) * 64 * src_pitch;
 #pragma unroll
 		for (int k = 0; k < kA; ++k) r[k] = kNonTemporal ? __builtin_nontemporal_load(base + src_off[k]) : base[src_off[k]];
 	};
@@ -361,9 +363,9 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 
 	// destination rows of this wave's tiles: tile a = row-word rw0 + kA * wave + a, lane = row within it
 	u64 tile_base[kA];                        // flat destination word index of the tile's row 0, column group 0
-	u64 const lane_off = (u64) lane * DW;
+	u64 const lane_off = (u64) lane * dst_pitch;
 #pragma unroll
-	for (int a = 0; a < kA; ++a) tile_base[a] = (rw0 + kA * wave + a) * 64 * DW;
+	for (int a = 0; a < kA; ++a) tile_base[a] = (rw0 + kA * wave + a) * 64 * dst_pitch;
 
 	auto const compute = [&](u32 cg, int buf) {
 		u64 tv[kA];
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 				u32 const idx = f * kSectorsPerStore + (lane >> kLgS);
 				if (idx >= n) continue;
 				u32 const row = j0 + (idx << lg_stride);
-				u64 const row_base = tile_base[a] + (u64) row * DW;                     // flat index of the row's word 0
+				u64 const row_base = tile_base[a] + (u64) row * dst_pitch;              // flat index of the row's word 0
 				u64 const g = row_base + cg;
 				u32 const slot = (u32) g & (kS - 1);
 				u64 const g0 = g - slot;                                                // the sector's first word

@@ -95,8 +95,9 @@ struct v2m_ctx {
 	dev_buf owned_paths;
 	dev_buf d_slice_src;     // v2m_upload_path_slice: the un-transposed slice (released after the transpose)
 	u64 path_rows{}, path_cols{};
+	u64 path_pitch{};        // words from one copy's column to the next (path_rows / 64 for caller-supplied matrices)
 
-	struct transpose_pick { u64 rows, cols; std::string kernel; };
+	struct transpose_pick { u64 rows, cols, src_pitch, dst_pitch; std::string kernel; };
 	std::vector<transpose_pick> transpose_choice;   // per matrix shape: which transpose kernel measured fastest
 
 	// store flavour of the aligned splice: -1 = not calibrated yet, 0 = plain, 1 = nontemporal
@@ -217,7 +218,7 @@ u32 rows_fastest_for(int order, u64 n_row_panels, u64 n_col_panels)
 }
 
 template <int kR, int kC>
-int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, bool xcd, int order)
+int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, bool xcd, int order)
 {
 	u64 const P((SW + kR - 1) / kR), Q((DW + kC - 1) / kC);
 	xcd_grid g;
@@ -225,20 +226,20 @@ int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *
 		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch (%llu x %llu bits)", (unsigned long long) (SW * 64), (unsigned long long) (DW * 64));
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL((v2m::transpose_bits_kernel<kR, kC>), dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
+		hipLaunchKernelGGL((v2m::transpose_bits_kernel<kR, kC>), dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, SP, DP, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
 }
 
-int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, bool xcd, int order)
+int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, bool xcd, int order)
 {
 	u64 const P((SW + v2m::kTsR - 1) / v2m::kTsR), Q((DW + v2m::kTsC - 1) / v2m::kTsC);
 	xcd_grid g;
 	if (P > 0xFFFFFFFFull || Q > 0xFFFFFFFFull || !make_xcd_grid(P * Q, xcd, g)) return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL(v2m::transpose_bits_stream_kernel, dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
+		hipLaunchKernelGGL(v2m::transpose_bits_stream_kernel, dim3(g.blocks), dim3(v2m::kTrThreads), 0, ctx->stream, d_src, d_dst, SW, DW, SP, DP, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
@@ -247,7 +248,7 @@ int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 
 // The sector-aligned streaming kernel: kR row-words per workgroup on kW waves, kS-word sectors, kD steps of prefetch,
 // spans of `span_groups` column groups (0 = default).
 template <int kR, int kW, int kS, int kD, bool kFast, bool kNT>
-int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst, u64 span_groups, bool xcd, int order)
+int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, u64 span_groups, bool xcd, int order)
 {
 	if (0 == span_groups) span_groups = 64;
 	span_groups = (span_groups + kS - 1) / kS * kS;
@@ -258,7 +259,7 @@ int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
 		hipLaunchKernelGGL((v2m::transpose_bits_ring_kernel<kR, kW, kS, kD, kFast, kNT>), dim3(g.blocks), dim3(64 * kW), 0, ctx->stream,
-			d_src, d_dst, SW, DW, u32(P), u32(NS), u32(span_groups), g.items_per_xcd, rows_fastest_for(order, P, NS));
+			d_src, d_dst, SW, DW, SP, DP, u32(P), u32(NS), u32(span_groups), g.items_per_xcd, rows_fastest_for(order, P, NS));
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
@@ -267,7 +268,7 @@ int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 *d
 // Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "ring:R,W,S,D[,K[,slow|nt]]" (slow = ds_bpermute
 // butterfly, nt = nontemporal loads and stores); trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks, "/pf" / "/sf" make the row
 // panels / the column panels (spans) run fastest in item order instead of the shorter dimension.
-int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u64 SW, u64 DW, u64 *d_dst)
+int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst)
 {
 	bool xcd(true);
 	int order(0);
@@ -288,22 +289,22 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		bool const fast(0 != std::strcmp(tail, "slow")), nt(0 == std::strcmp(tail, "nt"));
 #define V2M_RING(r, w, s, d)                                                                                         \
 		if (R == r && W == w && S == s && D == d)                                                                    \
-			return !fast ? launch_transpose_ring<r, w, s, d, false, false>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order) \
-				: nt ? launch_transpose_ring<r, w, s, d, true, true>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order)      \
-				     : launch_transpose_ring<r, w, s, d, true, false>(ctx, d_src, SW, DW, d_dst, u64(K), xcd, order);
+			return !fast ? launch_transpose_ring<r, w, s, d, false, false>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order) \
+				: nt ? launch_transpose_ring<r, w, s, d, true, true>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order)      \
+				     : launch_transpose_ring<r, w, s, d, true, false>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
 		V2M_RING(16, 8, 8, 4) V2M_RING(16, 16, 8, 8) V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4)
 		V2M_RING(8, 4, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 8, 4) V2M_RING(8, 8, 8, 8) V2M_RING(8, 8, 8, 16)
 #undef V2M_RING
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not instantiated", shape.c_str());
 	}
-	if (shape == "stream16") return launch_transpose_stream(ctx, d_src, SW, DW, d_dst, xcd, order);
-	if (shape == "4x16") return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, d_dst, xcd, order);
-	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, d_dst, xcd, order);
-	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, d_dst, xcd, order);
-	if (shape == "4x8") return launch_transpose_shape<4, 8>(ctx, d_src, SW, DW, d_dst, xcd, order);
-	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, d_dst, xcd, order);
-	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, d_dst, xcd, order);
-	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, d_dst, xcd, order);
+	if (shape == "stream16") return launch_transpose_stream(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "4x16") return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "4x8") return launch_transpose_shape<4, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "unknown transpose kernel '%s'", shape.c_str());
 }
 
@@ -312,14 +313,16 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 // remembered.  V2M_TRANSPOSE_PANEL forces one; V2M_TRANSPOSE_CANDIDATES (comma-free list separated by ';') replaces the list.
 char const *const kTransposeCandidates[] = {"8x8", "stream16", "ring:8,8,8,8,64", "ring:8,8,8,8,128"};
 
-int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst)
+// src_pitch / dst_pitch: words from one column to the next (0 = dense: n_rows / 64 and n_cols / 64).
+int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst, u64 src_pitch = 0, u64 dst_pitch = 0)
 {
 	u64 const SW(n_rows / 64), DW(n_cols / 64);
+	u64 const SP(src_pitch ? src_pitch : SW), DP(dst_pitch ? dst_pitch : DW);
 	char const *e(std::getenv("V2M_TRANSPOSE_PANEL"));
-	if (e && *e) return launch_transpose_named(ctx, e, d_src, SW, DW, d_dst);
-	if (SW * DW * 512 < (u64(32) << 20)) return launch_transpose_named(ctx, "8x8", d_src, SW, DW, d_dst);
+	if (e && *e) return launch_transpose_named(ctx, e, d_src, SW, DW, SP, DP, d_dst);
+	if (SW * DW * 512 < (u64(32) << 20)) return launch_transpose_named(ctx, "8x8", d_src, SW, DW, SP, DP, d_dst);
 	for (auto const &c : ctx->transpose_choice)
-		if (c.rows == n_rows && c.cols == n_cols) return launch_transpose_named(ctx, c.kernel, d_src, SW, DW, d_dst);
+		if (c.rows == n_rows && c.cols == n_cols && c.src_pitch == SP && c.dst_pitch == DP) return launch_transpose_named(ctx, c.kernel, d_src, SW, DW, SP, DP, d_dst);
 
 	std::vector<std::string> names;
 	if (char const *list = std::getenv("V2M_TRANSPOSE_CANDIDATES")) {
@@ -339,7 +342,7 @@ int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64
 		for (int rep(0); rep < 2; ++rep) {        // the second round's times count (the first touches the pages)
 			V2M_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
 			for (std::size_t k(0); k < names.size(); ++k) {
-				if (int const rc = launch_transpose_named(ctx, names[k], d_src, SW, DW, d_dst)) return rc;
+				if (int const rc = launch_transpose_named(ctx, names[k], d_src, SW, DW, SP, DP, d_dst)) return rc;
 				V2M_HIP_TRY(ctx, hipEventRecord(ev[k + 1], ctx->stream));
 			}
 			V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -351,8 +354,8 @@ int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64
 		}
 	}
 	std::size_t const pick(std::size_t(std::min_element(best.begin(), best.end()) - best.begin()));
-	ctx->transpose_choice.push_back({n_rows, n_cols, names[pick]});
-	std::string note("transpose " + std::to_string(n_rows) + "x" + std::to_string(n_cols) + " bits: " + names[pick] + " (");
+	ctx->transpose_choice.push_back({n_rows, n_cols, SP, DP, names[pick]});
+	std::string note("transpose " + std::to_string(n_rows) + "x" + std::to_string(n_cols) + " bits" + ((SP != SW || DP != DW) ? " (column pitches " + std::to_string(SP) + " / " + std::to_string(DP) + " words)" : std::string()) + ": " + names[pick] + " (");
 	for (std::size_t k(0); k < names.size(); ++k) {
 		char buf[64];
 		std::snprintf(buf, sizeof(buf), "%s%s %.3f ms", k ? ", " : "", names[k].c_str(), best[k]);
@@ -364,7 +367,7 @@ int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64
 	ctx->info += note;
 	// the calibration already produced the result; run the chosen kernel once more under the caller's profiling so
 	// that its launch is accounted for like any other
-	return launch_transpose_named(ctx, names[pick], d_src, SW, DW, d_dst);
+	return launch_transpose_named(ctx, names[pick], d_src, SW, DW, SP, DP, d_dst);
 }
 
 
@@ -506,14 +509,14 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 			u64 const nr(std::min<u64>(65535, n_rows - r0));
 			if (any_switching_row)
 				hipLaunchKernelGGL(v2m::assemble_row_bits_kernel, dim3(unsigned((n_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
-					ctx->d_paths, ctx->path_rows / 64, rs, ctx->d_row_bits.as<u64>(), u32(n_words), u32(r0));
+					ctx->d_paths, ctx->path_pitch, rs, ctx->d_row_bits.as<u64>(), u32(n_words), u32(r0));
 			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
-				ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
+				ctx->d_paths, ctx->path_pitch, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
 				ctx->d_eff.as<u64>(), u32(n_words), u32(eff_words), u32(r0), ctx->d_needs_serial.as<u32>(), max_back_words);
 		}
 		// rows whose restart point is too far back for the per-word kernel (chromosome-scale deletions)
 		hipLaunchKernelGGL(v2m::resolve_rows_serial_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
-			ctx->d_paths, ctx->path_rows / 64, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(),
+			ctx->d_paths, ctx->path_pitch, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(),
 			ctx->d_eff.as<u64>(), eff_words, u32(n_rows), ctx->d_needs_serial.as<u32>());
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
@@ -925,6 +928,7 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 		ctx->d_paths = ctx->owned_paths.as<u64>();
 		ctx->path_rows = g->path_rows;
 		ctx->path_cols = g->path_cols;
+		ctx->path_pitch = g->path_rows / 64;
 	}
 	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
@@ -946,7 +950,47 @@ int v2m_set_paths_device(v2m_ctx *ctx, const void *d_words, uint64_t path_rows, 
 	ctx->d_paths = static_cast<u64 const *>(d_words);
 	ctx->path_rows = path_rows;
 	ctx->path_cols = path_cols;
+	ctx->path_pitch = path_rows / 64;
 	return V2M_OK;
+}
+
+namespace {
+
+// The library's own copy of paths_by_chrom_copy_and_edge keeps every copy's column on a 128-byte line: the column pitch is
+// the word count rounded up to 16.  Nobody but the kernels of this file reads that buffer, and with line-aligned
+// destination columns the transpose stores whole lines.
+u64 aligned_pitch(u64 words) { return (words + 15) & ~u64(15); }
+
+// Transposes a device-resident transpose input (n_rows copies x n_cols edges, column pitch src_pitch words) into the
+// ctx-owned, line-aligned path matrix and binds it.  Asynchronous on the ctx's stream.
+int transpose_into_owned_paths(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 src_pitch)
+{
+	u64 const pitch(aligned_pitch(n_cols / 64));
+	V2M_HIP_TRY(ctx, ctx->owned_paths.ensure(pitch * n_rows * sizeof(u64)));
+	// (the pad words between a column's n_cols / 64 words and its pitch are neither written here nor read by any kernel)
+	if (int const rc = launch_transpose(ctx, d_src, n_rows, n_cols, ctx->owned_paths.as<u64>(), src_pitch, pitch)) return rc;
+	ctx->d_paths = ctx->owned_paths.as<u64>();
+	ctx->path_rows = n_cols;
+	ctx->path_cols = n_rows;
+	ctx->path_pitch = pitch;
+	return V2M_OK;
+}
+
+} // namespace
+
+int v2m_bind_path_matrix_device(v2m_ctx *ctx, const void *d_paths_by_edge_and_chrom_copy, uint64_t n_rows, uint64_t n_cols)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (!ctx->has_graph) return fail(ctx, V2M_ERR_STATE, "no graph uploaded");
+	if (n_rows % 64 || n_cols % 64)                            // transpose_matrix.cc:53-54
+		return fail(ctx, V2M_ERR_PRECONDITION, "matrix dimensions must be multiples of 64 (got %llu x %llu)", (unsigned long long) n_rows, (unsigned long long) n_cols);
+	if (n_cols < ctx->n_edges) return fail(ctx, V2M_ERR_PRECONDITION, "path matrix has %llu edge columns, the graph %llu edges", (unsigned long long) n_cols, (unsigned long long) ctx->n_edges);
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	ctx->d_paths = nullptr;
+	ctx->path_rows = ctx->path_cols = ctx->path_pitch = 0;
+	if (0 == n_rows || 0 == n_cols) return V2M_OK;
+	if (!d_paths_by_edge_and_chrom_copy || ((uintptr_t) d_paths_by_edge_and_chrom_copy & 7)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the matrix must be a non-NULL 8-byte aligned device pointer");
+	return transpose_into_owned_paths(ctx, static_cast<u64 const *>(d_paths_by_edge_and_chrom_copy), n_rows, n_cols, 0);
 }
 
 int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_rows, uint64_t n_cols, uint64_t first_copy, uint64_t n_copies)
@@ -960,16 +1004,19 @@ int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_ro
 	if (first_copy > n_rows || n_copies > n_rows - first_copy) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "copies [%llu, %llu) are outside the matrix (%llu rows)", (unsigned long long) first_copy, (unsigned long long) (first_copy + n_copies), (unsigned long long) n_rows);
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ctx->d_paths = nullptr;
-	ctx->path_rows = ctx->path_cols = 0;
+	ctx->path_rows = ctx->path_cols = ctx->path_pitch = 0;
 	if (0 == n_copies || 0 == n_cols) return V2M_OK;              // nothing to bind: rows of this ctx can only be REF rows
 	if (!src_words) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL matrix pointer");
 
 	u64 const hp((n_copies + 63) / 64 * 64);                      // the slice's row count: this GPU's copies, padded
-	size_t const col_bytes(hp / 8), take((n_copies + 7) / 8), src_col_bytes(n_rows / 8), bytes(col_bytes * n_cols);
+	size_t const take((n_copies + 7) / 8), src_col_bytes(n_rows / 8);
+	bool const whole(take == src_col_bytes);
+	// a packed slice gets line-aligned columns too (pitch rounded up to 16 words); the whole matrix is sent as it is
+	u64 const src_pitch(whole ? hp / 64 : aligned_pitch(hp / 64));
+	size_t const col_bytes(src_pitch * 8), bytes(col_bytes * n_cols);
 	V2M_HIP_TRY(ctx, ctx->d_slice_src.ensure(bytes));
-	V2M_HIP_TRY(ctx, ctx->owned_paths.ensure(bytes));
 	char const *const src(reinterpret_cast<char const *>(src_words) + first_copy / 8);
-	if (take == src_col_bytes) {
+	if (whole) {
 		// the whole matrix: one contiguous copy
 		V2M_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slice_src.p, src_words, bytes, hipMemcpyHostToDevice, ctx->stream));
 	} else {
@@ -1004,12 +1051,9 @@ int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_ro
 			V2M_HIP_TRY(ctx, hipEventRecord(sent[b], ctx->stream));
 		}
 	}
-	if (int const rc = launch_transpose(ctx, ctx->d_slice_src.as<u64>(), hp, n_cols, ctx->owned_paths.as<u64>())) return rc;
+	if (int const rc = transpose_into_owned_paths(ctx, ctx->d_slice_src.as<u64>(), hp, n_cols, src_pitch)) return rc;
 	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->d_slice_src.reset();
-	ctx->d_paths = ctx->owned_paths.as<u64>();
-	ctx->path_rows = n_cols;
-	ctx->path_cols = hp;
 	return V2M_OK;
 }
 
