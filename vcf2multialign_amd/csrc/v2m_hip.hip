@@ -102,6 +102,7 @@ struct v2m_ctx {
 
 	// store flavour of the aligned splice: -1 = not calibrated yet, 0 = plain, 1 = nontemporal
 	int store_mode{-1};
+	int unaligned_store_mode{-1};   // the same for the unaligned splice
 	std::string info;
 
 	// per-call scratch
@@ -648,17 +649,48 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 		hipLaunchKernelGGL(v2m::scan_tile_counts_kernel, dim3(unsigned(n_rows)), dim3(256), 0, ctx->stream,
 			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, ctx->d_row_lengths.as<u64>());
 	}
-	{
-		timed_launch tl(ctx, V2M_KERNEL_SPLICE_UNALIGNED);
-		char const *const mode_env(std::getenv("V2M_UNALIGNED_STORE"));   // tuning knob: plain | nt (default)
-		bool const plain(mode_env && 0 == std::strcmp(mode_env, "plain"));
-		auto const launch([&](auto kernel) {
+	auto const launch([&](bool nt) {
+		auto const go([&](auto kernel) {
 			hipLaunchKernelGGL(kernel, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 				ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
 				ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
 		});
-		if (plain) launch(v2m::splice_unaligned_kernel<false>);
-		else launch(v2m::splice_unaligned_kernel<true>);
+		if (nt) go(v2m::splice_unaligned_kernel<true>);
+		else go(v2m::splice_unaligned_kernel<false>);
+	});
+	// Store flavour: as for the aligned splice, which of nontemporal and plain stores is faster depends on the box and the
+	// buffer (7.2 vs 5.4 ms per 256 config-3 rows on one box, 5.6 vs 6.0 ms on another), so the first launch that writes
+	// >= 1 GiB is issued twice per flavour (same output every time) and the faster one is kept.  V2M_UNALIGNED_STORE=plain|nt forces.
+	int mode(ctx->unaligned_store_mode);
+	if (char const *const mode_env = std::getenv("V2M_UNALIGNED_STORE")) {
+		if (0 == std::strcmp(mode_env, "plain")) mode = 0;
+		else if (0 == std::strcmp(mode_env, "nt")) mode = 1;
+	}
+	if (mode < 0 && n_rows * ctx->ref_len >= (u64(1) << 30)) {
+		scoped_events ev;
+		V2M_HIP_TRY(ctx, ev.create(5));
+		V2M_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
+		for (int i(0); i < 4; ++i) {
+			launch(0 == (i & 1));   // nt, plain, nt, plain
+			V2M_HIP_TRY(ctx, hipEventRecord(ev[i + 1], ctx->stream));
+		}
+		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		float t[4];
+		for (int i(0); i < 4; ++i) V2M_HIP_TRY(ctx, hipEventElapsedTime(&t[i], ev[i], ev[i + 1]));
+		float const nt_ms(std::min(t[0], t[2])), plain_ms(std::min(t[1], t[3]));
+		ctx->unaligned_store_mode = nt_ms <= plain_ms ? 1 : 0;
+		char buf[160];
+		std::snprintf(buf, sizeof(buf), "unaligned splice stores: %s (calibrated on %llu rows: nontemporal %.3f ms, plain %.3f ms)",
+			ctx->unaligned_store_mode ? "nontemporal" : "plain", (unsigned long long) n_rows, nt_ms, plain_ms);
+		if (ctx->info.size() > 2000) ctx->info.clear();
+		if (!ctx->info.empty()) ctx->info += "; ";
+		ctx->info += buf;
+		mode = ctx->unaligned_store_mode;
+	}
+	if (mode < 0) mode = 1;   // small launches before any calibration
+	{
+		timed_launch tl(ctx, V2M_KERNEL_SPLICE_UNALIGNED);
+		launch(0 != mode);
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
