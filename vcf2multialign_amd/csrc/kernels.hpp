@@ -588,12 +588,15 @@ constexpr u32 kMaxBackWords = 2048;   // default max_back_words: restart points 
 __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
 	row_segments rs, edge_span const *__restrict__ spans, u64 const *__restrict__ overlappable,
-	u64 *__restrict__ eff, u32 n_words, u32 eff_words_per_row, u32 row_base, u32 *__restrict__ needs_serial, u32 max_back_words)
+	u64 *__restrict__ eff, u32 n_words, u32 eff_words_per_row, u32 row_base, u32 piece_base, u32 *__restrict__ needs_serial, u32 max_back_words)
 {
-	// grid: x over the row's words, y over rows -- the row (and with it the segment table lookups below) is uniform
-	// per workgroup, so those loads are scalar and leave the per-lane path with the one coalesced word load
-	u32 const row = blockIdx.y + row_base;
-	u32 const wi = blockIdx.x * blockDim.x + threadIdx.x;
+	// grid: x over rows, y over 256-word pieces of a row.  The row (and with it the segment table lookups below) is uniform
+	// per workgroup, so those loads are scalar and leave the per-lane path with the one coalesced word load.  Rows run
+	// fastest so that the workgroups in flight at any time work on the SAME few pieces of many rows: the replay path's
+	// scattered 8-byte reads of `spans` (a fifth of all words take it on config 5's graph) then hit lines another row's
+	// workgroup has just pulled into the L2, instead of streaming the 50-MB table once per row.
+	u32 const row = blockIdx.x + row_base;
+	u32 const wi = (blockIdx.y + piece_base) * blockDim.x + threadIdx.x;
 	if (wi >= n_words) return;
 	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
 	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;   // padding bits are zero by contract; do not trust them

@@ -511,9 +511,10 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 			if (any_switching_row)
 				hipLaunchKernelGGL(v2m::assemble_row_bits_kernel, dim3(unsigned((n_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
 					ctx->d_paths, ctx->path_pitch, rs, ctx->d_row_bits.as<u64>(), u32(n_words), u32(r0));
-			hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned((n_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
-				ctx->d_paths, ctx->path_pitch, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
-				ctx->d_eff.as<u64>(), u32(n_words), u32(eff_words), u32(r0), ctx->d_needs_serial.as<u32>(), max_back_words);
+			for (u64 piece0(0), pieces((n_words + 255) / 256); piece0 < pieces; piece0 += 65535)   // grid.y limit; rows run fastest, see the kernel
+				hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned(nr), unsigned(std::min<u64>(65535, pieces - piece0))), dim3(256), 0, ctx->stream,
+					ctx->d_paths, ctx->path_pitch, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
+					ctx->d_eff.as<u64>(), u32(n_words), u32(eff_words), u32(r0), u32(piece0), ctx->d_needs_serial.as<u32>(), max_back_words);
 		}
 		// rows whose restart point is too far back for the per-word kernel (chromosome-scale deletions)
 		hipLaunchKernelGGL(v2m::resolve_rows_serial_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
