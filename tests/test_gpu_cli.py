@@ -300,3 +300,17 @@ def test_plain_c_example(tmp_path):
 	r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
 	assert r.returncode == 0, r.stderr.decode()
 	assert r.stdout.decode().splitlines() == ["REF     ACG--TACGT", "copy 0  ACGTTTACGT", "copy 1  ACG--TACG-"]
+
+
+def test_sharded_c_example(tmp_path):
+	"""examples/sharded_rows.c: two contexts, each holding only its own slice of the path matrix (v2m_upload_path_slice), from C99."""
+	import shutil
+	from vcf2multialign_amd import build
+	src = os.path.join(ROOT, "examples", "sharded_rows.c")
+	exe = tmp_path / "sharded_rows"
+	subprocess.check_call([shutil.which("gcc"), "-std=c99", "-I" + os.path.join(ROOT, "include"), src, "-L" + build.PKG_DIR, "-lv2m_hip",
+		"-Wl,-rpath," + build.PKG_DIR, "-Wl,-rpath-link,/opt/rocm/lib", "-o", str(exe)])
+	r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+	assert r.returncode == 0, r.stderr.decode()
+	lines = r.stdout.decode().splitlines()
+	assert len(lines) == 17 and lines[0] == "REF     ACG--TACGTAC" and lines[4] == "copy    ACGTTTACG-AC"

@@ -159,7 +159,8 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
 	gcc = shutil.which("gcc")
 	assert gcc, "gcc is part of the image"
 	src = os.path.join(root, "examples", "splice_rows.c")
-	subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"), "-fsyntax-only", src])
+	for example in (src, os.path.join(root, "examples", "sharded_rows.c")):
+		subprocess.check_call([gcc, "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(root, "include"), "-fsyntax-only", example])
 	build.build_native()
 	exe = tmp_path / "splice_rows"
 	subprocess.check_call([gcc, "-std=c99", "-I" + os.path.join(root, "include"), src, "-L" + build.PKG_DIR, "-lv2m_hip",

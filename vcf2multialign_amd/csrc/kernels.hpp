@@ -820,6 +820,17 @@ struct tile_job {
 	u32 w0;             // first effective-bit word cached
 };
 
+// The effective-edge words of up to kGroupRowsLds rows, first_row onwards, for the tile's cached edge range.
+__device__ __forceinline__ void load_eff_cache(
+	patch_cache &pc, tile_job const &job, u64 const *__restrict__ eff, u64 eff_words_per_row, u32 first_row, u32 n_rows, int t)
+{
+	if (0 == job.n_lds) return;
+	u32 const nw = ((job.range_begin + job.n_lds - 1) >> 6) - job.w0 + 1;   // <= kEffWordsLds
+	u32 const rows = n_rows < (u32) kGroupRowsLds ? n_rows : (u32) kGroupRowsLds;
+	for (u32 i = t; i < rows * nw; i += kSpliceThreads)
+		pc.eff[i / nw][i % nw] = eff[(u64) (first_row + i / nw) * eff_words_per_row + job.w0 + i % nw];
+}
+
 __device__ __forceinline__ void load_patch_cache(
 	patch_cache &pc, tile_job &job, tile_tables const &tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
 	u64 const *__restrict__ eff, u64 eff_words_per_row, u32 tile, u32 row_begin, u32 n_group_rows, int t)
@@ -849,11 +860,8 @@ __device__ __forceinline__ void load_patch_cache(
 		u32 const label_len = label_span < (u32) kLabelLds ? label_span : (u32) kLabelLds;
 		for (u32 i = t; i < label_len; i += kSpliceThreads)
 			pc.labels[i] = (unsigned char) labels[label_base + i];
-		u32 const nw = ((job.range_begin + job.n_lds - 1) >> 6) - job.w0 + 1;   // <= kEffWordsLds
-		u32 const rows = n_group_rows < (u32) kGroupRowsLds ? n_group_rows : (u32) kGroupRowsLds;
-		for (u32 i = t; i < rows * nw; i += kSpliceThreads)
-			pc.eff[i / nw][i % nw] = eff[(u64) (row_begin + i / nw) * eff_words_per_row + job.w0 + i % nw];
 	}
+	load_eff_cache(pc, job, eff, eff_words_per_row, row_begin, n_group_rows, t);
 	if (t == 0) pc.long_count = 0;
 	// visibility: the caller's next __syncthreads() (after it has dropped the pristine tile into LDS)
 }
@@ -1101,14 +1109,24 @@ __global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
 	for (int wv = 0; wv < kSpliceThreads / 64; ++wv) tile_count += wave_sums[wv];
 
 	unsigned char const *const tile_bytes = (unsigned char const *) lds;
-	for (u32 row = row_begin; row < row_end; ++row) {
-		int delta = 0;
-		for_each_effective_candidate(pc, job, tt, patches, eff + (u64) row * eff_words_per_row, row - row_begin, t, [&](tile_patch const &tp) {
-			u32 const label_end = tp.aln_begin + tp.label_len;
-			int const label_in_tile = label_end > tp.from ? (int) ((label_end < tp.to ? label_end : tp.to) - tp.from) : 0;
-			delta += label_in_tile - (int) count_nonzero_bytes(tile_bytes, tp.from - job.tile_base, tp.to - job.tile_base);
-		});
-		if (delta) atomicAdd(&row_delta[row - row_begin], delta);
+	// The group may hold more rows than the LDS cache of effective-edge words (kGroupRowsLds): the template tile, its count
+	// and the patch descriptors are loaded once per group, the cached words are reloaded every kGroupRowsLds rows.
+	for (u32 sub = row_begin; sub < row_end; sub += kGroupRowsLds) {
+		u32 const sub_end = sub + kGroupRowsLds < row_end ? sub + kGroupRowsLds : row_end;
+		if (sub != row_begin) {
+			__syncthreads();                                     // everyone is done with the previous rows' words
+			load_eff_cache(pc, job, eff, eff_words_per_row, sub, sub_end - sub, t);
+			__syncthreads();
+		}
+		for (u32 row = sub; row < sub_end; ++row) {
+			int delta = 0;
+			for_each_effective_candidate(pc, job, tt, patches, eff + (u64) row * eff_words_per_row, row - sub, t, [&](tile_patch const &tp) {
+				u32 const label_end = tp.aln_begin + tp.label_len;
+				int const label_in_tile = label_end > tp.from ? (int) ((label_end < tp.to ? label_end : tp.to) - tp.from) : 0;
+				delta += label_in_tile - (int) count_nonzero_bytes(tile_bytes, tp.from - job.tile_base, tp.to - job.tile_base);
+			});
+			if (delta) atomicAdd(&row_delta[row - row_begin], delta);
+		}
 	}
 	__syncthreads();
 	for (u32 r = t; r < row_end - row_begin; r += kSpliceThreads)

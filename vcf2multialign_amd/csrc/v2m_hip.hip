@@ -643,10 +643,15 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 	V2M_HIP_TRY(ctx, ctx->d_tile_counts.ensure(n_rows * ctx->n_tiles * sizeof(u32)));
 	v2m::tile_tables tt{ctx->d_tile_edge_begin.as<u32>(), ctx->d_cross_offsets.as<u32>(), ctx->d_cross_edges.as<u32>()};
 	{
+		// pass 1 builds no row, so it takes more rows per workgroup than pass 2 (the template tile and its byte count are
+		// loaded once per group): V2M_COUNT_ROWS_PER_GROUP, at most 256 (kCountRowsMax)
+		char const *const ce(std::getenv("V2M_COUNT_ROWS_PER_GROUP"));
+		u32 const count_rows(u32(std::min<u64>(std::max<u64>(1, n_rows), (ce && *ce && std::atoi(ce) > 0) ? u64(std::min(std::atoi(ce), int(v2m::kCountRowsMax))) : u64(64))));
+		u32 const count_groups(u32((n_rows + count_rows - 1) / count_rows));
 		timed_launch tl(ctx, V2M_KERNEL_UNALIGNED_COUNT);
-		hipLaunchKernelGGL(v2m::count_unaligned_kernel, dim3(unsigned(g.n_blocks)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
+		hipLaunchKernelGGL(v2m::count_unaligned_kernel, dim3(unsigned(u64(ctx->n_tiles) * count_groups)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
 			ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
-			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
+			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, u32(n_rows), count_rows, count_groups, g.tile_run);
 		hipLaunchKernelGGL(v2m::scan_tile_counts_kernel, dim3(unsigned(n_rows)), dim3(256), 0, ctx->stream,
 			ctx->d_tile_counts.as<u32>(), ctx->n_tiles, ctx->d_row_lengths.as<u64>());
 	}
