@@ -13,6 +13,7 @@ from vcf2multialign_amd.host import HostGraph
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "config3"
 mode = sys.argv[2] if len(sys.argv) > 2 else "founders"    # or "haplotypes": BASELINE config 3 (all 5009 rows, 501 GB of A2M)
+devices = sys.argv[3] if len(sys.argv) > 3 else None        # e.g. "0,0": several contexts, each with its own slice of the path matrix
 tmp = os.environ.get("TMPDIR", "/tmp")
 fa, gf = os.path.join(tmp, cfg + ".fa"), os.path.join(tmp, cfg + ".v2mgraph")
 t = time.time()
@@ -38,7 +39,7 @@ ctx.close(); del src, dst
 print("prepared %s: graph file %.0f MB, FASTA %.0f MB in %.1f s" % (cfg, os.path.getsize(gf) / 1e6, os.path.getsize(fa) / 1e6, time.time() - t), flush=True)
 
 t = time.time()
-p = subprocess.Popen([build.CLI_PATH] + (["-F", "25", "-d", "50"] if mode == "founders" else ["-H"]) + ["-r", fa, "-g", gf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"],
+p = subprocess.Popen([build.CLI_PATH] + (["-F", "25", "-d", "50"] if mode == "founders" else ["-H"]) + ["-r", fa, "-g", gf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"] + (["--device=" + devices, "--verbose"] if devices else []),
 	stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 marks = []
 for line in p.stderr:
@@ -46,7 +47,8 @@ for line in p.stderr:
 p.wait()
 total = time.time() - t
 for m in marks:
-	print("  %7.2f s  %s" % m)
+	if not m[1].startswith("Handled "):
+		print("  %7.2f s  %s" % m)
 print(p.stdout.read().strip())
 rows = 26 if mode == "founders" else ds.n_copies + 1
 print("exit %d; total %.2f s (%d rows x %d bases = %.1f Gbases -> %.1f Gbases/s end to end)" % (p.returncode, total, rows, g.aligned_length, rows * g.aligned_length / 1e9, rows * g.aligned_length / 1e9 / total))
