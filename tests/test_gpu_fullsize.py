@@ -341,3 +341,45 @@ def test_config4_full_size(env):
 		assert np.array_equal(sums[check], exp_sums)
 		r = founders
 		assert out[r * pitch:r * pitch + L].cpu().numpy().tobytes() == og.output_sequence(ds.reference, cuts=batch_rows[r])
+
+
+def test_config3_path_slices_full_size(env):
+	"""SURVEY 8(e) at config 3's full size, through the product entry: the whole host-resident transpose input (5056 copies x
+	1 M edges, 632 MB) is offered to each of 8 'GPUs' (contexts on this one), each takes only its own copies
+	(v2m_upload_path_slice: packed slice, transposed there, line-aligned copy bound) and splices rows of them; sampled rows
+	of three ranks against the oracle, and every rank's shard against the chromosome-copy ranges sharding.py hands out."""
+	torch, v2m, synth = env
+	from vcf2multialign_amd.sharding import shard_copies
+	ds = synth.dataset("config3")
+	g = ds.graph
+	L = g.aligned_length
+	hp, ep = ds.path_cols, ds.path_rows
+	with v2m.Context(0) as ctx:
+		src, _ = _device_paths(torch, v2m, ds, ctx)
+		host_src = src.cpu().numpy().view(np.uint64)                       # paths_by_edge_and_chrom_copy as the builder would hold it
+		del src, _
+		world = 8
+		covered = 0
+		for rank in range(world):
+			c0, c1, hp_local = shard_copies(ds.n_copies, world, rank)
+			assert c0 == covered and c0 % 8 == 0
+			covered = c1
+			if rank not in (0, 3, 7):
+				continue
+			ctx.upload_graph(g, ds.reference)
+			ctx.upload_path_slice(host_src, hp, ep, c0, c1 - c0)
+			local = sorted({0, 1, (c1 - c0) // 2, c1 - c0 - 1})
+			rows = ([v2m.PLOIDY_MAX] if rank == 0 else []) + local
+			pitch = ctx.min_row_pitch
+			out = torch.empty(len(rows) * pitch, dtype=torch.uint8, device="cuda")
+			torch.cuda.synchronize()
+			ctx.splice_rows_device(rows, out.data_ptr(), pitch)
+			sums = ctx.checksum_rows_device(out.data_ptr(), pitch, len(rows), length=L)
+			og = _oracle_for(ds, [c0 + c for c in local])
+			want, lengths = og.row_checksums(ds.reference, ([oracle.PLOIDY_MAX] if rank == 0 else []) + list(range(len(local))), threads=len(rows))
+			assert set(lengths.tolist()) == {L}
+			assert np.array_equal(sums, want), (rank, c0, c1)
+			with pytest.raises(v2m.V2MError):                               # this context holds its own copies (padded) and no more
+				ctx.splice_rows_device([hp_local], out.data_ptr(), pitch)
+			del out
+		assert covered == ds.n_copies
