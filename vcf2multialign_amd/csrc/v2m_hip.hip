@@ -86,6 +86,7 @@ struct v2m_ctx {
 	std::vector<u32> h_csum;            // alt_edge_count_csum narrowed, [N + 1]
 	std::vector<u32> h_tgt_prefix_max;  // [E + 1]: max target over edges < e (cut validation)
 	dev_buf d_ref, d_ref_pos, d_aln_pos, d_spans, d_patches, d_labels, d_template, d_overlappable;
+	dev_buf d_ovl_rank, d_blocker_masks;   // per word: overlappable edges before it; per overlappable edge: who can block it
 	dev_buf d_template0;   // the REF row with 0 as padding byte (unaligned mode), built on first use
 	bool has_template0{};
 	dev_buf d_tile_edge_begin, d_cross_offsets, d_cross_edges;
@@ -514,6 +515,7 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 			for (u64 piece0(0), pieces((n_words + 255) / 256); piece0 < pieces; piece0 += 65535)   // grid.y limit; rows run fastest, see the kernel
 				hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned(nr), unsigned(std::min<u64>(65535, pieces - piece0))), dim3(256), 0, ctx->stream,
 					ctx->d_paths, ctx->path_pitch, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
+					ctx->d_ovl_rank.as<u32>(), ctx->d_blocker_masks.as<u64>(),
 					ctx->d_eff.as<u64>(), u32(n_words), u32(eff_words), u32(r0), u32(piece0), ctx->d_needs_serial.as<u32>(), max_back_words);
 		}
 		// rows whose restart point is too far back for the per-word kernel (chromosome-scale deletions)
@@ -904,6 +906,25 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 		}
 	}
 
+	// --- who can block an overlappable edge ----------------------------------------------------
+	// Edge e is skipped only if an EFFECTIVE earlier edge e' ends past e's source node (tgt[e'] > src[e]); if none of those
+	// edges is even set in a row, e is effective there without replaying the walk.  Per overlappable edge: the mask of such
+	// edges inside e's own 64-edge word (all ones when one lies in an earlier word: the kernel then replays), indexed by
+	// the edge's rank among the overlappable ones.
+	std::vector<u32> ovl_rank(overlappable.size() + 1, 0);
+	std::vector<u64> blocker_masks;
+	for (u64 wi(0); wi < overlappable.size(); ++wi) {
+		ovl_rank[wi] = u32(blocker_masks.size());
+		for (u64 m(overlappable[wi]); m; m &= m - 1) {
+			u64 const b(u64(__builtin_ctzll(m))), e(wi * 64 + b);
+			u64 mask(0);
+			if (tgt_prefix_max[wi * 64] > spans[e].src) mask = ~u64(0);
+			else for (u64 k(0); k < b; ++k) if (spans[wi * 64 + k].tgt > spans[e].src) mask |= u64(1) << k;
+			blocker_masks.push_back(mask);
+		}
+	}
+	ovl_rank.back() = u32(blocker_masks.size());
+
 	// --- per-tile edge tables ----------------------------------------------------------------
 	u32 const n_tiles(u32(std::max<u64>(1, (L + v2m::kTileBytes - 1) / v2m::kTileBytes)));
 	std::vector<u32> tile_edge_begin(n_tiles + 1), cross_offsets(n_tiles + 1, 0), cross_edges;
@@ -944,6 +965,8 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 	if (int const rc = upload_vec(ctx, ctx->d_spans, spans)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_patches, patches)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_overlappable, overlappable)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_ovl_rank, ovl_rank)) return rc;
+	if (int const rc = upload_vec(ctx, ctx->d_blocker_masks, blocker_masks)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_tile_edge_begin, tile_edge_begin)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_cross_offsets, cross_offsets)) return rc;
 	if (int const rc = upload_vec(ctx, ctx->d_cross_edges, cross_edges)) return rc;
