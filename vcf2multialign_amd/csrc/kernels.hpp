@@ -583,6 +583,7 @@ __global__ __launch_bounds__(256) void assemble_row_bits_kernel(
 	if (w0 + lane < n_words) assembled[(u64) row * rs.assembled_words + w0 + lane] = acc[threadIdx.x];
 }
 
+constexpr int kResolveWordsPerThread = 8;
 constexpr u32 kMaxBackWords = 2048;   // default max_back_words: restart points > 131072 edges back go to the serial kernel
 
 __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
@@ -596,86 +597,90 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 	// fastest so that the workgroups in flight at any time work on the SAME few pieces of many rows: the replay path's
 	// scattered 8-byte reads of `spans` (a fifth of all words take it on config 5's graph) then hit lines another row's
 	// workgroup has just pulled into the L2, instead of streaming the 50-MB table once per row.
+	// A workgroup takes kResolveWordsPerThread x 256 consecutive words of its row: with one word per thread the grid of a
+	// config-5 batch was 95 000 workgroups of 2 KB each and the kernel was bound by workgroup dispatch, not by memory.
 	u32 const row = blockIdx.x + row_base;
-	u32 const wi = (blockIdx.y + piece_base) * blockDim.x + threadIdx.x;
-	if (wi >= n_words) return;
 	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
 	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;   // padding bits are zero by contract; do not trust them
+	for (int piece = 0; piece < kResolveWordsPerThread; ++piece) {
+		u32 const wi = ((blockIdx.y + piece_base) * kResolveWordsPerThread + piece) * blockDim.x + threadIdx.x;
+		if (wi >= n_words) return;                           // pieces are consecutive: nothing further either
 
-	u64 w = load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, wi);
-	if (wi == n_words - 1) w &= tail_mask;
-	u64 const ovl_w = overlappable[wi];
-	u64 ov = w & ovl_w;
-	u64 out = w;
-	if (ov) {
-		// An overlappable edge none of whose possible blockers is set in this row is effective without any replay (the
-		// masks are per graph: the edges of this word that end past its source node; all ones when an earlier word holds
-		// one).  On config 5's graph a fifth of all words have a set overlappable edge and 1-2 % need the replay.
-		u32 const rank0 = ovl_rank[wi];
-		bool blocked = false;
-		for (u64 m = ov; m; m &= m - 1) {
-			int const b = __builtin_ctzll(m);
-			u64 const mask = blocker_masks[rank0 + (u32) __builtin_popcountll(ovl_w & ((1ULL << b) - 1))];
-			blocked = blocked || 0 != (w & mask);
-		}
-		if (!blocked) ov = 0;
-	}
-	if (ov) {
-		// Restart point: the nearest earlier edge that is NOT overlappable, set or not.  When the walk
-		// reaches such an edge every earlier target is <= its source node, so the scan state there is
-		// equivalent to cur = 0.  The search runs over the graph-static mask only.
-		int const b0 = __builtin_ctzll(ov);
-		u32 sw = wi;
-		int sb = 0;
-		bool ok = true;
-		u64 fixed = ~ovl_w & ((1ULL << b0) - 1);
-		if (fixed) {
-			sb = 63 - __builtin_clzll(fixed);
-		} else {
-			u32 steps = 0;
-			for (;;) {
-				if (0 == sw) { sb = 0; break; }              // edge 0 is never overlappable; defensive
-				--sw;
-				if (++steps > max_back_words) { ok = false; break; }
-				fixed = ~overlappable[sw];
-				if (fixed) { sb = 63 - __builtin_clzll(fixed); break; }
+		u64 w = load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, wi);
+		if (wi == n_words - 1) w &= tail_mask;
+		u64 const ovl_w = overlappable[wi];
+		u64 ov = w & ovl_w;
+		u64 out = w;
+		if (ov) {
+			// An overlappable edge none of whose possible blockers is set in this row is effective without any replay (the
+			// masks are per graph: the edges of this word that end past its source node; all ones when an earlier word holds
+			// one).  On config 5's graph a fifth of all words have a set overlappable edge and 1-2 % need the replay.
+			u32 const rank0 = ovl_rank[wi];
+			bool blocked = false;
+			for (u64 m = ov; m; m &= m - 1) {
+				int const b = __builtin_ctzll(m);
+				u64 const mask = blocker_masks[rank0 + (u32) __builtin_popcountll(ovl_w & ((1ULL << b) - 1))];
+				blocked = blocked || 0 != (w & mask);
 			}
+			if (!blocked) ov = 0;
 		}
-		if (!ok) {
-			atomicOr(&needs_serial[row], 1u);
-		} else {
-			out = (sw == wi) ? (w & ((1ULL << sb) - 1)) : 0;   // set bits before the restart point in this word are certain
-			u32 cur = 0;
-			for (u32 ww = sw; ww <= wi; ++ww) {
-				u64 x = (ww == wi) ? w : load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, ww);
-				if (ww == sw) x &= ~((1ULL << sb) - 1);
-				// The rule itself is sequential, the loads it needs are not: the spans of the next (up to) 8 set edges are
-				// fetched together, then the rule runs over them in registers.  One dependent load per set edge made this
-				// kernel latency-bound on dense graphs (config 5: a fifth of all words come here, ~5.5 set edges each).
-				while (x) {
-					constexpr int kBatch = 8;
-					edge_span sp[kBatch];
-					int bit[kBatch];
-					bool has[kBatch];
+		if (ov) {
+			// Restart point: the nearest earlier edge that is NOT overlappable, set or not.  When the walk
+			// reaches such an edge every earlier target is <= its source node, so the scan state there is
+			// equivalent to cur = 0.  The search runs over the graph-static mask only.
+			int const b0 = __builtin_ctzll(ov);
+			u32 sw = wi;
+			int sb = 0;
+			bool ok = true;
+			u64 fixed = ~ovl_w & ((1ULL << b0) - 1);
+			if (fixed) {
+				sb = 63 - __builtin_clzll(fixed);
+			} else {
+				u32 steps = 0;
+				for (;;) {
+					if (0 == sw) { sb = 0; break; }              // edge 0 is never overlappable; defensive
+					--sw;
+					if (++steps > max_back_words) { ok = false; break; }
+					fixed = ~overlappable[sw];
+					if (fixed) { sb = 63 - __builtin_clzll(fixed); break; }
+				}
+			}
+			if (!ok) {
+				atomicOr(&needs_serial[row], 1u);
+			} else {
+				out = (sw == wi) ? (w & ((1ULL << sb) - 1)) : 0;   // set bits before the restart point in this word are certain
+				u32 cur = 0;
+				for (u32 ww = sw; ww <= wi; ++ww) {
+					u64 x = (ww == wi) ? w : load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, ww);
+					if (ww == sw) x &= ~((1ULL << sb) - 1);
+					// The rule itself is sequential, the loads it needs are not: the spans of the next (up to) 8 set edges are
+					// fetched together, then the rule runs over them in registers.  One dependent load per set edge made this
+					// kernel latency-bound on dense graphs (config 5: a fifth of all words come here, ~5.5 set edges each).
+					while (x) {
+						constexpr int kBatch = 8;
+						edge_span sp[kBatch];
+						int bit[kBatch];
+						bool has[kBatch];
 #pragma unroll
-					for (int k = 0; k < kBatch; ++k) {
-						has[k] = 0 != x;
-						bit[k] = has[k] ? __builtin_ctzll(x) : 0;
-						x &= x - 1;                                        // stays 0 once it is 0
-						sp[k] = spans[ww * 64u + bit[k]];                  // always a valid edge of this word (its first one when the batch has run out)
-					}
+						for (int k = 0; k < kBatch; ++k) {
+							has[k] = 0 != x;
+							bit[k] = has[k] ? __builtin_ctzll(x) : 0;
+							x &= x - 1;                                        // stays 0 once it is 0
+							sp[k] = spans[ww * 64u + bit[k]];                  // always a valid edge of this word (its first one when the batch has run out)
+						}
 #pragma unroll
-					for (int k = 0; k < kBatch; ++k) {
-						if (has[k] && sp[k].src >= cur) {
-							cur = sp[k].tgt;
-							if (ww == wi) out |= 1ULL << bit[k];
+						for (int k = 0; k < kBatch; ++k) {
+							if (has[k] && sp[k].src >= cur) {
+								cur = sp[k].tgt;
+								if (ww == wi) out |= 1ULL << bit[k];
+							}
 						}
 					}
 				}
 			}
 		}
+		eff[(u64) row * eff_words_per_row + wi] = out;
 	}
-	eff[(u64) row * eff_words_per_row + wi] = out;
 }
 
 

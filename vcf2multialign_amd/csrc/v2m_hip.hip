@@ -512,7 +512,7 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 			if (any_switching_row)
 				hipLaunchKernelGGL(v2m::assemble_row_bits_kernel, dim3(unsigned((n_words + 255) / 256), unsigned(nr)), dim3(256), 0, ctx->stream,
 					ctx->d_paths, ctx->path_pitch, rs, ctx->d_row_bits.as<u64>(), u32(n_words), u32(r0));
-			for (u64 piece0(0), pieces((n_words + 255) / 256); piece0 < pieces; piece0 += 65535)   // grid.y limit; rows run fastest, see the kernel
+			for (u64 piece0(0), pieces((n_words + 256 * v2m::kResolveWordsPerThread - 1) / (256 * v2m::kResolveWordsPerThread)); piece0 < pieces; piece0 += 65535)   // grid.y limit; rows run fastest, see the kernel
 				hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned(nr), unsigned(std::min<u64>(65535, pieces - piece0))), dim3(256), 0, ctx->stream,
 					ctx->d_paths, ctx->path_pitch, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
 					ctx->d_ovl_rank.as<u32>(), ctx->d_blocker_masks.as<u64>(),
