@@ -602,13 +602,33 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 	u32 const row = blockIdx.x + row_base;
 	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
 	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;   // padding bits are zero by contract; do not trust them
+	// All of the thread's words (and their masks) are requested before any is looked at: with one 8-byte load per lane in
+	// flight at a time the kernel ran at 2 TB/s whatever else was done to it (Little's law: 32 waves x 512 B per CU).
+	// Where the row's bits come from is uniform per workgroup: one chromosome copy, nothing (REF row), or the assembled row.
+	u64 const *row_words = nullptr;
+	if (s_end - s_begin == 1) {
+		u32 const copy = rs.seg_copy[s_begin];
+		if (copy != 0xFFFFFFFFu) row_words = paths + (u64) copy * words_per_copy;
+	} else {
+		row_words = rs.assembled + (u64) row * rs.assembled_words;
+	}
+	u32 const w_first = (blockIdx.y + piece_base) * kResolveWordsPerThread * blockDim.x + threadIdx.x;
+	u64 w_all[kResolveWordsPerThread], ovl_all[kResolveWordsPerThread];
+#pragma unroll
 	for (int piece = 0; piece < kResolveWordsPerThread; ++piece) {
-		u32 const wi = ((blockIdx.y + piece_base) * kResolveWordsPerThread + piece) * blockDim.x + threadIdx.x;
+		u32 const wi = w_first + piece * blockDim.x;
+		u32 const wc = wi < n_words ? wi : n_words - 1;     // clamped: every load is issued, none sits under a branch
+		w_all[piece] = row_words ? row_words[wc] : 0;
+		ovl_all[piece] = overlappable[wc];
+	}
+#pragma unroll
+	for (int piece = 0; piece < kResolveWordsPerThread; ++piece) {
+		u32 const wi = w_first + piece * blockDim.x;
 		if (wi >= n_words) return;                           // pieces are consecutive: nothing further either
 
-		u64 w = load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, wi);
+		u64 w = w_all[piece];
 		if (wi == n_words - 1) w &= tail_mask;
-		u64 const ovl_w = overlappable[wi];
+		u64 const ovl_w = ovl_all[piece];
 		u64 ov = w & ovl_w;
 		u64 out = w;
 		if (ov) {
