@@ -613,21 +613,31 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 		row_words = rs.assembled + (u64) row * rs.assembled_words;
 	}
 	u32 const w_first = (blockIdx.y + piece_base) * kResolveWordsPerThread * blockDim.x + threadIdx.x;
-	u64 w_all[kResolveWordsPerThread], ovl_all[kResolveWordsPerThread];
+	u64 w_all[kResolveWordsPerThread], ovl_all[kResolveWordsPerThread], mask_all[kResolveWordsPerThread];
+	u32 rank_all[kResolveWordsPerThread];
 #pragma unroll
 	for (int piece = 0; piece < kResolveWordsPerThread; ++piece) {
 		u32 const wi = w_first + piece * blockDim.x;
 		u32 const wc = wi < n_words ? wi : n_words - 1;     // clamped: every load is issued, none sits under a branch
 		w_all[piece] = row_words ? row_words[wc] : 0;
 		ovl_all[piece] = overlappable[wc];
+		rank_all[piece] = ovl_rank[wc];
+		if (wi == n_words - 1) w_all[piece] &= tail_mask;
+	}
+	// second round, again for all words at once: the blocker mask of each word's first set overlappable edge (entry 0 of
+	// the table where there is none; the table is never empty)
+#pragma unroll
+	for (int piece = 0; piece < kResolveWordsPerThread; ++piece) {
+		u64 const ov = w_all[piece] & ovl_all[piece];
+		u32 const first = ov ? rank_all[piece] + (u32) __builtin_popcountll(ovl_all[piece] & ((1ULL << __builtin_ctzll(ov)) - 1)) : 0u;
+		mask_all[piece] = blocker_masks[first];
 	}
 #pragma unroll
 	for (int piece = 0; piece < kResolveWordsPerThread; ++piece) {
 		u32 const wi = w_first + piece * blockDim.x;
 		if (wi >= n_words) return;                           // pieces are consecutive: nothing further either
 
-		u64 w = w_all[piece];
-		if (wi == n_words - 1) w &= tail_mask;
+		u64 const w = w_all[piece];
 		u64 const ovl_w = ovl_all[piece];
 		u64 ov = w & ovl_w;
 		u64 out = w;
@@ -635,12 +645,10 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 			// An overlappable edge none of whose possible blockers is set in this row is effective without any replay (the
 			// masks are per graph: the edges of this word that end past its source node; all ones when an earlier word holds
 			// one).  On config 5's graph a fifth of all words have a set overlappable edge and 1-2 % need the replay.
-			u32 const rank0 = ovl_rank[wi];
-			bool blocked = false;
-			for (u64 m = ov; m; m &= m - 1) {
+			bool blocked = 0 != (w & mask_all[piece]);           // the first set overlappable edge: fetched above
+			for (u64 m = ov & (ov - 1); m && !blocked; m &= m - 1) {   // further ones are rare
 				int const b = __builtin_ctzll(m);
-				u64 const mask = blocker_masks[rank0 + (u32) __builtin_popcountll(ovl_w & ((1ULL << b) - 1))];
-				blocked = blocked || 0 != (w & mask);
+				blocked = 0 != (w & blocker_masks[rank_all[piece] + (u32) __builtin_popcountll(ovl_w & ((1ULL << b) - 1))]);
 			}
 			if (!blocked) ov = 0;
 		}
