@@ -586,25 +586,83 @@ __global__ __launch_bounds__(256) void assemble_row_bits_kernel(
 constexpr int kResolveWordsPerThread = 8;
 constexpr u32 kMaxBackWords = 2048;   // default max_back_words: restart points > 131072 edges back go to the serial kernel
 
+// The exact rule for one (row, word): restart at the nearest earlier edge that is NOT overlappable (set or not: when the
+// walk reaches such an edge every earlier target is <= its source node, so the scan state there is equivalent to
+// cur = 0; the search runs over the graph-static mask only) and replay the row's set edges from there to the end of the word.
+__device__ __forceinline__ u64 resolve_word_exact(
+	u64 const *__restrict__ paths, u64 words_per_copy, row_segments const &rs, u32 row, u32 s_begin, u32 s_end,
+	edge_span const *__restrict__ spans, u64 const *__restrict__ overlappable,
+	u32 wi, u64 w, u64 ovl_w, u32 *__restrict__ needs_serial, u32 max_back_words)
+{
+	u64 const ov = w & ovl_w;
+	if (0 == ov) return w;
+	int const b0 = __builtin_ctzll(ov);
+	u32 sw = wi;
+	int sb = 0;
+	u64 fixed = ~ovl_w & ((1ULL << b0) - 1);
+	if (fixed) {
+		sb = 63 - __builtin_clzll(fixed);
+	} else {
+		u32 steps = 0;
+		for (;;) {
+			if (0 == sw) { sb = 0; break; }              // edge 0 is never overlappable; defensive
+			--sw;
+			if (++steps > max_back_words) { atomicOr(&needs_serial[row], 1u); return w; }   // the row goes to resolve_rows_serial_kernel
+			fixed = ~overlappable[sw];
+			if (fixed) { sb = 63 - __builtin_clzll(fixed); break; }
+		}
+	}
+	u64 out = (sw == wi) ? (w & ((1ULL << sb) - 1)) : 0;   // set bits before the restart point in this word are certain
+	u32 cur = 0;
+	for (u32 ww = sw; ww <= wi; ++ww) {
+		u64 x = (ww == wi) ? w : load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, ww);
+		if (ww == sw) x &= ~((1ULL << sb) - 1);
+		// the rule is sequential, the loads it needs are not: the spans of the next (up to) 8 set edges are fetched together
+		while (x) {
+			constexpr int kBatch = 8;
+			edge_span sp[kBatch];
+			int bit[kBatch];
+			bool has[kBatch];
+#pragma unroll
+			for (int k = 0; k < kBatch; ++k) {
+				has[k] = 0 != x;
+				bit[k] = has[k] ? __builtin_ctzll(x) : 0;
+				x &= x - 1;                                        // stays 0 once it is 0
+				sp[k] = spans[ww * 64u + bit[k]];                  // always a valid edge of this word (its first one when the batch has run out)
+			}
+#pragma unroll
+			for (int k = 0; k < kBatch; ++k) {
+				if (has[k] && sp[k].src >= cur) {
+					cur = sp[k].tgt;
+					if (ww == wi) out |= 1ULL << bit[k];
+				}
+			}
+		}
+	}
+	return out;
+}
+
+// Pass 1, streaming.  grid: x over rows, y over pieces of kResolveWordsPerThread x 256 consecutive words of a row (the
+// row, and with it the segment table lookups, is uniform per workgroup).  Every load of the common path is issued before
+// any result is looked at, in two rounds: the row's words with the static masks and ranks, then the blocker masks of
+// each word's first two set overlappable edges.  A word is decided here when it has no set overlappable edge, or at most
+// two and none of their possible blockers is set (then all its set edges are effective).  Everything else -- a possible
+// blocker is set, or three and more overlappable edges are -- needs dependent loads, and ONE lane that takes them holds
+// its whole wave up for microseconds: on config 5's graph nearly every wave has such a lane, which is what this kernel's
+// time was made of (240 us per 251-row batch whether it handled 1 or 8 words per thread, replayed or looked masks up,
+// against 70 us for a plain copy of the same words).  Those words are appended to a queue instead (one atomic per wave)
+// and decided by resolve_queued_words_kernel, where 64 of them share a wave.
 __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
 	row_segments rs, edge_span const *__restrict__ spans, u64 const *__restrict__ overlappable,
 	u32 const *__restrict__ ovl_rank, u64 const *__restrict__ blocker_masks,
-	u64 *__restrict__ eff, u32 n_words, u32 eff_words_per_row, u32 row_base, u32 piece_base, u32 *__restrict__ needs_serial, u32 max_back_words)
+	u64 *__restrict__ eff, u32 n_words, u32 eff_words_per_row, u32 row_base, u32 piece_base,
+	u32 *__restrict__ queue, u32 *__restrict__ queue_count, u32 queue_capacity, u32 *__restrict__ needs_serial, u32 max_back_words)
 {
-	// grid: x over rows, y over 256-word pieces of a row.  The row (and with it the segment table lookups below) is uniform
-	// per workgroup, so those loads are scalar and leave the per-lane path with the one coalesced word load.  Rows run
-	// fastest so that the workgroups in flight at any time work on the SAME few pieces of many rows: the replay path's
-	// scattered 8-byte reads of `spans` (a fifth of all words take it on config 5's graph) then hit lines another row's
-	// workgroup has just pulled into the L2, instead of streaming the 50-MB table once per row.
-	// A workgroup takes kResolveWordsPerThread x 256 consecutive words of its row: with one word per thread the grid of a
-	// config-5 batch was 95 000 workgroups of 2 KB each and the kernel was bound by workgroup dispatch, not by memory.
 	u32 const row = blockIdx.x + row_base;
 	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
 	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;   // padding bits are zero by contract; do not trust them
-	// All of the thread's words (and their masks) are requested before any is looked at: with one 8-byte load per lane in
-	// flight at a time the kernel ran at 2 TB/s whatever else was done to it (Little's law: 32 waves x 512 B per CU).
-	// Where the row's bits come from is uniform per workgroup: one chromosome copy, nothing (REF row), or the assembled row.
+	// where the row's bits come from: one chromosome copy, nothing (REF row), or the assembled row
 	u64 const *row_words = nullptr;
 	if (s_end - s_begin == 1) {
 		u32 const copy = rs.seg_copy[s_begin];
@@ -613,7 +671,7 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 		row_words = rs.assembled + (u64) row * rs.assembled_words;
 	}
 	u32 const w_first = (blockIdx.y + piece_base) * kResolveWordsPerThread * blockDim.x + threadIdx.x;
-	u64 w_all[kResolveWordsPerThread], ovl_all[kResolveWordsPerThread], mask_all[kResolveWordsPerThread];
+	u64 w_all[kResolveWordsPerThread], ovl_all[kResolveWordsPerThread], mask_a[kResolveWordsPerThread], mask_b[kResolveWordsPerThread];
 	u32 rank_all[kResolveWordsPerThread];
 #pragma unroll
 	for (int piece = 0; piece < kResolveWordsPerThread; ++piece) {
@@ -624,90 +682,53 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 		rank_all[piece] = ovl_rank[wc];
 		if (wi == n_words - 1) w_all[piece] &= tail_mask;
 	}
-	// second round, again for all words at once: the blocker mask of each word's first set overlappable edge (entry 0 of
-	// the table where there is none; the table is never empty)
 #pragma unroll
 	for (int piece = 0; piece < kResolveWordsPerThread; ++piece) {
-		u64 const ov = w_all[piece] & ovl_all[piece];
-		u32 const first = ov ? rank_all[piece] + (u32) __builtin_popcountll(ovl_all[piece] & ((1ULL << __builtin_ctzll(ov)) - 1)) : 0u;
-		mask_all[piece] = blocker_masks[first];
+		u64 const ov = w_all[piece] & ovl_all[piece], ov2 = ov & (ov - 1);
+		auto const entry = [&](u64 m) {                     // the table entry of the lowest set bit of m (entry 0 when m is empty)
+			return m ? rank_all[piece] + (u32) __builtin_popcountll(ovl_all[piece] & ((1ULL << __builtin_ctzll(m)) - 1)) : 0u;
+		};
+		mask_a[piece] = blocker_masks[entry(ov)];
+		mask_b[piece] = blocker_masks[entry(ov2)];
 	}
+	int const lane = threadIdx.x & 63;
 #pragma unroll
 	for (int piece = 0; piece < kResolveWordsPerThread; ++piece) {
 		u32 const wi = w_first + piece * blockDim.x;
-		if (wi >= n_words) return;                           // pieces are consecutive: nothing further either
+		bool const in_range = wi < n_words;
+		u64 const w = w_all[piece], ov = w & ovl_all[piece], ov2 = ov & (ov - 1);
+		bool const hard = in_range && ov && ((w & mask_a[piece]) || (ov2 && ((w & mask_b[piece]) || (ov2 & (ov2 - 1)))));
+		if (in_range && !hard) eff[(u64) row * eff_words_per_row + wi] = w;
+		u64 const hard_lanes = __ballot(hard);
+		if (hard_lanes) {                                    // wave-uniform
+			u32 base = 0;
+			if (0 == lane) base = atomicAdd(queue_count, (u32) __builtin_popcountll(hard_lanes));
+			base = __shfl(base, 0, kWave);
+			if (hard) {
+				u32 const slot = base + __builtin_amdgcn_mbcnt_hi((u32) (hard_lanes >> 32), __builtin_amdgcn_mbcnt_lo((u32) hard_lanes, 0));
+				if (slot < queue_capacity) queue[slot] = (row - row_base) * n_words + wi;   // (the host sizes the queue for every word of the launch)
+				else eff[(u64) row * eff_words_per_row + wi] = resolve_word_exact(paths, words_per_copy, rs, row, s_begin, s_end, spans, overlappable, wi, w, ovl_all[piece], needs_serial, max_back_words);
+			}
+		}
+	}
+}
 
-		u64 const w = w_all[piece];
-		u64 const ovl_w = ovl_all[piece];
-		u64 ov = w & ovl_w;
-		u64 out = w;
-		if (ov) {
-			// An overlappable edge none of whose possible blockers is set in this row is effective without any replay (the
-			// masks are per graph: the edges of this word that end past its source node; all ones when an earlier word holds
-			// one).  On config 5's graph a fifth of all words have a set overlappable edge and 1-2 % need the replay.
-			bool blocked = 0 != (w & mask_all[piece]);           // the first set overlappable edge: fetched above
-			for (u64 m = ov & (ov - 1); m && !blocked; m &= m - 1) {   // further ones are rare
-				int const b = __builtin_ctzll(m);
-				blocked = 0 != (w & blocker_masks[rank_all[piece] + (u32) __builtin_popcountll(ovl_w & ((1ULL << b) - 1))]);
-			}
-			if (!blocked) ov = 0;
-		}
-		if (ov) {
-			// Restart point: the nearest earlier edge that is NOT overlappable, set or not.  When the walk
-			// reaches such an edge every earlier target is <= its source node, so the scan state there is
-			// equivalent to cur = 0.  The search runs over the graph-static mask only.
-			int const b0 = __builtin_ctzll(ov);
-			u32 sw = wi;
-			int sb = 0;
-			bool ok = true;
-			u64 fixed = ~ovl_w & ((1ULL << b0) - 1);
-			if (fixed) {
-				sb = 63 - __builtin_clzll(fixed);
-			} else {
-				u32 steps = 0;
-				for (;;) {
-					if (0 == sw) { sb = 0; break; }              // edge 0 is never overlappable; defensive
-					--sw;
-					if (++steps > max_back_words) { ok = false; break; }
-					fixed = ~overlappable[sw];
-					if (fixed) { sb = 63 - __builtin_clzll(fixed); break; }
-				}
-			}
-			if (!ok) {
-				atomicOr(&needs_serial[row], 1u);
-			} else {
-				out = (sw == wi) ? (w & ((1ULL << sb) - 1)) : 0;   // set bits before the restart point in this word are certain
-				u32 cur = 0;
-				for (u32 ww = sw; ww <= wi; ++ww) {
-					u64 x = (ww == wi) ? w : load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, ww);
-					if (ww == sw) x &= ~((1ULL << sb) - 1);
-					// The rule itself is sequential, the loads it needs are not: the spans of the next (up to) 8 set edges are
-					// fetched together, then the rule runs over them in registers.  One dependent load per set edge made this
-					// kernel latency-bound on dense graphs (config 5: a fifth of all words come here, ~5.5 set edges each).
-					while (x) {
-						constexpr int kBatch = 8;
-						edge_span sp[kBatch];
-						int bit[kBatch];
-						bool has[kBatch];
-#pragma unroll
-						for (int k = 0; k < kBatch; ++k) {
-							has[k] = 0 != x;
-							bit[k] = has[k] ? __builtin_ctzll(x) : 0;
-							x &= x - 1;                                        // stays 0 once it is 0
-							sp[k] = spans[ww * 64u + bit[k]];                  // always a valid edge of this word (its first one when the batch has run out)
-						}
-#pragma unroll
-						for (int k = 0; k < kBatch; ++k) {
-							if (has[k] && sp[k].src >= cur) {
-								cur = sp[k].tgt;
-								if (ww == wi) out |= 1ULL << bit[k];
-							}
-						}
-					}
-				}
-			}
-		}
-		eff[(u64) row * eff_words_per_row + wi] = out;
+// Pass 2, dense: one thread per queued (row, word).
+__global__ __launch_bounds__(256) void resolve_queued_words_kernel(
+	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
+	row_segments rs, edge_span const *__restrict__ spans, u64 const *__restrict__ overlappable,
+	u64 *__restrict__ eff, u32 n_words, u32 eff_words_per_row, u32 row_base,
+	u32 const *__restrict__ queue, u32 const *__restrict__ queue_count, u32 queue_capacity, u32 *__restrict__ needs_serial, u32 max_back_words)
+{
+	u32 const n = *queue_count < queue_capacity ? *queue_count : queue_capacity;
+	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;
+	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+		u32 const entry = queue[i];
+		u32 const row = row_base + entry / n_words, wi = entry % n_words;
+		u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
+		u64 w = load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, wi);
+		if (wi == n_words - 1) w &= tail_mask;
+		eff[(u64) row * eff_words_per_row + wi] = resolve_word_exact(paths, words_per_copy, rs, row, s_begin, s_end, spans, overlappable, wi, w, overlappable[wi], needs_serial, max_back_words);
 	}
 }
 
