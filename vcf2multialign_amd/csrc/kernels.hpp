@@ -584,6 +584,7 @@ __global__ __launch_bounds__(256) void assemble_row_bits_kernel(
 }
 
 constexpr int kResolveWordsPerThread = 8;
+constexpr u32 kResolveQueueShards = 1024;
 constexpr u32 kMaxBackWords = 2048;   // default max_back_words: restart points > 131072 edges back go to the serial kernel
 
 // The exact rule for one (row, word): restart at the nearest earlier edge that is NOT overlappable (set or not: when the
@@ -650,16 +651,19 @@ __device__ __forceinline__ u64 resolve_word_exact(
 // blocker is set, or three and more overlappable edges are -- needs dependent loads, and ONE lane that takes them holds
 // its whole wave up for microseconds: on config 5's graph nearly every wave has such a lane, which is what this kernel's
 // time was made of (240 us per 251-row batch whether it handled 1 or 8 words per thread, replayed or looked masks up,
-// against 70 us for a plain copy of the same words).  Those words are appended to a queue instead (one atomic per wave)
-// and decided by resolve_queued_words_kernel, where 64 of them share a wave.
+// against 70 us for a plain copy of the same words).  Those words are appended to a queue instead and decided by
+// resolve_queued_words_kernel, where 64 of them share a wave.  The queue is cut into kResolveQueueShards segments with a
+// counter each, a workgroup appends to the segment its index picks, one atomic per wave: a single counter would take
+// every wave's atomic in turn (~88 per microsecond) and cost more than the kernel.
 __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
 	row_segments rs, edge_span const *__restrict__ spans, u64 const *__restrict__ overlappable,
 	u32 const *__restrict__ ovl_rank, u64 const *__restrict__ blocker_masks,
 	u64 *__restrict__ eff, u32 n_words, u32 eff_words_per_row, u32 row_base, u32 piece_base,
-	u32 *__restrict__ queue, u32 *__restrict__ queue_count, u32 queue_capacity, u32 *__restrict__ needs_serial, u32 max_back_words)
+	u32 *__restrict__ queue, u32 *__restrict__ queue_counts /* [kResolveQueueShards] */, u32 shard_capacity, u32 *__restrict__ needs_serial, u32 max_back_words)
 {
 	u32 const row = blockIdx.x + row_base;
+	u32 const shard = (blockIdx.y * gridDim.x + blockIdx.x) % kResolveQueueShards;
 	u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
 	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;   // padding bits are zero by contract; do not trust them
 	// where the row's bits come from: one chromosome copy, nothing (REF row), or the assembled row
@@ -702,28 +706,29 @@ __global__ __launch_bounds__(256) void resolve_effective_edges_kernel(
 		u64 const hard_lanes = __ballot(hard);
 		if (hard_lanes) {                                    // wave-uniform
 			u32 base = 0;
-			if (0 == lane) base = atomicAdd(queue_count, (u32) __builtin_popcountll(hard_lanes));
+			if (0 == lane) base = atomicAdd(&queue_counts[shard], (u32) __builtin_popcountll(hard_lanes));
 			base = __shfl(base, 0, kWave);
 			if (hard) {
 				u32 const slot = base + __builtin_amdgcn_mbcnt_hi((u32) (hard_lanes >> 32), __builtin_amdgcn_mbcnt_lo((u32) hard_lanes, 0));
-				if (slot < queue_capacity) queue[slot] = (row - row_base) * n_words + wi;   // (the host sizes the queue for every word of the launch)
+				if (slot < shard_capacity) queue[(u64) shard * shard_capacity + slot] = (row - row_base) * n_words + wi;
 				else eff[(u64) row * eff_words_per_row + wi] = resolve_word_exact(paths, words_per_copy, rs, row, s_begin, s_end, spans, overlappable, wi, w, ovl_all[piece], needs_serial, max_back_words);
 			}
 		}
 	}
 }
 
-// Pass 2, dense: one thread per queued (row, word).
+// Pass 2, dense: one thread per queued (row, word); workgroup b works on segment b % kResolveQueueShards.
 __global__ __launch_bounds__(256) void resolve_queued_words_kernel(
 	u64 const *__restrict__ paths, u64 words_per_copy, u32 n_edges,
 	row_segments rs, edge_span const *__restrict__ spans, u64 const *__restrict__ overlappable,
 	u64 *__restrict__ eff, u32 n_words, u32 eff_words_per_row, u32 row_base,
-	u32 const *__restrict__ queue, u32 const *__restrict__ queue_count, u32 queue_capacity, u32 *__restrict__ needs_serial, u32 max_back_words)
+	u32 const *__restrict__ queue, u32 const *__restrict__ queue_counts, u32 shard_capacity, u32 *__restrict__ needs_serial, u32 max_back_words)
 {
-	u32 const n = *queue_count < queue_capacity ? *queue_count : queue_capacity;
+	u32 const shard = blockIdx.x % kResolveQueueShards, part = blockIdx.x / kResolveQueueShards, parts = gridDim.x / kResolveQueueShards;
+	u32 const n = queue_counts[shard] < shard_capacity ? queue_counts[shard] : shard_capacity;
 	u64 const tail_mask = (n_edges & 63) ? (1ULL << (n_edges & 63)) - 1 : ~0ULL;
-	for (u32 i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-		u32 const entry = queue[i];
+	for (u32 i = part * blockDim.x + threadIdx.x; i < n; i += parts * blockDim.x) {
+		u32 const entry = queue[(u64) shard * shard_capacity + i];
 		u32 const row = row_base + entry / n_words, wi = entry % n_words;
 		u32 const s_begin = rs.seg_offsets[row], s_end = rs.seg_offsets[row + 1];
 		u64 w = load_row_word(paths, words_per_copy, rs, row, s_begin, s_end, wi);

@@ -516,22 +516,22 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 				for (u64 y0(0); y0 < nr; y0 += 65535)   // grid.y limit
 					hipLaunchKernelGGL(v2m::assemble_row_bits_kernel, dim3(unsigned((n_words + 255) / 256), unsigned(std::min<u64>(65535, nr - y0))), dim3(256), 0, ctx->stream,
 						ctx->d_paths, ctx->path_pitch, rs, ctx->d_row_bits.as<u64>(), u32(n_words), u32(r0 + y0));
-			// the queue holds every word of the launch if it has to (iid random bits do that), up to 1 GiB; past that the
-			// streaming pass decides the overflow itself
-			u64 const capacity(std::min<u64>(nr * n_words, u64(1) << 28));
-			V2M_HIP_TRY(ctx, ctx->d_resolve_queue.ensure(capacity * sizeof(u32)));
-			V2M_HIP_TRY(ctx, ctx->d_resolve_count.ensure(16));
-			V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_resolve_count.p, 0, sizeof(u32), ctx->stream));
+			// the queue's segments hold every word of the launch if they have to (iid random bits do that), up to 1 GiB in all;
+			// a workgroup whose segment is full decides its overflow itself
+			u64 const shard_capacity(std::max<u64>(256, std::min<u64>(nr * n_words, u64(1) << 28) / v2m::kResolveQueueShards));
+			V2M_HIP_TRY(ctx, ctx->d_resolve_queue.ensure(shard_capacity * v2m::kResolveQueueShards * sizeof(u32)));
+			V2M_HIP_TRY(ctx, ctx->d_resolve_count.ensure(v2m::kResolveQueueShards * sizeof(u32)));
+			V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_resolve_count.p, 0, v2m::kResolveQueueShards * sizeof(u32), ctx->stream));
 			for (u64 piece0(0), pieces((n_words + 256 * v2m::kResolveWordsPerThread - 1) / (256 * v2m::kResolveWordsPerThread)); piece0 < pieces; piece0 += 65535)   // grid.y limit; rows run fastest
 				hipLaunchKernelGGL(v2m::resolve_effective_edges_kernel, dim3(unsigned(nr), unsigned(std::min<u64>(65535, pieces - piece0))), dim3(256), 0, ctx->stream,
 					ctx->d_paths, ctx->path_pitch, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
 					ctx->d_ovl_rank.as<u32>(), ctx->d_blocker_masks.as<u64>(),
 					ctx->d_eff.as<u64>(), u32(n_words), u32(eff_words), u32(r0), u32(piece0),
-					ctx->d_resolve_queue.as<u32>(), ctx->d_resolve_count.as<u32>(), u32(capacity), ctx->d_needs_serial.as<u32>(), max_back_words);
-			hipLaunchKernelGGL(v2m::resolve_queued_words_kernel, dim3(unsigned(std::min<u64>(2048, (capacity + 255) / 256))), dim3(256), 0, ctx->stream,
+					ctx->d_resolve_queue.as<u32>(), ctx->d_resolve_count.as<u32>(), u32(shard_capacity), ctx->d_needs_serial.as<u32>(), max_back_words);
+			hipLaunchKernelGGL(v2m::resolve_queued_words_kernel, dim3(2 * v2m::kResolveQueueShards), dim3(256), 0, ctx->stream,
 				ctx->d_paths, ctx->path_pitch, u32(ctx->n_edges), rs, ctx->d_spans.as<v2m::edge_span>(), ctx->d_overlappable.as<u64>(),
 				ctx->d_eff.as<u64>(), u32(n_words), u32(eff_words), u32(r0),
-				ctx->d_resolve_queue.as<u32>(), ctx->d_resolve_count.as<u32>(), u32(capacity), ctx->d_needs_serial.as<u32>(), max_back_words);
+				ctx->d_resolve_queue.as<u32>(), ctx->d_resolve_count.as<u32>(), u32(shard_capacity), ctx->d_needs_serial.as<u32>(), max_back_words);
 		}
 		// rows whose restart point is too far back for the per-word kernel (chromosome-scale deletions)
 		hipLaunchKernelGGL(v2m::resolve_rows_serial_kernel, dim3(unsigned((n_rows + 3) / 4)), dim3(256), 0, ctx->stream,
