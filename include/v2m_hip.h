@@ -199,8 +199,9 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
  * the row's end and the next multiple of 16 are clobbered.  Unaligned mode: row_pitch must be >= the longest row
  * (reference length + total label bytes is always enough; see v2m_max_unaligned_length()).
  * row_lengths_out (host, optional, [n_rows]) receives each row's length.
- * The call returns once the kernels are QUEUED on the ctx's stream, after a host-side wait for the upload of the
- * batch's (small) row tables; the first >= 1 GiB launch of a ctx also times both store flavours, synchronously.
+ * The call returns once the kernels are QUEUED on the ctx's stream (the batch's small row tables travel through two
+ * pinned staging areas used in turn, so consecutive calls do not wait for each other's kernels); the first >= 1 GiB
+ * launch of a ctx also times both store flavours, synchronously.
  * With row_lengths_out in unaligned mode the call waits for the kernels.  Use v2m_ctx_synchronize() before reading d_out. */
 int v2m_splice_rows_device(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, void *d_out, uint64_t row_pitch, uint64_t *row_lengths_out);
 

@@ -107,7 +107,12 @@ struct v2m_ctx {
 	std::string info;
 
 	// per-call scratch
-	pinned_buf h_row_stage;   // segment tables of the row batch being resolved
+	// segment tables of the row batch being resolved: two pinned staging areas used in turn, so that the host can prepare and
+	// queue the next slice while the previous one is still running (each area is reused only after its uploads have left it)
+	pinned_buf h_row_stage[2];
+	hipEvent_t ev_row_stage[2]{};
+	bool row_stage_in_flight[2]{};
+	int row_stage_next{};
 	dev_buf d_resolve_queue, d_resolve_count;   // (row, word) pairs the streaming resolve pass leaves to the dense one
 	dev_buf d_eff, d_row_bits, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial, d_tile_counts, d_row_lengths;
 	dev_buf ring[2];
@@ -400,8 +405,13 @@ int prepare_rows(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row
 	if (max_segments >= 0xFFFFFFFFull)
 		return fail(ctx, V2M_ERR_UNSUPPORTED, "row batch has too many cut segments (%llu) for one call", (unsigned long long) max_segments);
 	auto const pad([](u64 n) { return (n * sizeof(u32) + 63) & ~u64(63); });
-	V2M_HIP_TRY(ctx, ctx->h_row_stage.ensure(pad(n_rows + 1) + 2 * pad(max_segments)));
-	char *const base(static_cast<char *>(ctx->h_row_stage.p));
+	int const area(ctx->row_stage_next);
+	if (ctx->row_stage_in_flight[area]) {
+		V2M_HIP_TRY(ctx, hipEventSynchronize(ctx->ev_row_stage[area]));   // the uploads of two slices ago
+		ctx->row_stage_in_flight[area] = false;
+	}
+	V2M_HIP_TRY(ctx, ctx->h_row_stage[area].ensure(pad(n_rows + 1) + 2 * pad(max_segments)));
+	char *const base(static_cast<char *>(ctx->h_row_stage[area].p));
 	out.seg_offsets = reinterpret_cast<u32 *>(base);
 	out.seg_edge_begin = reinterpret_cast<u32 *>(base + pad(n_rows + 1));
 	out.seg_copy = reinterpret_cast<u32 *>(base + pad(n_rows + 1) + pad(max_segments));
@@ -492,8 +502,10 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 	if (int const rc = upload(ctx->d_seg_offsets, pr.seg_offsets, n_rows + 1)) return rc;
 	if (int const rc = upload(ctx->d_seg_edge_begin, pr.seg_edge_begin, pr.n_segments)) return rc;
 	if (int const rc = upload(ctx->d_seg_copy, pr.seg_copy, pr.n_segments)) return rc;
-	// the staging area is reused by the next call
-	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	// the staging area the tables came from is free again once these copies have run; the other one takes the next slice
+	V2M_HIP_TRY(ctx, hipEventRecord(ctx->ev_row_stage[ctx->row_stage_next], ctx->stream));
+	ctx->row_stage_in_flight[ctx->row_stage_next] = true;
+	ctx->row_stage_next ^= 1;
 	V2M_HIP_TRY(ctx, ctx->d_eff.ensure(n_rows * eff_words * sizeof(u64)));
 	V2M_HIP_TRY(ctx, ctx->d_needs_serial.ensure(n_rows * sizeof(u32)));
 	V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_needs_serial.p, 0, n_rows * sizeof(u32), ctx->stream));
@@ -769,6 +781,7 @@ int v2m_ctx_create(int device_id, v2m_ctx **ctx_out)
 	for (int i(0); i < 2 && hipSuccess == st; ++i) {
 		st = hipEventCreateWithFlags(&ctx->ev_compute[i], hipEventDisableTiming);
 		if (hipSuccess == st) st = hipEventCreateWithFlags(&ctx->ev_copy[i], hipEventDisableTiming);
+		if (hipSuccess == st) st = hipEventCreateWithFlags(&ctx->ev_row_stage[i], hipEventDisableTiming);
 	}
 	if (hipSuccess != st) {
 		std::string const what(hipGetErrorString(st));
@@ -790,6 +803,7 @@ void v2m_ctx_destroy(v2m_ctx *ctx)
 	for (int i(0); i < 2; ++i) {
 		if (ctx->ev_compute[i]) (void) hipEventDestroy(ctx->ev_compute[i]);
 		if (ctx->ev_copy[i]) (void) hipEventDestroy(ctx->ev_copy[i]);
+		if (ctx->ev_row_stage[i]) (void) hipEventDestroy(ctx->ev_row_stage[i]);
 	}
 	(void) hipStreamDestroy(ctx->stream);
 	(void) hipStreamDestroy(ctx->copy_stream);
