@@ -950,48 +950,73 @@ struct tile_patch {
 };
 
 // Calls f(tile_patch) for every candidate edge of the tile that is effective in the row, each candidate on one thread.
+// Candidate i of the tile (crossing edges first, then the range that begins in it): its edge index and whether the
+// cached LDS copies (patch descriptor, effective-edge words) cover it.
+__device__ __forceinline__ u32 candidate_edge(tile_job const &job, tile_tables const &tt, u32 i)
+{
+	return (i < job.n_cross) ? tt.cross_edges[job.cross_begin + i] : job.range_begin + (i - job.n_cross);
+}
+
+__device__ __forceinline__ bool candidate_in_lds(tile_job const &job, u32 i)
+{
+	return i >= job.n_cross && i - job.n_cross < job.n_lds;
+}
+
+// The part of candidate i's span that falls into the tile, from the cached descriptor when it is representable there.
+__device__ __forceinline__ tile_patch candidate_patch(
+	patch_cache const &pc, tile_job const &job, edge_patch const *__restrict__ patches, u32 i, u32 e, bool cached)
+{
+	u32 const tile_end = job.tile_base + kTileBytes;
+	cached_patch c{};
+	if (cached) {
+		c = pc.patch[i - job.n_cross];
+		cached = c.span != 0xFFFF && c.label_rel != 0xFFFF;
+	}
+	tile_patch tp;
+	tp.edge = e;
+	if (cached) {
+		tp.aln_begin = tp.from = job.tile_base + c.begin_rel;
+		tp.to = tp.from + c.span < tile_end ? tp.from + c.span : tile_end;
+		tp.label_len = c.label_len;
+		tp.label_begin = c.label_rel;
+		tp.in_lds = true;
+	} else {
+		edge_patch const p = patches[e];
+		tp.aln_begin = p.aln_begin;
+		tp.from = p.aln_begin > job.tile_base ? p.aln_begin : job.tile_base;
+		tp.to = p.aln_end < tile_end ? p.aln_end : tile_end;
+		tp.label_len = p.label_len;
+		tp.label_begin = p.label_begin;
+		tp.in_lds = false;
+	}
+	return tp;
+}
+
+// Whether candidate i is effective for the row (local_row = its index within the rows whose words are cached).
+__device__ __forceinline__ bool candidate_effective(
+	patch_cache const &pc, tile_job const &job, tile_tables const &tt, u64 const *__restrict__ eff_row, u32 local_row, u32 i,
+	u32 &e, bool &cached)
+{
+	cached = candidate_in_lds(job, i) && local_row < (u32) kGroupRowsLds;
+	if (cached) {
+		e = job.range_begin + (i - job.n_cross);
+		return (pc.eff[local_row][(e >> 6) - job.w0] >> (e & 63)) & 1;
+	}
+	e = candidate_edge(job, tt, i);
+	return (eff_row[e >> 6] >> (e & 63)) & 1;
+}
+
 template <typename F>
 __device__ __forceinline__ void for_each_effective_candidate(
 	patch_cache const &pc, tile_job const &job, tile_tables const &tt, edge_patch const *__restrict__ patches,
 	u64 const *__restrict__ eff_row, u32 local_row, int t, F &&f)
 {
 	u32 const n_cand = job.n_cross + job.n_range;
-	u32 const tile_end = job.tile_base + kTileBytes;
 	for (u32 i = t; i < n_cand; i += kSpliceThreads) {
-		bool cached = i >= job.n_cross && i - job.n_cross < job.n_lds && local_row < (u32) kGroupRowsLds;
 		u32 e;
-		bool set;
-		if (cached) {
-			e = job.range_begin + (i - job.n_cross);
-			set = (pc.eff[local_row][(e >> 6) - job.w0] >> (e & 63)) & 1;
-		} else {
-			e = (i < job.n_cross) ? tt.cross_edges[job.cross_begin + i] : job.range_begin + (i - job.n_cross);
-			set = (eff_row[e >> 6] >> (e & 63)) & 1;
-		}
-		if (!set) continue;
-		cached_patch c{};
-		if (cached) {
-			c = pc.patch[i - job.n_cross];
-			cached = c.span != 0xFFFF && c.label_rel != 0xFFFF;
-		}
-		tile_patch tp;
-		tp.edge = e;
-		if (cached) {
-			tp.aln_begin = tp.from = job.tile_base + c.begin_rel;
-			tp.to = tp.from + c.span < tile_end ? tp.from + c.span : tile_end;
-			tp.label_len = c.label_len;
-			tp.label_begin = c.label_rel;
-			tp.in_lds = true;
-		} else {
-			edge_patch const p = patches[e];
-			tp.aln_begin = p.aln_begin;
-			tp.from = p.aln_begin > job.tile_base ? p.aln_begin : job.tile_base;
-			tp.to = p.aln_end < tile_end ? p.aln_end : tile_end;
-			tp.label_len = p.label_len;
-			tp.label_begin = p.label_begin;
-			tp.in_lds = false;
-		}
-		f(tp);
+		bool cached;
+		if (!candidate_effective(pc, job, tt, eff_row, local_row, i, e, cached)) continue;
+		f(candidate_patch(pc, job, patches, i, e, cached));
 	}
 }
 
@@ -1142,6 +1167,7 @@ __device__ __forceinline__ u32 count_nonzero_bytes(unsigned char const *tile, u3
 }
 
 constexpr int kCountRowsMax = 256;   // rows per group the count kernel can hold (host clamps rows_per_group)
+constexpr int kCandDeltaLds = 1024;  // candidates per tile whose (row-independent) count change is kept in LDS
 
 __global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
 	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
@@ -1152,6 +1178,7 @@ __global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
 	__shared__ vec4u lds[kTileChunks];        // the pristine template tile, shared by all rows of the group
 	__shared__ patch_cache pc;
 	__shared__ int row_delta[kCountRowsMax];
+	__shared__ int cand_delta[kCandDeltaLds];
 	__shared__ u32 wave_sums[kSpliceThreads / 64];
 
 	int const t = threadIdx.x;
@@ -1182,23 +1209,57 @@ __global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
 	for (int wv = 0; wv < kSpliceThreads / 64; ++wv) tile_count += wave_sums[wv];
 
 	unsigned char const *const tile_bytes = (unsigned char const *) lds;
+	// What an edge changes in the tile's count does not depend on the row (the effective edges of a row have disjoint
+	// spans): label bytes it puts into the tile minus template bytes its span removes.  Computed once per candidate
+	// here, so that the row loop is one LDS read per effective edge.
+	auto patch_delta = [&](tile_patch const &tp) {
+		u32 const label_end = tp.aln_begin + tp.label_len;
+		int const label_in_tile = label_end > tp.from ? (int) ((label_end < tp.to ? label_end : tp.to) - tp.from) : 0;
+		return label_in_tile - (int) count_nonzero_bytes(tile_bytes, tp.from - job.tile_base, tp.to - job.tile_base);
+	};
+	u32 const n_cand = job.n_cross + job.n_range;
+	for (u32 i = t; i < n_cand && i < (u32) kCandDeltaLds; i += kSpliceThreads)
+		cand_delta[i] = patch_delta(candidate_patch(pc, job, patches, i, candidate_edge(job, tt, i), candidate_in_lds(job, i)));
+	__syncthreads();
 	// The group may hold more rows than the LDS cache of effective-edge words (kGroupRowsLds): the template tile, its count
-	// and the patch descriptors are loaded once per group, the cached words are reloaded every kGroupRowsLds rows.
+	// and the per-candidate changes are set up once per group, the cached words are reloaded every kGroupRowsLds rows.
 	for (u32 sub = row_begin; sub < row_end; sub += kGroupRowsLds) {
 		u32 const sub_end = sub + kGroupRowsLds < row_end ? sub + kGroupRowsLds : row_end;
 		if (sub != row_begin) {
+			// (explicit wait: hipcc leaves it out at this loop header -- harmless here, the only LDS operations possibly in
+			// flight are the row_delta atomics, but tests/test_kernel_isa.py holds every barrier to the same rule)
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 			__syncthreads();                                     // everyone is done with the previous rows' words
 			load_eff_cache(pc, job, eff, eff_words_per_row, sub, sub_end - sub, t);
 			__syncthreads();
 		}
-		for (u32 row = sub; row < sub_end; ++row) {
+		u32 const sub_rows = sub_end - sub;
+		// Candidates whose effective-edge words are in LDS: one thread per (row, word), walking the set bits only.
+		u32 const nw = job.n_lds ? ((job.range_begin + job.n_lds - 1) >> 6) - job.w0 + 1 : 0;
+		for (u32 idx = t; idx < sub_rows * nw; idx += kSpliceThreads) {
+			u32 const r = idx / nw, w = idx % nw;
+			u32 const first = (job.w0 + w) * 64u;                 // edge of bit 0 of this word
+			u64 bits = pc.eff[r][w];
+			if (first < job.range_begin) bits &= ~0ULL << (job.range_begin - first);
+			u32 const cached_end = job.range_begin + job.n_lds;
+			if (cached_end < first + 64u) bits &= (1ULL << (cached_end - first)) - 1;
 			int delta = 0;
-			for_each_effective_candidate(pc, job, tt, patches, eff + (u64) row * eff_words_per_row, row - sub, t, [&](tile_patch const &tp) {
-				u32 const label_end = tp.aln_begin + tp.label_len;
-				int const label_in_tile = label_end > tp.from ? (int) ((label_end < tp.to ? label_end : tp.to) - tp.from) : 0;
-				delta += label_in_tile - (int) count_nonzero_bytes(tile_bytes, tp.from - job.tile_base, tp.to - job.tile_base);
-			});
-			if (delta) atomicAdd(&row_delta[row - row_begin], delta);
+			for (; bits; bits &= bits - 1) {
+				u32 const e = first + (u32) __builtin_ctzll(bits);
+				u32 const i = job.n_cross + (e - job.range_begin);
+				delta += i < (u32) kCandDeltaLds ? cand_delta[i] : patch_delta(candidate_patch(pc, job, patches, i, e, true));
+			}
+			if (delta) atomicAdd(&row_delta[sub - row_begin + r], delta);
+		}
+		// The others (edges crossing into the tile from the left, candidates beyond the cache): one thread per (row, candidate).
+		u32 const n_other = n_cand - job.n_lds;
+		for (u32 idx = t; idx < sub_rows * n_other; idx += kSpliceThreads) {
+			u32 const r = idx / n_other, j = idx % n_other;
+			u32 const i = j < job.n_cross ? j : j + job.n_lds;
+			u32 const e = candidate_edge(job, tt, i);
+			if (!((eff[(u64) (sub + r) * eff_words_per_row + (e >> 6)] >> (e & 63)) & 1)) continue;
+			int const delta = i < (u32) kCandDeltaLds ? cand_delta[i] : patch_delta(candidate_patch(pc, job, patches, i, e, false));
+			if (delta) atomicAdd(&row_delta[sub - row_begin + r], delta);
 		}
 	}
 	__syncthreads();
