@@ -1267,6 +1267,20 @@ __global__ __launch_bounds__(kSpliceThreads) void count_unaligned_kernel(
 		tile_counts[(u64) (row_begin + r) * n_tiles + tile] = (u32) ((int) tile_count + row_delta[r]);
 }
 
+// v_perm_b32 selector that moves the bytes of a dword named by the 4-bit mask `keep` to its low end, in order (0x0c = a
+// zero byte): entry `keep` of the 16-entry LDS table the stream-out kernel compacts padded chunks with.
+__device__ __forceinline__ u32 compaction_selector(u32 keep)
+{
+	u32 sel = 0x0c0c0c0cu, n = 0;
+	for (u32 b = 0; b < 4; ++b)
+		if (keep >> b & 1) { sel = (sel & ~(0xFFu << (8 * n))) | (b << (8 * n)); ++n; }
+	return sel;
+}
+
+typedef unsigned short u16;
+typedef u16 u16_unaligned __attribute__((aligned(1)));
+typedef u32 u32_unaligned __attribute__((aligned(1)));
+typedef u64 u64_unaligned __attribute__((aligned(1)));
 typedef vec4u vec4u_unaligned __attribute__((aligned(1)));   // 16-B access at any byte address (gfx950 / HSA unaligned access mode; tools/unaligned_store_test.hip)
 
 template <bool kNonTemporal>
@@ -1279,9 +1293,11 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	__shared__ vec4u lds[kTileChunks];
 	__shared__ patch_cache pc;
 	__shared__ u32 wave_sums[kChunksPerThread][kSpliceThreads / 64];
+	__shared__ u32 compact_sel[16];
 
 	int const t = threadIdx.x;
 	int const lane = t & 63, wave = t >> 6;
+	if (t < 16) compact_sel[t] = compaction_selector((u32) t);   // first read follows the row loop's barriers
 	u32 tile, group;
 	map_block(blockIdx.x, n_groups, n_tiles, tile_run, tile, group);
 	u32 const row_begin = group * rows_per_group;
@@ -1341,16 +1357,30 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 				if (kNonTemporal) __builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));
 				else *(vec4u_unaligned *) (dst + off) = v[k];
 			} else if (cnt[k]) {
-				// (few chunks hold padding -- 1.6 % at config 3 -- and parking them in LDS for the whole wave to store, one byte
-				// per lane, was 10 % slower than this predicated per-lane loop: profiles/r02/unaligned_byte_path_ab.txt)
-				u32 p = off;
+				// A chunk with padding: its surviving bytes are packed to the low end of a 16-B value in registers (per
+				// dword with v_perm_b32 and the selector table, then the four pieces are shifted together) and go out as
+				// at most one store each of 8, 4, 2 and 1 bytes.  One store per byte (up to 16 predicated store
+				// instructions for the whole wave whenever any lane holds such a chunk -- 64 % of the time at config 3,
+				// always at config 5) is what made this kernel 15 % / 60 % slower than the aligned one.
+				u32 piece[4], len[4];
 #pragma unroll
-				for (int d = 0; d < 4; ++d)
-#pragma unroll
-					for (int bb = 0; bb < 4; ++bb) {
-						unsigned char const ch = (unsigned char) (v[k][d] >> (8 * bb));
-						if (ch) dst[p++] = (char) ch;
-					}
+				for (int d = 0; d < 4; ++d) {
+					u32 const keep = ~zero_bytes_mask(v[k][d]) & 0x80808080u;          // 0x80 per surviving byte
+					u32 const m = (((keep >> 7) * 0x01020408u) >> 24) & 0xFu;          // ... gathered into 4 bits
+					piece[d] = __builtin_amdgcn_perm(0u, v[k][d], compact_sel[m]);
+					len[d] = (u32) __builtin_popcount(m);
+				}
+				u64 const lo = (u64) piece[0] | ((u64) piece[1] << (8 * len[0]));
+				u64 const hi = (u64) piece[2] | ((u64) piece[3] << (8 * len[2]));
+				u32 const s = 8 * (len[0] + len[1]);                                   // 0 ... 64
+				u64 const packed_lo = lo | (s < 64 ? hi << s : 0);
+				u64 const packed_hi = 0 == s ? 0 : (64 == s ? hi : hi >> (64 - s));
+				char *p = dst + off;
+				u64 rest = packed_lo;
+				if (cnt[k] & 8) { *(u64_unaligned *) p = packed_lo; p += 8; rest = packed_hi; }
+				if (cnt[k] & 4) { *(u32_unaligned *) p = (u32) rest; p += 4; rest >>= 32; }
+				if (cnt[k] & 2) { *(u16_unaligned *) p = (u16) rest; p += 2; rest >>= 16; }
+				if (cnt[k] & 1) *p = (char) rest;
 			}
 		}
 		// wave_sums is rewritten only after the next row's barriers
