@@ -1155,6 +1155,14 @@ __device__ __forceinline__ u32 wave_inclusive_scan_u32(u32 v)
 	return v;
 }
 
+// Lane i receives lane i + 1's value, lane 63 receives 0 (v_mov_b32_dpp wave_shl:1, no LDS round trip).
+__device__ __forceinline__ u64 wave_shift_left_u64(u64 v)
+{
+	u32 const lo = (u32) __builtin_amdgcn_update_dpp(0, (int) (u32) v, 0x130, 0xf, 0xf, true);
+	u32 const hi = (u32) __builtin_amdgcn_update_dpp(0, (int) (u32) (v >> 32), 0x130, 0xf, 0xf, true);
+	return (u64) hi << 32 | lo;
+}
+
 // Non-zero bytes of tile[lo, hi).
 __device__ __forceinline__ u32 count_nonzero_bytes(unsigned char const *tile, u32 lo, u32 hi)
 {
@@ -1350,37 +1358,63 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			}
 			u32 const off = running + before + incl[k] - cnt[k];
 			running += total;
-			if (16 == cnt[k]) {
-				// a wave's 64 such stores cover one contiguous KiB at whatever byte phase the row is in
-				// (rounding the address down to 16 B -- wrong output, timing only -- changes nothing: 6.59 vs 6.44 ms per
-				// 256 rows of config 3; the misalignment is not what this kernel is bound by)
-				if (kNonTemporal) __builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));
-				else *(vec4u_unaligned *) (dst + off) = v[k];
-			} else if (cnt[k]) {
-				// A chunk with padding: its surviving bytes are packed to the low end of a 16-B value in registers (per
-				// dword with v_perm_b32 and the selector table, then the four pieces are shifted together) and go out as
-				// at most one store each of 8, 4, 2 and 1 bytes.  One store per byte (up to 16 predicated store
-				// instructions for the whole wave whenever any lane holds such a chunk -- 64 % of the time at config 3,
-				// always at config 5) is what made this kernel 15 % / 60 % slower than the aligned one.
-				u32 piece[4], len[4];
+			auto const store16 = [&](vec4u const &x) {
+				if (kNonTemporal) __builtin_nontemporal_store(x, (vec4u_unaligned *) (dst + off));
+				else *(vec4u_unaligned *) (dst + off) = x;
+			};
+			if (!__any(16 != cnt[k])) {
+				// no padding in any of the wave's 64 chunks: one 16-B store each, covering one contiguous KiB at whatever
+				// byte phase the row is in (rounding the addresses down to 16 B -- wrong output, timing only -- changes
+				// nothing; the misalignment is not what this kernel is bound by)
+				store16(v[k]);
+				continue;
+			}
+			// Some chunk of the wave holds padding (64 % of the time at config 3, always at config 5).  What bounds this
+			// kernel is the number of small store requests such chunks cause (profiles/r02/unaligned_what_bounds_it.txt), so:
+			//  1. every lane packs its chunk's surviving bytes to the low end of a 16-B value in registers (v_perm_b32 per
+			//     dword with the selector table, then the four pieces shifted together; a full chunk packs to itself);
+			//  2. a lane whose chunk is short fills its value up with the FIRST bytes of the next lane's packed chunk (DPP
+			//     wave shift) and stores 16 B like everybody else: the bytes it writes beyond its own are exactly the ones
+			//     the next lane writes there too, so the overlap is harmless whichever store lands last;
+			//  3. only a lane that cannot do that -- lane 63, or a next chunk too short to fill up from -- stores its bytes
+			//     exactly, as at most one store each of 8, 4, 2 and 1 bytes.
+			u32 piece[4], len[4];
 #pragma unroll
-				for (int d = 0; d < 4; ++d) {
-					u32 const keep = ~zero_bytes_mask(v[k][d]) & 0x80808080u;          // 0x80 per surviving byte
-					u32 const m = (((keep >> 7) * 0x01020408u) >> 24) & 0xFu;          // ... gathered into 4 bits
-					piece[d] = __builtin_amdgcn_perm(0u, v[k][d], compact_sel[m]);
-					len[d] = (u32) __builtin_popcount(m);
+			for (int d = 0; d < 4; ++d) {
+				u32 const keep = ~zero_bytes_mask(v[k][d]) & 0x80808080u;          // 0x80 per surviving byte
+				u32 const m = (((keep >> 7) * 0x01020408u) >> 24) & 0xFu;          // ... gathered into 4 bits
+				piece[d] = __builtin_amdgcn_perm(0u, v[k][d], compact_sel[m]);
+				len[d] = (u32) __builtin_popcount(m);
+			}
+			u64 const lo = (u64) piece[0] | ((u64) piece[1] << (8 * len[0]));
+			u64 const hi = (u64) piece[2] | ((u64) piece[3] << (8 * len[2]));
+			u32 const s = 8 * (len[0] + len[1]);                                   // 0 ... 64
+			u64 const packed_lo = lo | (s < 64 ? hi << s : 0);
+			u64 const packed_hi = 0 == s ? 0 : (64 == s ? hi : hi >> (64 - s));
+
+			u64 const next_lo = wave_shift_left_u64(packed_lo), next_hi = wave_shift_left_u64(packed_hi);   // lane 63: 0
+			u32 const next_cnt = (u32) __builtin_amdgcn_update_dpp(0, (int) cnt[k], 0x130, 0xf, 0xf, true);
+			u32 const c = cnt[k];
+			if (c && c + next_cnt >= 16) {          // (a full chunk qualifies by itself; lane 63 only if full)
+				u32 const sh = 8 * c;                // next << sh, 128 bits wide; sh = 128 for a full chunk
+				u64 fill_lo = 0, fill_hi = 0;
+				if (sh < 64) {
+					fill_lo = next_lo << sh;
+					fill_hi = (next_hi << sh) | (sh ? next_lo >> (64 - sh) : 0);
+				} else if (sh < 128) {
+					fill_hi = next_lo << (sh - 64);
 				}
-				u64 const lo = (u64) piece[0] | ((u64) piece[1] << (8 * len[0]));
-				u64 const hi = (u64) piece[2] | ((u64) piece[3] << (8 * len[2]));
-				u32 const s = 8 * (len[0] + len[1]);                                   // 0 ... 64
-				u64 const packed_lo = lo | (s < 64 ? hi << s : 0);
-				u64 const packed_hi = 0 == s ? 0 : (64 == s ? hi : hi >> (64 - s));
+				u64 const out_lo = packed_lo | fill_lo, out_hi = packed_hi | fill_hi;
+				vec4u x;
+				x[0] = (u32) out_lo; x[1] = (u32) (out_lo >> 32); x[2] = (u32) out_hi; x[3] = (u32) (out_hi >> 32);
+				store16(x);
+			} else if (c) {
 				char *p = dst + off;
 				u64 rest = packed_lo;
-				if (cnt[k] & 8) { *(u64_unaligned *) p = packed_lo; p += 8; rest = packed_hi; }
-				if (cnt[k] & 4) { *(u32_unaligned *) p = (u32) rest; p += 4; rest >>= 32; }
-				if (cnt[k] & 2) { *(u16_unaligned *) p = (u16) rest; p += 2; rest >>= 16; }
-				if (cnt[k] & 1) *p = (char) rest;
+				if (c & 8) { *(u64_unaligned *) p = packed_lo; p += 8; rest = packed_hi; }
+				if (c & 4) { *(u32_unaligned *) p = (u32) rest; p += 4; rest >>= 32; }
+				if (c & 2) { *(u16_unaligned *) p = (u16) rest; p += 2; rest >>= 16; }
+				if (c & 1) *p = (char) rest;
 			}
 		}
 		// wave_sums is rewritten only after the next row's barriers
