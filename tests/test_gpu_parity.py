@@ -522,8 +522,9 @@ def test_precondition_errors(v2m, ctx, tmp_path):
 
 @pytest.mark.parametrize("mode", ["", "plain"])
 def test_unaligned_rows_with_much_padding(ctx, v2m, tmp_path, monkeypatch, mode):
-	"""Graphs dense with insertions: most 16-byte chunks of a tile hold padding, so nearly every chunk takes the byte path
-	instead of the single 16-byte store."""
+	"""Graphs dense with insertions: most 16-byte chunks of a tile hold padding -- runs of chunks with a few surviving bytes
+	or none, so every way the stream-out kernel stores a chunk is taken: the plain 16-byte store, the 16-byte store filled up
+	from the next lane's chunk, and the exact 8 / 4 / 2 / 1-byte pieces where the next chunk is too short to fill up from."""
 	monkeypatch.setenv("V2M_UNALIGNED_STORE", mode)
 	g = synth.build_case(tmp_path, 94, 120000, 9000, 6, mix=(0.2, 0.7, 0.1), max_indel=40)   # an insertion every ~20 bases
 	vg = v2m.VariantGraph.from_object(g)
