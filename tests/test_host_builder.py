@@ -197,3 +197,29 @@ def test_graph_file_round_trip(HostGraph, tmp_path):
 	bad.write_bytes(good + b"\0" * 8)
 	with pytest.raises(ValueError, match="do not match the size of the file"):
 		HostGraph.read(bad)
+
+
+def test_graph_file_with_blocks_read_by_several_threads(HostGraph, tmp_path):
+	"""A path matrix of 96 MiB: read_graph() fetches and checksums it in 32-MiB parts on several threads; the file, the
+	arrays and the verdict on a flipped bit in the last part are what the single-threaded reader gives."""
+	from types import SimpleNamespace
+	n_nodes, n_edges, n_samples, ploidy = 3, 2, 1024 * 3, 2                   # 6144 copies x 16384-bit columns = 96 MiB
+	rng = np.random.default_rng(5)
+	hp, ep = n_samples * ploidy, 16384 * 8
+	words = rng.integers(0, 2 ** 63, size=ep // 64 * hp, dtype=np.uint64)
+	g = SimpleNamespace(reference_positions=[0, 1, 2], aligned_positions=[0, 1, 2], alt_edge_targets=[1, 2], alt_edge_count_csum=[0, 1, 2, 2],
+		label_offsets=[0, 1, 2], label_bytes=b"AC")
+	h = HostGraph.from_arrays(g, words, hp, ep, n_samples, ploidy)
+	path = tmp_path / "big.graph"
+	h.write(path)
+	r = HostGraph.read(path)
+	assert np.array_equal(r.paths_by_edge_and_chrom_copy, words) and r.paths_by_edge_and_chrom_copy_dims == (hp, ep)
+	assert list(r.alt_edge_targets) == [1, 2] and r.label_bytes == b"AC" and len(r.sample_names) == n_samples
+	size = os.path.getsize(path)
+	with open(path, "r+b") as f:
+		f.seek(size - 40 * 1024 * 1024)
+		b = f.read(1)
+		f.seek(size - 40 * 1024 * 1024)
+		f.write(bytes([b[0] ^ 1]))
+	with pytest.raises(ValueError, match="checksum"):
+		HostGraph.read(path)

@@ -39,7 +39,8 @@ ctx.close(); del src, dst
 print("prepared %s: graph file %.0f MB, FASTA %.0f MB in %.1f s" % (cfg, os.path.getsize(gf) / 1e6, os.path.getsize(fa) / 1e6, time.time() - t), flush=True)
 
 t = time.time()
-p = subprocess.Popen([build.CLI_PATH] + (["-F", "25", "-d", "50"] if mode == "founders" else ["-H"]) + ["-r", fa, "-g", gf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"] + (["--device=" + devices, "--verbose"] if devices else []),
+wrap = os.environ.get("E2E_WRAP", "").split()   # e.g. "rocprofv3 --hip-trace --stats -d DIR -o t --": the driver under a profiler
+p = subprocess.Popen(wrap + [build.CLI_PATH] + (["-F", "25", "-d", "50"] if mode == "founders" else ["-H"]) + ["-r", fa, "-g", gf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"] + (["--device=" + devices, "--verbose"] if devices else []),
 	stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 marks = []
 for line in p.stderr:

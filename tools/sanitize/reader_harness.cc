@@ -1,6 +1,7 @@
 // Sanitizer harness for the host's readers, graph builder and graph checkpoint (csrc/host/readers.cc,
 // graph_builder.cc, graph_file.cc): reader_harness FASTA VCF SCRATCH_FILE builds the graph on 1, 3 and 8 threads
-// (with a sample filter and both matrix paddings), compares the results and round-trips the checkpoint.
+// (with a sample filter and both matrix paddings), compares the results and round-trips the checkpoint, once more with a
+// matrix large enough for the reader's threads.
 #include "graph_file.hh"
 #include "readers.hh"
 
@@ -34,6 +35,27 @@ int main(int argc, char **argv)
 		variant_graph back;
 		read_graph(argv[3], back);
 		if (back.alt_edge_targets != g.alt_edge_targets || back.paths_by_edge_and_chrom_copy.words != g.paths_by_edge_and_chrom_copy.words) return 3;
+	}
+	{
+		// a path matrix of 72 MiB: read_graph() fetches and checksums it in 32-MiB parts on three threads
+		variant_graph g;
+		g.reference_positions = {0, 1};
+		g.aligned_positions = {0, 1};
+		g.alt_edge_targets = {1};
+		g.alt_edge_count_csum = {0, 1, 1};
+		g.alt_edge_label_offsets = {0, 1};
+		g.alt_edge_label_bytes = "A";
+		g.sample_names.assign(4608, "S");
+		g.ploidy_csum.resize(4609);
+		for (u32 i(0); i < 4609; ++i) g.ploidy_csum[i] = 2 * i;
+		g.paths_by_edge_and_chrom_copy = bit_matrix(9216, 65536);
+		u64 x(88172645463325252ULL);
+		for (auto &w : g.paths_by_edge_and_chrom_copy.words) { x ^= x << 13; x ^= x >> 7; x ^= x << 17; w = x; }
+		write_graph(g, argv[3]);
+		variant_graph back;
+		read_graph(argv[3], back);
+		if (back.paths_by_edge_and_chrom_copy.words != g.paths_by_edge_and_chrom_copy.words || back.sample_names.size() != 4608) return 5;
+		std::printf("72-MiB matrix: checkpoint round trip on several reader threads\n");
 	}
 	return (signature[0] == signature[1] && signature[1] == signature[2]) ? 0 : 4;
 }

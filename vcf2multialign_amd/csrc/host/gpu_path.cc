@@ -51,6 +51,18 @@ void upload_path_slice(gpu_context &gpu, variant_graph const &g, copy_shard shar
 }
 
 
+void warm_up_sink(gpu_context &gpu, bool unaligned)
+{
+	// six REF rows into a sink that drops them: more than one slice of the sink path's default 512-MB slots whenever two
+	// slices can occur at all, so both device slots and both pinned slots are allocated at the size later calls use
+	u32 const copies[6] = {kPloidyMax, kPloidyMax, kPloidyMax, kPloidyMax, kPloidyMax, kPloidyMax};
+	v2m_row_batch batch{};
+	batch.n_rows = 6;
+	batch.copy_index = copies;
+	gpu.check(v2m_splice_rows(gpu.get(), &batch, unaligned ? V2M_SPLICE_UNALIGNED : 0u, [](void *, uint64_t, char const *, uint64_t) -> int { return 0; }, nullptr));
+}
+
+
 void upload_graph(gpu_context &gpu, sequence_type const &ref_seq, variant_graph const &g, bool with_paths)
 {
 	v2m_graph_view view{};

@@ -37,6 +37,11 @@ void transpose_paths(gpu_context &gpu, variant_graph &graph);
 // comes from upload_path_slice()).
 void upload_graph(gpu_context &gpu, sequence_type const &ref_seq, variant_graph const &graph, bool with_paths = true);
 
+// Pays the sink path's one-off costs ahead of time (a gigabyte of pinned host memory: 0.15 s of hipHostMalloc, the device
+// slots, the templates) by splicing a few REF rows into a sink that drops them.  For callers that have something else
+// to do before the first real row (the founder search); needs an uploaded graph.
+void warm_up_sink(gpu_context &gpu, bool unaligned);
+
 // The chromosome copies [first, end) a GPU owns when `n_copies` copies are sharded over `world` GPUs (SURVEY.md section 8e;
 // the same rule as vcf2multialign_amd/sharding.py:shard_copies): contiguous blocks of whole bytes of the bit-packed path
 // matrix (8 copies), the blocks that do not divide evenly go to the last GPUs because the first one also carries the REF row.

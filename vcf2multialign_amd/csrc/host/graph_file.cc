@@ -1,8 +1,17 @@
 #include "graph_file.hh"
 
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <cstdio>
 #include <cstring>
+#include <exception>
 #include <stdexcept>
+#include <thread>
 #include <vector>
 
 namespace v2m::host {
@@ -37,22 +46,72 @@ struct writer {
 	}
 };
 
+// Reads with pread() so that a large block (the path matrices: 0.6 GB each at BASELINE config 3) is fetched and
+// checksummed by several threads at once; the checksum is a sum over (word index, word), so the parts just add up.
 struct reader {
-	std::FILE *f;
-	u64 index{}, sum{};
+	int fd;
+	u64 offset{}, index{}, sum{};
+
+	static void read_exactly(int fd, unsigned char *dst, u64 n, u64 at)
+	{
+		while (n) {
+			ssize_t const got(::pread(fd, dst, n, off_t(at)));
+			if (got < 0 && EINTR == errno) continue;
+			if (got <= 0) throw std::runtime_error("unexpected end of graph file");
+			dst += got; at += u64(got); n -= u64(got);
+		}
+	}
+
+	static u64 checksum(unsigned char const *p, u64 n_words, u64 first_index)
+	{
+		u64 sum(0);
+		for (u64 i(0); i < n_words; ++i) { u64 w; std::memcpy(&w, p + 8 * i, 8); sum += mix64((first_index + i) ^ w); }
+		return sum;
+	}
+
 	void words(void *p, u64 n_bytes)
 	{
-		u64 const padded((n_bytes + 7) & ~u64(7));
-		std::vector<unsigned char> tmp;
-		unsigned char *dst(static_cast<unsigned char *>(p));
-		if (padded != n_bytes) { tmp.resize(padded); dst = tmp.data(); }
-		if (padded && 1 != std::fread(dst, padded, 1, f)) throw std::runtime_error("unexpected end of graph file");
-		for (u64 i(0); i < padded / 8; ++i) { u64 w; std::memcpy(&w, dst + 8 * i, 8); sum += mix64(index++ ^ w); }
-		if (padded != n_bytes) std::memcpy(p, tmp.data(), n_bytes);
+		u64 const full(n_bytes / 8);
+		unsigned char *const dst(static_cast<unsigned char *>(p));
+		u64 const part_words(u64(4) << 20);                                   // 32 MiB per task
+		unsigned const n_threads(unsigned(std::min<u64>({(full + part_words - 1) / part_words, 16, std::max(1u, std::thread::hardware_concurrency())})));
+		if (n_threads <= 1) {
+			if (full) read_exactly(fd, dst, 8 * full, offset);
+			sum += checksum(dst, full, index);
+		} else {
+			std::atomic<u64> next(0);
+			std::vector<u64> sums(n_threads, 0);
+			std::vector<std::exception_ptr> errors(n_threads);
+			std::vector<std::thread> threads;
+			for (unsigned t(0); t < n_threads; ++t)
+				threads.emplace_back([&, t] {
+					try {
+						for (u64 first(next.fetch_add(part_words)); first < full; first = next.fetch_add(part_words)) {
+							u64 const n(std::min(part_words, full - first));
+							read_exactly(fd, dst + 8 * first, 8 * n, offset + 8 * first);
+							sums[t] += checksum(dst + 8 * first, n, index + first);
+						}
+					} catch (...) { errors[t] = std::current_exception(); }
+				});
+			for (auto &th : threads) th.join();
+			for (auto const &e : errors) if (e) std::rethrow_exception(e);
+			for (u64 const part : sums) sum += part;
+		}
+		offset += 8 * full;
+		index += full;
+		if (n_bytes % 8) {                                                      // the last word is padded with zeros in the file
+			unsigned char tail[8];
+			read_exactly(fd, tail, 8, offset);
+			sum += checksum(tail, 1, index);
+			std::memcpy(dst + 8 * full, tail, n_bytes % 8);
+			offset += 8;
+			++index;
+		}
 	}
 };
 
 struct file_closer { std::FILE *f; ~file_closer() { if (f) std::fclose(f); } };
+struct fd_closer { int fd; ~fd_closer() { if (fd >= 0) ::close(fd); } };
 
 } // namespace
 
@@ -89,10 +148,10 @@ void write_graph(variant_graph const &g, char const *path)
 
 void read_graph(char const *path, variant_graph &g)
 {
-	std::FILE *f(std::fopen(path, "rb"));
-	if (!f) throw std::runtime_error(std::string("unable to open ") + path);
-	file_closer closer{f};
-	reader r{f};
+	int const fd(::open(path, O_RDONLY | O_CLOEXEC));
+	if (fd < 0) throw std::runtime_error(std::string("unable to open ") + path);
+	fd_closer closer{fd};
+	reader r{fd};
 	char magic[8];
 	r.words(magic, 8);
 	if (0 != std::memcmp(magic, kMagic, 8)) throw std::runtime_error(std::string(path) + " is not a V2MGRAF1 graph file");
@@ -104,13 +163,11 @@ void read_graph(char const *path, variant_graph &g)
 	// the counts must agree with each other and with the size of the file before anything is allocated from them
 	if (c[3] && c[5] != c[3] + 1) throw std::runtime_error("graph file: ploidy_csum must have one entry more than there are samples");
 	{
-		long const at(std::ftell(f));
-		if (at < 0 || 0 != std::fseek(f, 0, SEEK_END)) throw std::runtime_error(std::string("unable to size ") + path);
-		long const end(std::ftell(f));
-		if (end < 0 || 0 != std::fseek(f, at, SEEK_SET)) throw std::runtime_error(std::string("unable to size ") + path);
+		struct stat st;
+		if (0 != ::fstat(fd, &st) || st.st_size < 0) throw std::runtime_error(std::string("unable to size ") + path);
 		auto const pad8([](u64 n) { return (n + 7) & ~u64(7); });   // every block is padded to whole 8-byte words
 		u64 const payload(8 * (2 * c[0] + c[1] + (c[0] + 1) + (c[1] + 1)) + c[6] / 64 * c[7] * 8 + c[8] / 64 * c[9] * 8 + pad8(4 * c[5]) + pad8(c[2]) + pad8(c[4]) + 8);
-		if (payload != u64(end - at)) throw std::runtime_error(std::string(path) + ": the counts in the header do not match the size of the file (truncated or corrupted graph file)");
+		if (u64(st.st_size) < r.offset || payload != u64(st.st_size) - r.offset) throw std::runtime_error(std::string(path) + ": the counts in the header do not match the size of the file (truncated or corrupted graph file)");
 	}
 	g = variant_graph{};
 	g.reference_positions.resize(c[0]);
@@ -118,8 +175,8 @@ void read_graph(char const *path, variant_graph &g)
 	g.alt_edge_targets.resize(c[1]);
 	g.alt_edge_count_csum.resize(c[0] + 1);
 	g.alt_edge_label_offsets.resize(c[1] + 1);
-	g.paths_by_chrom_copy_and_edge = bit_matrix(c[6], c[7]);
-	g.paths_by_edge_and_chrom_copy = bit_matrix(c[8], c[9]);
+	g.paths_by_chrom_copy_and_edge = bit_matrix::for_overwrite(c[6], c[7]);
+	g.paths_by_edge_and_chrom_copy = bit_matrix::for_overwrite(c[8], c[9]);
 	g.ploidy_csum.resize(c[5]);
 	g.alt_edge_label_bytes.resize(c[2]);
 	std::string names(c[4], '\0');
@@ -134,7 +191,8 @@ void read_graph(char const *path, variant_graph &g)
 	r.words(g.alt_edge_label_bytes.data(), c[2]);
 	r.words(names.data(), c[4]);
 	u64 stored(0);
-	if (1 != std::fread(&stored, 8, 1, f) || stored != r.sum) throw std::runtime_error(std::string(path) + ": checksum mismatch (truncated or corrupted graph file)");
+	reader::read_exactly(fd, reinterpret_cast<unsigned char *>(&stored), 8, r.offset);
+	if (stored != r.sum) throw std::runtime_error(std::string(path) + ": checksum mismatch (truncated or corrupted graph file)");
 	for (std::size_t pos(0); pos < names.size();) {
 		std::size_t const end(names.find('\0', pos));
 		if (std::string::npos == end) break;

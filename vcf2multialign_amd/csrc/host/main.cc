@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <memory>
 #include <set>
@@ -264,9 +265,18 @@ int main(int argc, char **argv)
 	if (opt.include_samples && opt.exclude_samples) { std::cerr << "ERROR: --include-samples and --exclude-samples are mutually exclusive.\n"; return EXIT_FAILURE; }
 
 	try {
-		vh::gpu_context gpu(opt.devices.front());   // fails here, loudly, without a usable MI355X
-		std::vector<std::unique_ptr<vh::gpu_context>> more_gpus;
-		for (std::size_t k(1); k < opt.devices.size(); ++k) more_gpus.emplace_back(new vh::gpu_context(opt.devices[k]));
+		// The GPU contexts come up on a second thread (HIP runtime start-up and stream creation: 0.2 s) while this one reads the
+		// reference and the graph; without a usable MI355X the run still fails, loudly, at the first use below.
+		auto contexts_coming(std::async(std::launch::async, [&opt] {
+			std::vector<std::unique_ptr<vh::gpu_context>> contexts;
+			for (int const device : opt.devices) contexts.emplace_back(new vh::gpu_context(device));
+			return contexts;
+		}));
+		std::vector<std::unique_ptr<vh::gpu_context>> contexts;
+		auto const first_gpu([&]() -> vh::gpu_context & {
+			if (contexts.empty()) contexts = contexts_coming.get();
+			return *contexts.front();
+		});
 
 		vh::sequence_type ref_seq;
 		std::cerr << "Reading the reference sequence..." << std::flush;
@@ -299,7 +309,7 @@ int main(int argc, char **argv)
 			vh::build_variant_graph(ref_seq, opt.input_variants, opt.chromosome, graph, stats, delegate, 0, 64);   // the reference's padding (variant_graph.cc:277,449)
 			// variant_graph.cc:453 (the transpose) happens on the GPU(s) below; the transposed matrix only comes back to the host
 			// when something on the host reads it: the founder search and the graph checkpoint.
-			if (opt.founder_mode || opt.output_graph) vh::transpose_paths(gpu, graph);
+			if (opt.founder_mode || opt.output_graph) vh::transpose_paths(first_gpu(), graph);
 			std::cerr << "Done. Handled variants: " << stats.handled_variants << " Chromosome ID mismatches: " << stats.chr_id_mismatches << '\n';
 			if (0 == stats.handled_variants) std::cerr << "WARNING: no variants matched the chromosome identifier \"" << opt.chromosome << "\".\n";
 		}
@@ -330,15 +340,18 @@ int main(int argc, char **argv)
 		// and an aligned A2M file as the only output, GPU k receives the bits of its own chromosome copies only, transposes
 		// them itself and splices the rows of those copies.  Every other combination (one GPU, pipes, unaligned or separate
 		// output) needs the whole matrix on the GPU that writes a row; founder rows read copies all over the matrix.
-		std::vector<vh::gpu_context *> all_gpus{&gpu};
-		for (auto &g : more_gpus) all_gpus.push_back(g.get());
+		vh::gpu_context &gpu(first_gpu());
+		std::vector<vh::gpu_context *> all_gpus;
+		for (auto &g : contexts) all_gpus.push_back(g.get());
 		bool const sharded(opt.haplotypes && all_gpus.size() > 1 && opt.output_sequences_a2m && !opt.pipe && !opt.unaligned && !opt.output_sequences_separate);
 		std::vector<vh::copy_shard> shards;
-		for (std::size_t k(0); k < all_gpus.size(); ++k) {
-			if (opt.founder_mode) {
-				vh::upload_graph(*all_gpus[k], ref_seq, graph, true);      // the host-transposed matrix (the search needs it on the host anyway)
-				continue;
-			}
+		std::future<void> founder_graph_uploaded;
+		if (opt.founder_mode)   // the host-transposed matrix (the search needs it on the host anyway), uploaded while the search runs
+			founder_graph_uploaded = std::async(std::launch::async, [&] {
+				for (auto *g : all_gpus) vh::upload_graph(*g, ref_seq, graph, true);
+				for (auto *g : all_gpus) vh::warm_up_sink(*g, opt.unaligned);       // ... and the output path's buffers set up meanwhile
+			});
+		for (std::size_t k(0); k < all_gpus.size() && !opt.founder_mode; ++k) {
 			vh::upload_graph(*all_gpus[k], ref_seq, graph, false);
 			vh::copy_shard const shard(sharded
 				? vh::shard_copies(graph.total_chromosome_copies(), vh::u32(all_gpus.size()), vh::u32(k))
@@ -366,12 +379,12 @@ int main(int argc, char **argv)
 
 		if (opt.haplotypes) {
 			vh::haplotype_output output(gpu, opt.pipe, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
-			for (auto &g : more_gpus) output.add_gpu(*g);
+			for (std::size_t k(1); k < all_gpus.size(); ++k) output.add_gpu(*all_gpus[k]);
 			if (sharded) output.set_copy_shards(shards);
 			do_output(output);
 		} else {                                            // main.cc:487-550
 			vh::founder_sequence_greedy_output output(gpu, opt.pipe, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
-			for (auto &g : more_gpus) output.add_gpu(*g);
+			for (std::size_t k(1); k < all_gpus.size(); ++k) output.add_gpu(*all_gpus[k]);
 			std::vector<vh::u64> cuts;
 			vh::u32 score(0);
 			vh::u64 cut_min_distance(vh::u64(opt.minimum_distance));
@@ -407,8 +420,15 @@ int main(int argc, char **argv)
 			}
 			output.set_cut_positions(std::move(cuts));
 			output.set_assigned_samples(std::move(assigned), vh::u32(opt.founder_sequences));
+			founder_graph_uploaded.get();
 			do_output(output);
 		}
+		// Everything is written and closed.  What is left is giving back a gigabyte of pinned memory, the device buffers and
+		// the 1.3-GB graph piece by piece (0.3 s at BASELINE config 4, of a 2-s run): the kernel does that faster for a
+		// process that just ends.
+		std::cout.flush();
+		std::cerr.flush();
+		std::_Exit(EXIT_SUCCESS);
 	} catch (vh::gpu_error const &e) {
 		std::cerr << "ERROR (GPU path, code " << e.code << "): " << e.what() << '\n';
 		return EXIT_FAILURE;

@@ -7,8 +7,12 @@
 #pragma once
 
 #include <cstdint>
+#include <memory>
+#include <new>
 #include <string>
 #include <string_view>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 namespace v2m::host {
@@ -20,13 +24,26 @@ constexpr u32 kPloidyMax = UINT32_MAX;   // variant_graph.hh:55
 constexpr u64 kEdgeMax = UINT64_MAX;     // variant_graph.hh:53
 
 // Column-major bit matrix; one column = rows/64 consecutive words; rows is a multiple of 64.
+// std::allocator, except that resize(n) without a value leaves the new elements as they are instead of zeroing them:
+// a matrix that is about to be overwritten completely (read_graph: 0.6 GB per matrix at BASELINE config 3) then is not
+// written twice, and its pages are first touched by the threads that fill it.
+template <typename T>
+struct default_init_allocator : std::allocator<T> {
+	template <typename U> struct rebind { using other = default_init_allocator<U>; };
+	using std::allocator<T>::allocator;
+	template <typename U> void construct(U *p) noexcept(std::is_nothrow_default_constructible_v<U>) { ::new (static_cast<void *>(p)) U; }
+	template <typename U, typename... Args> void construct(U *p, Args &&... args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
+};
+
 struct bit_matrix {
 	u64 rows{};
 	u64 cols{};
-	std::vector<u64> words;
+	std::vector<u64, default_init_allocator<u64>> words;
 
 	bit_matrix() = default;
 	bit_matrix(u64 rows_, u64 cols_) : rows(rows_), cols(cols_), words(rows_ / 64 * cols_, 0) {}
+	// a matrix whose words the caller is going to overwrite, all of them
+	static bit_matrix for_overwrite(u64 rows_, u64 cols_) { bit_matrix m; m.rows = rows_; m.cols = cols_; m.words.resize(rows_ / 64 * cols_); return m; }
 
 	u64 words_per_column() const { return rows / 64; }
 	bool test(u64 r, u64 c) const { return (words[c * (rows / 64) + (r >> 6)] >> (r & 63)) & 1; }
