@@ -3,6 +3,10 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
 
 #include "../host/graph_builder.hh"
 
@@ -156,28 +160,47 @@ bool write_fasta_and_vcf(dataset const &ds, u64 seed, u32 samples, u32 ploidy, c
 	std::fputs("##fileformat=VCFv4.2\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT", f);
 	for (u32 s(0); s < samples; ++s) std::fprintf(f, "\tS%u", s);
 	std::fputc('\n', f);
-	std::string line;
-	u64 idx(0);
-	for (auto const &r : ds.records) {
-		line.clear();
-		line += chromosome; line += '\t'; line += std::to_string(r.pos + 1); line += "\tv"; line += std::to_string(idx++); line += '\t';
-		line.append(ds.reference, r.pos, r.ref_length); line += '\t';
-		line += r.alts[0];
-		if (r.n_alts > 1) { line += ','; line += r.alts[1]; }
-		line += "\t.\tPASS\t.\tGT";
-		for (u32 s(0); s < samples; ++s) {
-			line += '\t';
-			for (u32 c(0); c < ploidy; ++c) {
-				if (c) line += '|';
-				u64 const copy(u64(s) * ploidy + c);
-				char allele('0');
-				for (u32 a(0); a < r.n_alts; ++a)
-					if (path_bit(seed, r.first_edge + a, copy, ds.edge_thresholds[r.first_edge + a])) { allele = char('1' + a); break; }
-				line += allele;
+	// The genotype text is most of the work (config 3: 10 GB, 5 G fields): blocks of records are formatted by several
+	// threads at once and written in order.
+	auto const format_block([&](u64 first, u64 end, std::string &text) {
+		text.clear();
+		for (u64 idx(first); idx < end; ++idx) {
+			auto const &r(ds.records[idx]);
+			text += chromosome; text += '\t'; text += std::to_string(r.pos + 1); text += "\tv"; text += std::to_string(idx); text += '\t';
+			text.append(ds.reference, r.pos, r.ref_length); text += '\t';
+			text += r.alts[0];
+			if (r.n_alts > 1) { text += ','; text += r.alts[1]; }
+			text += "\t.\tPASS\t.\tGT";
+			std::size_t at(text.size());
+			text.resize(at + std::size_t(samples) * 2 * ploidy);                // per sample: a tab, then alleles separated by '|'
+			for (u32 s(0); s < samples; ++s) {
+				text[at++] = '\t';
+				for (u32 c(0); c < ploidy; ++c) {
+					if (c) text[at++] = '|';
+					u64 const copy(u64(s) * ploidy + c);
+					char allele('0');
+					for (u32 a(0); a < r.n_alts; ++a)
+						if (path_bit(seed, r.first_edge + a, copy, ds.edge_thresholds[r.first_edge + a])) { allele = char('1' + a); break; }
+					text[at++] = allele;
+				}
 			}
+			text += '\n';
 		}
-		line += '\n';
-		std::fwrite(line.data(), 1, line.size(), f);
+	});
+	u64 const n_records(ds.records.size());
+	unsigned const n_threads(std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
+	u64 const block(std::max<u64>(1, std::min<u64>(4096, (u64(32) << 20) / (64 + u64(samples) * 2 * ploidy))));   // about 32 MB of text
+	std::vector<std::string> texts(n_threads);
+	for (u64 round_first(0); round_first < n_records; round_first += block * n_threads) {
+		std::vector<std::thread> threads;
+		for (unsigned t(0); t < n_threads; ++t) {
+			u64 const first(round_first + block * t);
+			if (first >= n_records) { texts[t].clear(); continue; }
+			threads.emplace_back(format_block, first, std::min(n_records, first + block), std::ref(texts[t]));
+		}
+		for (auto &th : threads) th.join();
+		for (auto const &text : texts)
+			if (!text.empty() && text.size() != std::fwrite(text.data(), 1, text.size(), f)) { std::fclose(f); return false; }
 	}
 	return 0 == std::fclose(f);
 }
