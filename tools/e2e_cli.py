@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Config 2 through the whole text pipeline: synthetic FASTA + VCF (400 MB) -> bin/vcf2multialign --haplotypes -> A2M
-(20 GB) into /dev/null, wall-clock per stage from the driver's own log lines."""
+"""A BASELINE config through the whole text pipeline: synthetic FASTA + VCF (config 2: 400 MB, config 3: 10 GB; put TMPDIR
+on /dev/shm for that one) -> bin/vcf2multialign --haplotypes -> A2M (20 GB / 502 GB) into /dev/null, wall-clock per stage
+from the driver's own log lines.  Usage: python tools/e2e_cli.py [config2|config3]"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -11,7 +12,9 @@ fa, vcf = os.path.join(tmp, cfg + ".fa"), os.path.join(tmp, cfg + ".vcf")
 t = time.time(); ds = synth.dataset(cfg); ds.write_fasta_and_vcf(fa, vcf)
 print("generated %s: VCF %.0f MB in %.1f s" % (cfg, os.path.getsize(vcf) / 1e6, time.time() - t), flush=True)
 t = time.time()
-p = subprocess.Popen([build.CLI_PATH, "-H", "-r", fa, "-a", vcf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+# (overlapping variants go to a file: on stdout, which is read only after the run, they would fill the pipe and stall the driver)
+overlaps = os.path.join(tmp, cfg + ".overlaps.tsv")
+p = subprocess.Popen([build.CLI_PATH, "-H", "-r", fa, "-a", vcf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics", "--output-overlaps=" + overlaps], stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 marks = []
 for line in p.stderr:
 	marks.append((time.time() - t, line.rstrip()))
@@ -22,4 +25,5 @@ for m in marks:
 print(p.stdout.read().strip())
 rows, L = ds.n_copies + 1, ds.graph.aligned_length
 print("exit %d; total %.2f s for %d rows x %d bases = %.1f Gbases -> %.2f Gbases/s end to end incl. VCF parsing" % (p.returncode, total, rows, L, rows * L / 1e9, rows * L / total / 1e9))
-os.remove(vcf); os.remove(fa)
+print("overlap report: %.1f MB" % (os.path.getsize(overlaps) / 1e6))
+os.remove(vcf); os.remove(fa); os.remove(overlaps)
