@@ -423,12 +423,6 @@ int main(int argc, char **argv)
 			founder_graph_uploaded.get();
 			do_output(output);
 		}
-		// Everything is written and closed.  What is left is giving back a gigabyte of pinned memory, the device buffers and
-		// the 1.3-GB graph piece by piece (0.3 s at BASELINE config 4, of a 2-s run): the kernel does that faster for a
-		// process that just ends.
-		std::cout.flush();
-		std::cerr.flush();
-		std::_Exit(EXIT_SUCCESS);
 	} catch (vh::gpu_error const &e) {
 		std::cerr << "ERROR (GPU path, code " << e.code << "): " << e.what() << '\n';
 		return EXIT_FAILURE;
