@@ -308,7 +308,7 @@ def test_founder_rows_many_segments(v2m, ctx, tmp_path, monkeypatch, max_back):
 	assert ctx.splice_rows(rows[:2], unaligned=True) == _oracle_rows(g, rows[:2], unaligned=True)
 
 
-@pytest.mark.parametrize("seed", range(96))
+@pytest.mark.parametrize("seed", range(int(os.environ.get("V2M_FUZZ_SEEDS", "96"))))   # a longer soak: V2M_FUZZ_SEEDS=2000
 def test_fuzz_small_graphs(v2m, ctx, tmp_path, seed):
 	"""Random small inputs with random shapes (0 .. 3000 records over 100 .. 70 000 bases, 1-5 samples, any variant mix,
 	long indels, multi-allelic sites, genotype or iid path bits): every row, REF, and founder-style rows cut at random
