@@ -12,7 +12,7 @@ from vcf2multialign_amd import synth, build
 from vcf2multialign_amd.host import HostGraph
 
 cfg = sys.argv[1] if len(sys.argv) > 1 else "config3"
-mode = sys.argv[2] if len(sys.argv) > 2 else "founders"    # or "haplotypes": BASELINE config 3 (all 5009 rows, 501 GB of A2M)
+mode = sys.argv[2] if len(sys.argv) > 2 else "founders"    # or "haplotypes": BASELINE config 3 (all 5009 rows, 501 GB of A2M); "unaligned": the same rows with --unaligned
 devices = sys.argv[3] if len(sys.argv) > 3 else None        # e.g. "0,0": several contexts, each with its own slice of the path matrix
 tmp = os.environ.get("TMPDIR", "/tmp")
 fa, gf = os.path.join(tmp, cfg + ".fa"), os.path.join(tmp, cfg + ".v2mgraph")
@@ -40,7 +40,7 @@ print("prepared %s: graph file %.0f MB, FASTA %.0f MB in %.1f s" % (cfg, os.path
 
 t = time.time()
 wrap = os.environ.get("E2E_WRAP", "").split()   # e.g. "rocprofv3 --hip-trace --stats -d DIR -o t --": the driver under a profiler
-p = subprocess.Popen(wrap + [build.CLI_PATH] + (["-F", "25", "-d", "50"] if mode == "founders" else ["-H"]) + ["-r", fa, "-g", gf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"] + (["--device=" + devices, "--verbose"] if devices else []),
+p = subprocess.Popen(wrap + [build.CLI_PATH] + (["-F", "25", "-d", "50"] if mode == "founders" else ["-H", "--unaligned"] if mode == "unaligned" else ["-H"]) + ["-r", fa, "-g", gf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"] + (["--device=" + devices, "--verbose"] if devices else []),
 	stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 marks = []
 for line in p.stderr:
