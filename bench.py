@@ -78,6 +78,55 @@ def _device_bytes(ptr, nbytes):
 	return buf.raw
 
 
+def launch_ranks(n, argv):
+	"""`python bench.py --gpus N` typed as is (no WORLD_SIZE in the environment): this parent -- which has parsed its arguments
+	and nothing else, no torch import, no HIP call -- starts the N ranks as fresh child processes with the torch.distributed
+	environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and waits for them.  Rank 0's single JSON line is
+	relayed on stdout; everything else any rank prints goes to stderr.  Never os.exec*: the children are children."""
+	import socket
+	import subprocess
+	with socket.socket() as sock:
+		sock.bind(("127.0.0.1", 0))
+		port = sock.getsockname()[1]
+	procs = []
+	for r in range(n):
+		env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+		env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+		procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+			stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
+	import threading
+	chunks = []
+	reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+	reader.start()
+	# a rank that dies leaves the others waiting at a barrier: end them (by their own PIDs) instead of hanging until a timeout
+	while any(p.poll() is None for p in procs):
+		if any(p.poll() not in (None, 0) for p in procs):
+			time.sleep(5.0)
+			for p in procs:
+				if p.poll() is None:
+					p.terminate()
+			break
+		time.sleep(0.2)
+	codes = [p.wait() for p in procs]
+	reader.join(timeout=30)
+	out0 = b"".join(chunks).decode(errors="replace")
+	line = None
+	for l in out0.splitlines():
+		if l.startswith("{") and line is None:
+			line = l
+		elif l.strip():
+			log(l)
+	bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+	if bad:
+		log("[bench] rank(s) failed: " + ", ".join("rank %d -> exit %d" % rc for rc in bad))
+	if line is not None:
+		print(line, flush=True)
+	if bad:
+		sys.exit(bad[0][1] if 0 < bad[0][1] < 256 else 1)
+	if line is None:
+		sys.exit("[bench] rank 0 printed no result line")
+
+
 def main():
 	ap = argparse.ArgumentParser()
 	ap.add_argument("--gpus", type=int, default=1)
@@ -91,17 +140,23 @@ def main():
 	ap.add_argument("--output-candidates", type=int, default=4, help="device buffers v2m_alloc_output may hold at once to choose the output buffer from (as many as fit are tried; 1 = plain allocation)")
 	ap.add_argument("--cpu-baseline-rows", type=int, default=320, help="haplotypes (plus REF) the CPU oracle is timed on (320 rows of config 3 = 32 Gbases, about 11 s on one core); 0 disables")
 	ap.add_argument("--verify-rows", type=int, default=1, help="after timing: rows per batch (every batch) checked against the CPU oracle, plus REF and the last batch's ragged final group; 0 disables")
-	ap.add_argument("--unaligned-rows", type=int, default=256, help="rows of the separately timed --unaligned leg (rank 0, after the main timing); 0 disables")
+	ap.add_argument("--unaligned-rows", type=int, default=256, help="the separately timed --unaligned leg (rank 0, after the main timing) runs on as many rows as the output buffer holds and, beside it, on the first this-many rows; 0 disables")
+	ap.add_argument("--cpu-transpose", type=int, default=1, help="after timing (rank 0, N=1): time the CPU oracle's transpose_matrix on the same matrix and compare it bit for bit with the GPU's dense-form result (config 3: ~8 s); 0 disables")
 	ap.add_argument("--transpose-extras", type=int, default=1, help="after timing, also measure the inverse transpose and a 1024-bit-padded matrix (rank 0); 0 disables")
 	args = ap.parse_args()
 
 	rank = int(os.environ.get("RANK", "0"))
 	local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 	world = int(os.environ.get("WORLD_SIZE", "1"))
+	if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+		return launch_ranks(args.gpus, sys.argv[1:])
 	if world != args.gpus:
-		if world == 1 and args.gpus > 1:
-			sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
 		sys.exit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+	# Only the result line may appear on stdout: file descriptor 1 is pointed at stderr for everything else in this process
+	# (c10d / gloo / RCCL print connection chatter from C++), and the line goes out through a private copy of the real stdout.
+	sys.stdout.flush()
+	result_out = os.fdopen(os.dup(1), "w")
+	os.dup2(2, 1)
 
 	import torch
 	import torch.distributed as dist
@@ -194,8 +249,13 @@ def main():
 	ctx.synchronize()
 	torch.cuda.synchronize()
 	elapsed = time.perf_counter() - t_begin
+	per_rank = [{"rank": 0, "rows": n_rows, "batches": len(batches), "ms_per_step": round(1e3 * elapsed / args.steps, 3)}]
 	if world > 1:
 		dist.barrier()
+		mine = torch.tensor([elapsed, float(n_rows), float(len(batches))], dtype=torch.float64, device=red_dev)
+		everyone = [torch.zeros_like(mine) for _ in range(world)]
+		dist.all_gather(everyone, mine)      # reporting only (after the timed region): rank 0 carries REF, so imbalance should be visible
+		per_rank = [{"rank": r, "rows": int(t[1].item()), "batches": int(t[2].item()), "ms_per_step": round(1e3 * t[0].item() / args.steps, 3)} for r, t in enumerate(everyone)]
 		elapsed = max_over_ranks(elapsed, dist, red_dev)
 	ctx.profile_enable(False)
 
@@ -251,6 +311,7 @@ def main():
 			"rows_total": total_rows, "aligned_length": L, "batch_rows": batch_rows,
 			"path_matrix": "%d x %d bits per rank: this rank's copies x ALT edges, both padded to multiples of 64 as in the reference (variant_graph.cc:277,449), nothing more" % (hp_local, Ep),
 			"sharding": "contiguous chromosome copies per rank (multiples of 8), graph + reference replicated, no collective",
+			"per_rank": per_rank,
 			"tuning": ctx.info,
 		},
 		"roofline": {
@@ -374,58 +435,95 @@ def main():
 			dist.all_reduce(lo, op=dist.ReduceOp.MIN)
 			dist.all_reduce(flags, op=dist.ReduceOp.SUM)
 			ok, checked = bool(lo[0].item()), int(flags[1].item())
-		result["parity"] = {"rows_checked": checked, "batches_covered": len(batches) * world if world > 1 else len(batches), "bit_exact": ok,
+		result["parity"] = {"rows_checked": checked, "batches_covered": sum(p["batches"] for p in per_rank), "bit_exact": ok,
 			"method": "per rank, after timing: every batch of the step re-run; device checksums (v2m_checksum_rows_device) of %d row(s) per batch, REF and the last batch's final ragged group against the CPU oracle's rows, plus the last row of the last batch byte for byte" % args.verify_rows}
 		if not ok:
 			log("[bench] PARITY FAILURE against the CPU oracle")
 
 	# ---- second leg, timed on its own: --unaligned (sequence_writer.cc:80: no '-' padding) -----------------------------
+	# Measured on the SAME address footprint as the aligned leg (as many rows as the ~63-GB output buffer holds at the unaligned
+	# pitch: the store pattern only reaches its full rate when a launch spans several tens of GB), and, for
+	# continuity with rounds 1-2, on the first --unaligned-rows (256) rows as well.
 	if rank == 0 and args.unaligned_rows and n_rows > 1:
 		import oracle
 		upitch = (ctx.max_unaligned_length + 255) // 256 * 256
-		n_u = max(1, min(args.unaligned_rows, out_bytes // upitch, n_rows))
-		ub = v2m.RowBatch(rows[:n_u])
-		ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True)      # warm-up (builds the second template)
-		ctx.synchronize()
-		ctx.profile_enable(True)
-		ctx.profile_reset()
-		reps = 3
-		t_u = time.perf_counter()
-		for _ in range(reps):
-			lengths = ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True, want_lengths=True)
-		ctx.synchronize()
-		wall_u = (time.perf_counter() - t_u) / reps
-		_, u_count = ctx.profile_get(N.KERNEL_UNALIGNED_COUNT)
-		_, u_splice = ctx.profile_get(N.KERNEL_SPLICE_UNALIGNED)
-		_, u_resolve = ctx.profile_get(N.KERNEL_RESOLVE)
-		ctx.profile_enable(False)
-		u_count, u_splice, u_resolve = u_count / reps, u_splice / reps, u_resolve / reps
-		bases_u = int(lengths.sum())
 		n_tiles = -(-L // 16384)
-		# pass 2 (splice_unaligned_kernel): row bytes out + the rows' bit columns + the shared inputs + one tile offset per (row, tile);
-		# pass 1 (count + scan): the shared inputs + bit columns in, the tile counts out and in and out again (scan in place)
-		alg_u = bases_u + n_u * Ep // 8 + shared_bytes + 4 * n_u * n_tiles
-		alg_c = n_u * Ep // 8 + shared_bytes + 3 * 4 * n_u * n_tiles
-		usample = sorted({0, 1, n_u // 2, n_u - 1})
-		ucopies = [c0 + rows[i] for i in usample if rows[i] != v2m.PLOIDY_MAX]
-		uog = oracle_graph(ucopies)
-		ucol = {c: i for i, c in enumerate(ucopies)}
-		uwant, ulen = uog.row_checksums(ds.reference, [oracle.PLOIDY_MAX if rows[i] == v2m.PLOIDY_MAX else ucol[c0 + rows[i]] for i in usample], unaligned=True, threads=len(usample))
-		ugot = np.array([ctx.checksum_rows_device(out_ptr + i * upitch, upitch, 1, length=int(lengths[i]))[0] for i in usample], dtype=np.uint64)
-		u_ok = bool(np.array_equal(ulen, lengths[usample])) and bool(np.array_equal(ugot, uwant))
-		result["unaligned"] = {
-			"metric": "unaligned (--unaligned) Gbases/sec, one batch, kernels only", "rows": n_u, "bases": bases_u,
-			"value": round(bases_u / (u_resolve + u_count + u_splice) / 1e6, 1), "unit": "Gbases/s", "wall_ms_per_batch": round(1e3 * wall_u, 3),
-			"kernels_ms": {"resolve_effective_edges_kernel": round(u_resolve, 3), "count_unaligned_kernel+scan_tile_counts_kernel": round(u_count, 3), "splice_unaligned_kernel": round(u_splice, 3)},
-			"roofline": {"bound": "hbm", "kernel": "splice_unaligned_kernel", "algorithmic_bytes_per_launch": int(alg_u), "achieved": round(alg_u / u_splice / 1e6, 1), "peak": HBM_PEAK_GBS,
-				"unit": "GB/s", "frac": round(alg_u / u_splice / 1e6 / HBM_PEAK_GBS, 4)},
-			"roofline_count_pass": {"bound": "hbm", "kernel": "count_unaligned_kernel+scan_tile_counts_kernel", "algorithmic_bytes_per_launch": int(alg_c), "achieved": round(alg_c / u_count / 1e6, 1),
-				"unit": "GB/s", "note": "reads the shared inputs and the rows' effective-edge bits, writes 4 bytes per (row, 16-KiB tile); builds no row"},
-			"parity": {"rows_checked": len(usample), "bit_exact": u_ok, "method": "row lengths and device checksums against the CPU oracle's unaligned rows"},
+		aligned_ms_per_base = (splice_ms / max(1, launches)) / max(1, batch_rows * L)
+
+		def unaligned_leg(n_u, reps=3):
+			ub = v2m.RowBatch(rows[:n_u])
+			ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True)      # warm-up (builds the second template; first >= 1-GiB launch: calibrates the store flavour)
+			ctx.synchronize()
+			ctx.profile_enable(True)
+			ctx.profile_reset()
+			t_u = time.perf_counter()
+			for _ in range(reps):
+				lengths = ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True, want_lengths=True)
+			ctx.synchronize()
+			wall_u = (time.perf_counter() - t_u) / reps
+			_, u_count = ctx.profile_get(N.KERNEL_UNALIGNED_COUNT)
+			_, u_splice = ctx.profile_get(N.KERNEL_SPLICE_UNALIGNED)
+			_, u_resolve = ctx.profile_get(N.KERNEL_RESOLVE)
+			ctx.profile_enable(False)
+			u_count, u_splice, u_resolve = u_count / reps, u_splice / reps, u_resolve / reps
+			bases_u = int(lengths.sum())
+			# pass 2 (splice_unaligned_kernel): row bytes out + the rows' bit columns + the shared inputs + one tile offset per (row, tile);
+			# pass 1 (count + scan): the shared inputs + bit columns in, the tile counts out and in and out again (scan in place)
+			alg_u = bases_u + n_u * Ep // 8 + shared_bytes + 4 * n_u * n_tiles
+			alg_c = n_u * Ep // 8 + shared_bytes + 3 * 4 * n_u * n_tiles
+			usample = sorted({0, 1, n_u // 2, n_u - 1})
+			ucopies = [c0 + rows[i] for i in usample if rows[i] != v2m.PLOIDY_MAX]
+			uog = oracle_graph(ucopies)
+			ucol = {c: i for i, c in enumerate(ucopies)}
+			uwant, ulen = uog.row_checksums(ds.reference, [oracle.PLOIDY_MAX if rows[i] == v2m.PLOIDY_MAX else ucol[c0 + rows[i]] for i in usample], unaligned=True, threads=len(usample))
+			ugot = np.array([ctx.checksum_rows_device(out_ptr + i * upitch, upitch, 1, length=int(lengths[i]))[0] for i in usample], dtype=np.uint64)
+			u_ok = bool(np.array_equal(ulen, lengths[usample])) and bool(np.array_equal(ugot, uwant))
+			ms_per_base = u_splice / max(1, bases_u)
+			return {
+				"rows": n_u, "bases": bases_u, "footprint_GB": round(n_u * upitch / 1e9, 2),
+				"value": round(bases_u / (u_resolve + u_count + u_splice) / 1e6, 1), "unit": "Gbases/s", "wall_ms_per_batch": round(1e3 * wall_u, 3),
+				"kernels_ms": {"resolve_effective_edges_kernel": round(u_resolve, 3), "count_unaligned_kernel+scan_tile_counts_kernel": round(u_count, 3), "splice_unaligned_kernel": round(u_splice, 3)},
+				"roofline": {"bound": "hbm", "kernel": "splice_unaligned_kernel", "algorithmic_bytes_per_launch": int(alg_u), "achieved": round(alg_u / u_splice / 1e6, 1), "peak": HBM_PEAK_GBS,
+					"unit": "GB/s", "frac": round(alg_u / u_splice / 1e6 / HBM_PEAK_GBS, 4)},
+				"time_per_base_vs_aligned_kernel": round(ms_per_base / aligned_ms_per_base, 3) if aligned_ms_per_base > 0 else None,
+				"roofline_count_pass": {"bound": "hbm", "kernel": "count_unaligned_kernel+scan_tile_counts_kernel", "algorithmic_bytes_per_launch": int(alg_c), "achieved": round(alg_c / u_count / 1e6, 1),
+					"unit": "GB/s", "note": "reads the shared inputs and the rows' effective-edge bits, writes 4 bytes per (row, 16-KiB tile); builds no row"},
+				"parity": {"rows_checked": len(usample), "bit_exact": u_ok, "method": "row lengths and device checksums against the CPU oracle's unaligned rows"},
+			}
+
+		n_full = max(1, min(out_bytes // upitch, n_rows))
+		n_small = max(1, min(args.unaligned_rows, n_full))
+		small = unaligned_leg(n_small)
+		full = unaligned_leg(n_full) if n_full != n_small else small
+		result["unaligned"] = dict(full, metric="unaligned (--unaligned) Gbases/sec, one batch on the aligned leg's output buffer (same ~%.0f-GB address footprint), kernels only" % (out_bytes / 1e9),
+			first_rows_only=small, tuning=ctx.info)
+		for leg in (small, full):
+			if not leg["parity"]["bit_exact"]:
+				log("[bench] PARITY FAILURE (unaligned leg, %d rows) against the CPU oracle" % leg["rows"])
+				result.setdefault("parity", {})["bit_exact"] = False
+
+	# ---- the CPU path beside the GPU transpose ("time the whole matrix on CPU, one call per run") ---------
+	if rank == 0 and world == 1 and args.cpu_transpose and hp_local and "roofline_transpose" in result:
+		import oracle
+		host_src = np.frombuffer(_device_bytes(paths_src.data_ptr(), tr_bytes // 2), dtype=np.uint64)      # copied to the host once, after all GPU timing
+		ctx.transpose_bits_device(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())                # the ABI's dense form: caller-visible destination
+		ctx.synchronize()
+		gpu_dense = np.frombuffer(_device_bytes(paths_dst.data_ptr(), tr_bytes // 2), dtype=np.uint64)
+		t_c = time.perf_counter()
+		cpu_dst = oracle.transpose_matrix(host_src, hp_local, Ep)          # transpose_matrix.cc:41-109's traversal, one thread, -O2
+		secs_c = time.perf_counter() - t_c
+		same = bool(np.array_equal(cpu_dst, gpu_dense))
+		gpu_ms = result["roofline_transpose"]["avg_launch_ms"]
+		result["roofline_transpose"]["cpu_baseline"] = {
+			"seconds": round(secs_c, 3), "value": round(tr_bytes / secs_c / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+			"sample": "the whole %d x %d-bit matrix of this run (%.3f GB read + written), one call of the oracle's v2mo_transpose_matrix (the 8x8-block traversal of transpose_matrix.cc:41-109), including its zero-fill of the destination; host has %d logical CPUs"
+				% (hp_local, Ep, tr_bytes / 1e9, os.cpu_count()),
+			"bit_exact_vs_gpu_dense_form": same, "gpu_over_cpu": round(secs_c * 1e3 / gpu_ms, 1) if gpu_ms > 0 else None,
 		}
-		if not u_ok:
-			log("[bench] PARITY FAILURE (unaligned leg) against the CPU oracle")
+		if not same:
+			log("[bench] PARITY FAILURE: the GPU's dense-form transpose differs from the CPU oracle's")
 			result.setdefault("parity", {})["bit_exact"] = False
+		del host_src, gpu_dense, cpu_dst
 
 	if rank == 0 and world == 1 and args.cpu_baseline_rows:
 		nb = min(args.cpu_baseline_rows, H)
@@ -439,7 +537,8 @@ def main():
 		}
 
 	if rank == 0:
-		print(json.dumps(result), flush=True)
+		result_out.write(json.dumps(result) + "\n")
+		result_out.flush()
 	if world > 1:
 		dist.barrier()
 		dist.destroy_process_group()

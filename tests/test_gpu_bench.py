@@ -40,6 +40,34 @@ def test_bench_line_has_the_contract_fields():
 	assert tr["matrix_bits"][0] % 64 == 0 and tr["matrix_bits"][1] % 64 == 0 and tr["matrix_bits"][0] < 1024   # mini3: 200 copies -> 256, not 1024
 	assert tr["algorithmic_bytes"] == 2 * tr["matrix_bits"][0] * tr["matrix_bits"][1] // 8 and tr["achieved"] > 0
 	assert tr["after_timing"]["involution_bit_exact"] is True and tr["after_timing"]["dense_forward_ms"] > 0
-	un = d["unaligned"]                             # the separately timed --unaligned leg
-	assert un["value"] > 0 and un["parity"]["bit_exact"] is True and un["roofline"]["kernel"] == "splice_unaligned_kernel"
-	assert set(un["kernels_ms"]) == {"resolve_effective_edges_kernel", "count_unaligned_kernel+scan_tile_counts_kernel", "splice_unaligned_kernel"}
+	tc = tr["cpu_baseline"]                         # the CPU path timed beside the GPU transpose, on the same matrix
+	assert tc["kind"] == "port" and tc["cores"] == 1 and tc["seconds"] > 0 and tc["value"] > 0 and tc["unit"] == "GB/s"
+	assert tc["bit_exact_vs_gpu_dense_form"] is True and tc["sample"]
+	un = d["unaligned"]                             # the separately timed --unaligned leg: on the aligned leg's footprint, and on the first rows only
+	for leg in (un, un["first_rows_only"]):
+		assert leg["value"] > 0 and leg["parity"]["bit_exact"] is True and leg["roofline"]["kernel"] == "splice_unaligned_kernel"
+		assert set(leg["kernels_ms"]) == {"resolve_effective_edges_kernel", "count_unaligned_kernel+scan_tile_counts_kernel", "splice_unaligned_kernel"}
+		assert leg["time_per_base_vs_aligned_kernel"] > 0 and leg["footprint_GB"] > 0
+	assert un["rows"] >= un["first_rows_only"]["rows"] and "tuning" in un
+	assert d["config"]["per_rank"] == [{"rank": 0, "rows": d["config"]["rows_total"], "batches": d["parity"]["batches_covered"], "ms_per_step": d["ms_per_step"]}]
+
+
+def test_bench_gpus_2_as_typed_starts_its_own_ranks():
+	"""`python bench.py --gpus 2` with no launcher around it: the parent starts both ranks as child processes (here both on device 0
+	over gloo, the one-GPU rehearsal of the N > 1 path), relays exactly one line on stdout and the ranks' chatter on stderr."""
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--force-device", "0", "--dist-backend", "gloo", "--config", "mini3",
+		"--steps", "2", "--warmup", "1", "--output-candidates", "1", "--batch-rows", "40"],
+		stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT, env=env)
+	assert r.returncode == 0, r.stderr.decode()[-3000:]
+	lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+	assert len(lines) == 1, "exactly one line on stdout: " + repr(lines)[:500]
+	d = json.loads(lines[0])
+	assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["value"] > 0
+	assert d["parity"]["bit_exact"] is True
+	per_rank = d["config"]["per_rank"]
+	assert [p["rank"] for p in per_rank] == [0, 1] and all(p["ms_per_step"] > 0 for p in per_rank)
+	assert sum(p["rows"] for p in per_rank) == d["config"]["rows_total"]
+	assert d["parity"]["batches_covered"] == sum(p["batches"] for p in per_rank) and all(p["batches"] >= 2 for p in per_rank)
+	assert d["ms_per_step"] >= max(p["ms_per_step"] for p in per_rank) - 1e-3      # the line's time is the MAX over ranks
+	assert "cpu_baseline" not in d                                                 # timed on rank 0 at N = 1 only

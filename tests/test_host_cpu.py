@@ -214,3 +214,26 @@ def test_ring_transpose_indexing_model():
 	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "ring_transpose_model.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
 	assert r.returncode == 0, r.stderr.decode()[-2000:]
 	assert b"cases ok" in r.stdout
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+	import subprocess
+	import sys
+	env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+	r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"), "--gpus", "2"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=env)
+	assert r.returncode != 0 and b"WORLD_SIZE (3) != --gpus (2)" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_as_typed_starts_child_ranks_and_relays_their_failure():
+	"""`python bench.py --gpus 2` without WORLD_SIZE starts two child ranks itself (no GPU here: both fail at the first HIP call);
+	the parent must relay the failure as a non-zero exit, print nothing on stdout and never exec over itself."""
+	import subprocess
+	import sys
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+	if os.path.exists("/dev/kfd"):
+		pytest.skip("a GPU is present: the working path is covered by tests/test_gpu_bench.py")
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "mini3", "--dist-backend", "gloo"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+	assert r.returncode != 0 and not r.stdout.strip()
+	assert b"rank 0 -> exit" in r.stderr and b"rank 1 -> exit" in r.stderr
+	with open(os.path.join(ROOT, "bench.py")) as f:
+		assert "os.exec" not in f.read().replace("Never os.exec*", "")
