@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define V2M_ABI_VERSION 2
+#define V2M_ABI_VERSION 3
 
 enum {
 	V2M_OK = 0,
@@ -136,7 +136,6 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *graph, const char *ref_
  * valid and unchanged until the next upload/set or ctx destruction. */
 int v2m_set_paths_device(v2m_ctx *ctx, const void *d_words, uint64_t path_rows, uint64_t path_cols);
 
-/* aligned_positions.back(): the length of every aligned row. 0 before an upload. */
 /* One GPU's share of the path matrix when chromosome copies are sharded over several GPUs (rows are independent,
  * haplotype_output.cc:62-81; the graph and reference are replicated with v2m_upload_graph, the matrix is not).
  * `paths_by_edge_and_chrom_copy` is the WHOLE host-resident transpose input (variant_graph.hh:62: n_rows = chromosome
@@ -150,6 +149,17 @@ int v2m_set_paths_device(v2m_ctx *ctx, const void *d_words, uint64_t path_rows, 
  * back to the host.  The result is owned by the ctx.  Synchronous. */
 int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *paths_by_edge_and_chrom_copy, uint64_t n_rows, uint64_t n_cols, uint64_t first_copy, uint64_t n_copies);
 
+/* The same for a GPU whose chromosome copies are not one contiguous range but every stride_copies-th block of block_copies
+ * copies: copies first_copy + j * stride_copies + [0, block_copies) for j = 0, 1, ..., clipped to copy_end (first_copy,
+ * block_copies and stride_copies multiples of 8).  Column l of the bound matrix is copy
+ * first_copy + (l / block_copies) * stride_copies + l % block_copies, and row batches for this ctx use those local indices.
+ * This is how several GPUs share an output that has to leave in row order (a pipe, an unaligned A2M file,
+ * haplotype_output.cc:62-81 with sequence_writer.cc:80): with blocks dealt round-robin, GPU k produces rows
+ * k * block, ..., then (k + G) * block, ... while the others produce the blocks in between, and a single writer can drain
+ * them in order from buffers that hold a few rows per GPU; contiguous shards would leave all but one GPU waiting.
+ * v2m_upload_path_slice(first, n) is the one-block case.  Synchronous. */
+int v2m_upload_path_blocks(v2m_ctx *ctx, const uint64_t *paths_by_edge_and_chrom_copy, uint64_t n_rows, uint64_t n_cols, uint64_t first_copy, uint64_t block_copies, uint64_t stride_copies, uint64_t copy_end);
+
 /* The same for a transpose input that already lives in HBM (n_rows copies x n_cols edges, dense column-major words as
  * above, e.g. generated or assembled on the device): transposes it into a ctx-owned copy of paths_by_chrom_copy_and_edge and
  * binds that -- the one-call form of v2m_transpose_bits_device() + v2m_set_paths_device().  The owned copy is laid out for
@@ -158,6 +168,7 @@ int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *paths_by_edge_and_chrom_
  * has finished (v2m_ctx_synchronize()). */
 int v2m_bind_path_matrix_device(v2m_ctx *ctx, const void *d_paths_by_edge_and_chrom_copy, uint64_t n_rows, uint64_t n_cols);
 
+/* aligned_positions.back(): the length of every aligned row. 0 before an upload. */
 uint64_t v2m_aligned_length(const v2m_ctx *ctx);
 /* The row pitch the library itself uses in aligned mode (aligned length rounded up to 256: rows then start on
  * 256-B boundaries).  v2m_splice_rows_device accepts any multiple of 16 that is >= the aligned length rounded up to 16. */

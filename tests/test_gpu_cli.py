@@ -157,10 +157,57 @@ def test_sharded_output_over_several_contexts(tmp_path):
 	r = run(["-F", "7", "-r", fa, "-a", vcf, "-c", "1", "-s", str(three), "--dst-chromosome=chrQ", "--device=0,0"])
 	assert r.returncode == 0, r.stderr.decode()
 	assert one.read_bytes() == three.read_bytes() and one.read_bytes().count(b">chrQ\t") == 8
-	# unaligned output falls back to the first context
-	assert run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(three), "--unaligned", "--device=0,0"]).returncode == 0
+
+
+def test_ordered_outputs_over_several_contexts(tmp_path):
+	"""--unaligned, --pipe and --output-sequences-separate with --device=0,0,0: the outputs that have to leave in row order
+	(sequence_writer.cc:80, output.cc:47-76, haplotype_output.cc:85-132).  The chromosome copies are dealt to the contexts
+	round-robin in blocks of 8 (no context holds the whole matrix), every context splices its rows on its own thread and the
+	rows reach the one writer in turns: byte-identical to one context."""
+	g = synth.build_case(tmp_path, 66, 150000, 2200, 27, long_every=300)           # 54 copies: 7 blocks of 8, the last one short
+	fa, vcf = str(tmp_path / "synth.fa"), str(tmp_path / "synth.vcf")
+	common = ["-H", "-r", fa, "-a", vcf, "-c", "1"]
+	one, three, exp = tmp_path / "one.fa", tmp_path / "three.fa", tmp_path / "exp.fa"
+	env_small_slots = dict(os.environ, V2M_RING_SLOT_BYTES=str(400000))              # 2 rows per slice: many slices per context, turns in the middle of them
+	# unaligned A2M file
 	g.haplotype_output_a2m(g.ref, str(exp), unaligned=True)
-	assert three.read_bytes() == exp.read_bytes()
+	assert run(common + ["-s", str(one), "--unaligned"]).returncode == 0
+	r = run(common + ["-s", str(three), "--unaligned", "--device=0,0,0", "--verbose"])
+	assert r.returncode == 0, r.stderr.decode()
+	assert one.read_bytes() == exp.read_bytes() == three.read_bytes()
+	for k in range(3):
+		assert ("GPU context %d (device 0): chromosome copies %d + 24 j + [0, 8), j = 0, 1, ..." % (k, 8 * k)).encode() in r.stderr, r.stderr.decode()
+	three.unlink()
+	r = subprocess.run([CLI] + common + ["-s", str(three), "--unaligned", "--device=0,0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env_small_slots)
+	assert r.returncode == 0 and three.read_bytes() == exp.read_bytes()
+	# more contexts than blocks; no REF row
+	g.haplotype_output_a2m(g.ref, str(exp), unaligned=True, output_reference=False)
+	r = run(common + ["-s", str(three), "--unaligned", "--omit-reference", "--device=0,0,0,0,0,0,0,0,0"])
+	assert r.returncode == 0 and three.read_bytes() == exp.read_bytes()
+	# aligned, through a pipe
+	script = tmp_path / "sink.sh"
+	script.write_text("#!/bin/sh\ncat > \"$1.piped\"\n")
+	script.chmod(0o755)
+	g.haplotype_output_a2m(g.ref, str(exp))
+	r = subprocess.run([CLI] + common + ["-s", str(tmp_path / "p.a2m"), "--pipe=" + str(script), "--device=0,0,0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env_small_slots)
+	assert r.returncode == 0, r.stderr.decode()
+	assert (tmp_path / "p.a2m.piped").read_bytes() == exp.read_bytes()
+	# a reader that goes away must end the run (every context's thread), not hang it
+	quitter = tmp_path / "quit.sh"
+	quitter.write_text("#!/bin/sh\nhead -c 10 > /dev/null\nexit 3\n")
+	quitter.chmod(0o755)
+	r = run(common + ["-s", str(tmp_path / "x.a2m"), "--pipe=" + str(quitter), "--device=0,0,0"])
+	assert r.returncode != 0 and b"exited with status 3" in r.stderr
+	# one file per sequence (and the aligned A2M file in the same run: then it is written in turns as well)
+	(tmp_path / "a").mkdir(); (tmp_path / "b").mkdir()
+	assert run(common + ["--output-sequences-separate", "-s", "all.a2m"], cwd=str(tmp_path / "a")).returncode == 0
+	r = run(common + ["--output-sequences-separate", "-s", "all.a2m", "--device=0,0,0"], cwd=str(tmp_path / "b"))
+	assert r.returncode == 0, r.stderr.decode()
+	names = sorted(os.listdir(tmp_path / "a"))
+	assert len(names) == 56 and sorted(os.listdir(tmp_path / "b")) == names
+	for n in names:
+		assert (tmp_path / "b" / n).read_bytes() == (tmp_path / "a" / n).read_bytes(), n
+	assert (tmp_path / "b" / "all.a2m").read_bytes() == exp.read_bytes()
 
 
 def test_graph_checkpoint(tmp_path):

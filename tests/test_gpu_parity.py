@@ -70,7 +70,9 @@ def test_transpose_fixed(ctx, case):   # tests/transpose_matrix.cc:188-251
 	assert np.array_equal(ctx.transpose_matrix(src, case["rows"], case["cols"]), exp)
 
 
-TRANSPOSE_KERNELS = ["8x8", "stream16", "4x16", "8x8/rr", "ring:16,8,8,4,16", "ring:16,8,8,4,64,slow", "ring:8,4,8,4,8", "ring:16,8,4,4,64", "ring:16,8,16,4,32", "ring:16,16,8,8,64/rr", "ring:8,8,8,8,64", "ring:8,8,8,8,128,nt", "ring:8,8,8,16,24/sf"]
+# every kernel of the product build, with the dispatch-order switches (the other shapes and flavours exist in the tuning build
+# only: tests/test_gpu_tuning_build.py)
+TRANSPOSE_KERNELS = ["8x8", "stream16", "8x8/rr", "stream16/pf", "ring:8,8,8,8,64", "ring:8,8,8,8,128", "ring:8,8,8,8,24/sf", "ring:8,8,8,8,8/rr"]
 
 
 @pytest.mark.parametrize("kernel", TRANSPOSE_KERNELS)
@@ -106,6 +108,17 @@ def test_transpose_writes_only_the_destination(ctx, monkeypatch, kernel, h, w):
 	host = d_dst.cpu().numpy().view(np.uint64)
 	assert (host[:guard] == 0x5A5A5A5A5A5A5A5A).all() and (host[guard + n:] == 0x5A5A5A5A5A5A5A5A).all()
 	assert np.array_equal(host[guard:guard + n], oracle.transpose_matrix(src, rows, cols, naive=True))
+
+
+def test_product_build_has_no_tuning_kernels(ctx, v2m, monkeypatch):
+	"""The shapes that were only ever measured are not compiled into libv2m_hip.so; asking for one is an error, not a fallback."""
+	monkeypatch.setenv("V2M_TRANSPOSE_PANEL", "ring:16,8,8,4,64")
+	with pytest.raises(v2m.V2MError) as e:
+		ctx.transpose_matrix(np.zeros(64, np.uint64), 64, 64)
+	assert e.value.code == 1 and "V2M_TUNING_BUILD" in str(e.value)
+	monkeypatch.setenv("V2M_TRANSPOSE_PANEL", "4x16")
+	with pytest.raises(v2m.V2MError):
+		ctx.transpose_matrix(np.zeros(64, np.uint64), 64, 64)
 
 
 def test_transpose_edge_cases(ctx, v2m):
@@ -565,7 +578,7 @@ def test_path_slices_reproduce_every_row(ctx, v2m, tmp_path, world):
 	assert [got[r] for r in range(n_copies + 1)] == expected
 
 
-@pytest.mark.parametrize("kernel", ["", "8x8", "stream16", "ring:8,8,8,8,64", "ring:8,8,8,8,128/sf", "ring:16,8,8,4,16"])
+@pytest.mark.parametrize("kernel", ["", "8x8", "stream16", "ring:8,8,8,8,64", "ring:8,8,8,8,128/sf"])
 def test_bind_path_matrix_device(ctx, v2m, tmp_path, monkeypatch, kernel):
 	"""v2m_bind_path_matrix_device: a device-resident transpose input becomes the context's own (line-aligned) path matrix;
 	every transpose kernel with a destination pitch that differs from the word count."""
@@ -591,6 +604,41 @@ def test_bind_path_matrix_device(ctx, v2m, tmp_path, monkeypatch, kernel):
 		ctx.bind_path_matrix_device(d_src.data_ptr(), hp, 64)                     # fewer edge columns than the graph has edges
 	with pytest.raises(v2m.V2MError):
 		ctx.bind_path_matrix_device(d_src.data_ptr(), hp - 1, ep)
+
+
+@pytest.mark.parametrize("world,block", [(2, 8), (3, 8), (3, 16), (5, 24), (9, 8)])
+def test_path_blocks_dealt_round_robin(v2m, tmp_path, world, block):
+	"""v2m_upload_path_blocks: every world-th block of `block` chromosome copies on one context; together the contexts
+	reproduce every row (local copy l = global first + (l // block) * stride + l % block), and a context refuses copies beyond
+	its share."""
+	g = synth.build_case(tmp_path, 97, 30000, 500, 43)                 # 86 copies -> 128 rows
+	hp, ep = g.paths_by_edge_and_chrom_copy_dims
+	n_copies = g.total_chromosome_copies
+	expected = [g.output_sequence(g.ref, copy_index=c) for c in range(n_copies)]
+	vg = v2m.VariantGraph.from_object(g)
+	vg.paths_by_chrom_copy_and_edge = None
+	seen = 0
+	for rank in range(world):
+		with v2m.Context(0) as ctx:
+			ctx.upload_graph(vg, g.ref)
+			ctx.upload_path_blocks(g.paths_by_edge_and_chrom_copy, hp, ep, block * rank, block, block * world)
+			mine = [c for c in range(n_copies) if (c // block) % world == rank]
+			local = [(c // (block * world)) * block + c % block for c in mine]
+			assert local == sorted(local)
+			if mine:
+				got = ctx.splice_rows(local)
+				assert got == [expected[c] for c in mine]
+				assert ctx.splice_rows(local[:3], unaligned=True) == [g.output_sequence(g.ref, copy_index=c, unaligned=True) for c in mine[:3]]
+			n_local = len([c for c in range(hp) if (c // block) % world == rank])
+			with pytest.raises(v2m.V2MError):
+				ctx.splice_rows([64 * ((n_local + 63) // 64)])
+			seen += len(mine)
+	assert seen == n_copies
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(vg, g.ref)
+		for bad in ((4, 8, 16), (0, 12, 24), (0, 8, 20), (0, 16, 8), (0, 0, 8)):
+			with pytest.raises(v2m.V2MError):
+				ctx.upload_path_blocks(g.paths_by_edge_and_chrom_copy, hp, ep, *bad)
 
 
 def test_path_slice_edges(ctx, v2m, tmp_path):

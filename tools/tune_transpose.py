@@ -10,6 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the shapes beyond the product's three exist in the tuning build only (vcf2multialign_amd/build.py)
+os.environ.setdefault("V2M_HIP_LIBRARY", os.path.join(ROOT, "vcf2multialign_amd", "libv2m_hip_tuning.so"))
 import torch  # noqa: E402
 
 import vcf2multialign_amd as v2m  # noqa: E402

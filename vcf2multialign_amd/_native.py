@@ -23,7 +23,7 @@ V2M_SPLICE_UNALIGNED = 0x1
 
 KERNEL_TRANSPOSE, KERNEL_RESOLVE, KERNEL_SPLICE_ALIGNED, KERNEL_SPLICE_UNALIGNED, KERNEL_TEMPLATE, KERNEL_UNALIGNED_COUNT = range(6)
 KERNEL_NAMES = ["transpose_bits_kernel", "resolve_effective_edges_kernel", "splice_aligned_kernel", "splice_unaligned_kernel", "expand_reference_row_kernel", "count_unaligned_kernel"]
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GraphView(C.Structure):
@@ -59,6 +59,7 @@ SIGNATURES = {
 	"v2m_upload_graph": (C.c_int, [C.c_void_p, C.POINTER(GraphView), C.c_void_p, C.c_uint64]),
 	"v2m_set_paths_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
 	"v2m_upload_path_slice": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
+	"v2m_upload_path_blocks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64]),
 	"v2m_bind_path_matrix_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64]),
 	"v2m_aligned_length": (C.c_uint64, [C.c_void_p]),
 	"v2m_min_row_pitch": (C.c_uint64, [C.c_void_p]),
@@ -78,7 +79,8 @@ _lib = None
 
 
 def library_path():
-	return _build.LIB_PATH
+	"""The product library; V2M_HIP_LIBRARY names another build of the same sources (the tuning build, tools and tests only)."""
+	return os.environ.get("V2M_HIP_LIBRARY") or _build.LIB_PATH
 
 
 def load():

@@ -1,6 +1,9 @@
 """Builds the native pieces in-tree (the .so files travel to the GPU box with the snapshot).
 
-  libv2m_hip.so   -- the product: HIP kernels + C ABI (include/v2m_hip.h), gfx950 only.
+  libv2m_hip.so          -- the product: HIP kernels + C ABI (include/v2m_hip.h), gfx950 only.
+  libv2m_hip_tuning.so   -- the same sources with -DV2M_TUNING_BUILD: every transpose shape / flavour that was measured on
+                            the way to the three the product ships.  Loaded only by tools/tune_transpose.py and
+                            tests/test_gpu_tuning_build.py (V2M_HIP_LIBRARY); nothing in the product path uses it.
 
 hipcc cross-compiles for gfx950 without a GPU present.
 """
@@ -19,6 +22,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libv2m_hip.so")
 HIP_SOURCES = [os.path.join(CSRC, "v2m_hip.hip")]
 HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "kernels.hpp"), os.path.join(ROOT, "include", "v2m_hip.h")]
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra"]
+TUNING_LIB_PATH = os.path.join(PKG_DIR, "libv2m_hip_tuning.so")
 
 # synthetic-input generator (bench + scale tests): host generator + the HIP kernel filling genotype bits
 SYNTH_LIB_PATH = os.path.join(PKG_DIR, "libv2m_synth.so")
@@ -87,13 +91,13 @@ def _build_host(force, verbose):
 		_link([cxx] + CXX_FLAGS, CLI_PATH, CLI_SOURCES + ["-L" + PKG_DIR, "-lv2m_host", "-lv2m_hip", "-Wl,-rpath,$ORIGIN/.."], verbose)
 
 
-def _build(target, sources, deps, force, verbose):
+def _build(target, sources, deps, force, verbose, extra_flags=()):
 	if not force and not _stale(target, deps):
 		return target
 	hipcc = find_hipcc()
 	if hipcc is None:
 		raise RuntimeError("hipcc not found: cannot build " + target)
-	_link([hipcc] + HIPCC_FLAGS, target, sources, verbose)
+	_link([hipcc] + HIPCC_FLAGS + list(extra_flags), target, sources, verbose)
 	return target
 
 
@@ -102,5 +106,6 @@ def build_native(force=False, verbose=False):
 	with _build_lock():
 		_build(SYNTH_LIB_PATH, SYNTH_SOURCES, SYNTH_DEPS, force, verbose)
 		_build(LIB_PATH, HIP_SOURCES, HIP_DEPS, force, verbose)
+		_build(TUNING_LIB_PATH, HIP_SOURCES, HIP_DEPS, force, verbose, ["-DV2M_TUNING_BUILD"])
 		_build_host(force, verbose)
 	return LIB_PATH

@@ -134,6 +134,15 @@ class Context:
 		n_copies = n_rows - first_copy if n_copies is None else n_copies
 		self._check(self._lib.v2m_upload_path_slice(self._h, words.ctypes.data if words.size else None, n_rows, n_cols, first_copy, n_copies))
 
+	def upload_path_blocks(self, paths_by_edge_and_chrom_copy, n_rows, n_cols, first_copy, block_copies, stride_copies, copy_end=None):
+		"""v2m_upload_path_blocks: every stride_copies-th block of block_copies chromosome copies from first_copy on (up to copy_end):
+		the share of one of several GPUs whose rows have to leave in row order.  Local copy l = global copy
+		first_copy + (l // block_copies) * stride_copies + l % block_copies."""
+		words = np.ascontiguousarray(paths_by_edge_and_chrom_copy, dtype=np.uint64)
+		assert words.size == n_rows // 64 * n_cols
+		self._check(self._lib.v2m_upload_path_blocks(self._h, words.ctypes.data if words.size else None, n_rows, n_cols, first_copy, block_copies, stride_copies,
+			n_rows if copy_end is None else copy_end))
+
 	@property
 	def aligned_length(self):
 		return self._lib.v2m_aligned_length(self._h)

@@ -51,6 +51,14 @@ void upload_path_slice(gpu_context &gpu, variant_graph const &g, copy_shard shar
 }
 
 
+void upload_path_blocks(gpu_context &gpu, variant_graph const &g, copy_interleave deal, u32 rank)
+{
+	auto const &m(g.paths_by_edge_and_chrom_copy);
+	u64 const first(std::min<u64>(m.rows, deal.block * rank));
+	gpu.check(v2m_upload_path_blocks(gpu.get(), m.words.empty() ? nullptr : m.words.data(), m.rows, m.cols, first, deal.block, deal.block * deal.world, m.rows));
+}
+
+
 void warm_up_sink(gpu_context &gpu, bool unaligned)
 {
 	// six REF rows into a sink that drops them: more than one slice of the sink path's default 512-MB slots whenever two

@@ -53,4 +53,16 @@ copy_shard shard_copies(u64 n_copies, u32 world, u32 rank);
 // indices relative to `first`.  Nothing comes back to the host.
 void upload_path_slice(gpu_context &gpu, variant_graph const &graph, copy_shard shard);
 
+// Chromosome copies dealt to `world` GPUs in blocks of `block` copies, round-robin (v2m_upload_path_blocks): GPU `rank` owns the
+// copies c with (c / block) % world == rank.  This is the sharding for outputs that have to leave in row order -- pipes,
+// unaligned A2M, one file per sequence with a delegate that counts them -- where contiguous shards would leave all GPUs but
+// one waiting for their turn: with blocks dealt round-robin every GPU always has rows that are due soon.
+struct copy_interleave {
+	u64 block{8};     // copies per block: a multiple of 8 (whole bytes of the bit-packed columns)
+	u32 world{1};
+	u32 owner(u64 copy) const { return u32((copy / block) % world); }
+	u64 local(u64 copy) const { return (copy / (block * world)) * block + copy % block; }   // the copy's index in its owner's matrix
+};
+void upload_path_blocks(gpu_context &gpu, variant_graph const &graph, copy_interleave deal, u32 rank);
+
 } // namespace v2m::host

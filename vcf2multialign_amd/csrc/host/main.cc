@@ -11,6 +11,7 @@
 #include <cstring>
 #include <fstream>
 #include <future>
+#include <thread>
 #include <iostream>
 #include <memory>
 #include <set>
@@ -188,6 +189,12 @@ struct progress_delegate final : vh::output_delegate {
 int main(int argc, char **argv)
 {
 	::signal(SIGPIPE, SIG_IGN);   // main.cc:372: a --pipe child that goes away shows up as a write error
+	// A command-line run is one shot: the library's per-context calibrations (which transpose kernel for a matrix shape, plain
+	// or nontemporal row stores: a handful of extra launches each) have nothing to amortise over, so the driver presets what
+	// they choose on nearly every box.  A value already in the environment wins.
+	::setenv("V2M_TRANSPOSE_PANEL", "stream16", 0);
+	::setenv("V2M_NT_STORES", "1", 0);
+	::setenv("V2M_UNALIGNED_STORE", "plain", 0);
 	options opt;
 	enum { o_keep_ref = 900, o_separate = 1000, o_sep_format, o_omit_ref, o_unaligned, o_overlaps, o_stats, o_mismatch, o_include, o_device, o_verbose, o_pipe, o_unsupported };
 	static option const longopts[] = {
@@ -336,14 +343,20 @@ int main(int argc, char **argv)
 			std::cout << "Total ploidy: " << graph.total_chromosome_copies() << '\n';
 		}
 
-		// Graph and reference are replicated on every GPU; the path matrix is not: with several GPUs
-		// and an aligned A2M file as the only output, GPU k receives the bits of its own chromosome copies only, transposes
-		// them itself and splices the rows of those copies.  Every other combination (one GPU, pipes, unaligned or separate
-		// output) needs the whole matrix on the GPU that writes a row; founder rows read copies all over the matrix.
+		// Graph and reference are replicated on every GPU; the path matrix is not.  With several GPUs, GPU k
+		// receives the bits of its own chromosome copies only, transposes them itself and splices the rows of those copies:
+		//  - an aligned A2M file as the only output: contiguous blocks of copies, every GPU's thread writes its rows at their
+		//    final file offsets (all aligned rows have the same length);
+		//  - every output that has to leave in row order (pipes, unaligned A2M, one file per sequence): the copies dealt
+		//    round-robin in blocks of 8, so that every GPU always has rows that are due soon, handed to the writer in turns.
+		// Founder rows read copies all over the matrix: every GPU then holds all of it.
 		vh::gpu_context &gpu(first_gpu());
 		std::vector<vh::gpu_context *> all_gpus;
 		for (auto &g : contexts) all_gpus.push_back(g.get());
-		bool const sharded(opt.haplotypes && all_gpus.size() > 1 && opt.output_sequences_a2m && !opt.pipe && !opt.unaligned && !opt.output_sequences_separate);
+		bool const several(opt.haplotypes && all_gpus.size() > 1);
+		bool const sharded(several && opt.output_sequences_a2m && !opt.pipe && !opt.unaligned && !opt.output_sequences_separate);
+		bool const interleaved(several && !sharded);
+		vh::copy_interleave const deal{8, vh::u32(all_gpus.size())};
 		std::vector<vh::copy_shard> shards;
 		std::future<void> founder_graph_uploaded;
 		if (opt.founder_mode)   // the host-transposed matrix (the search needs it on the host anyway), uploaded while the search runs
@@ -351,16 +364,29 @@ int main(int argc, char **argv)
 				for (auto *g : all_gpus) vh::upload_graph(*g, ref_seq, graph, true);
 				for (auto *g : all_gpus) vh::warm_up_sink(*g, opt.unaligned);       // ... and the output path's buffers set up meanwhile
 			});
-		for (std::size_t k(0); k < all_gpus.size() && !opt.founder_mode; ++k) {
-			vh::upload_graph(*all_gpus[k], ref_seq, graph, false);
-			vh::copy_shard const shard(sharded
-				? vh::shard_copies(graph.total_chromosome_copies(), vh::u32(all_gpus.size()), vh::u32(k))
-				: vh::copy_shard{0, graph.paths_by_edge_and_chrom_copy.rows});
-			vh::upload_path_slice(*all_gpus[k], graph, shard);
-			if (sharded) {
-				shards.push_back(shard);
-				if (opt.verbose) std::cerr << "GPU context " << k << " (device " << opt.devices[k] << "): chromosome copies [" << shard.first << ", " << shard.end << ")\n";
+		if (!opt.founder_mode) {
+			// every context's graph and matrix share go up on that context's own thread (one PCIe link each)
+			std::vector<std::exception_ptr> upload_errors(all_gpus.size());
+			std::vector<std::thread> uploaders;
+			for (std::size_t k(0); k < all_gpus.size(); ++k) {
+				vh::copy_shard const shard(sharded
+					? vh::shard_copies(graph.total_chromosome_copies(), vh::u32(all_gpus.size()), vh::u32(k))
+					: vh::copy_shard{0, graph.paths_by_edge_and_chrom_copy.rows});
+				if (sharded) shards.push_back(shard);
+				if (opt.verbose && sharded) std::cerr << "GPU context " << k << " (device " << opt.devices[k] << "): chromosome copies [" << shard.first << ", " << shard.end << ")\n";
+				if (opt.verbose && interleaved) std::cerr << "GPU context " << k << " (device " << opt.devices[k] << "): chromosome copies " << deal.block * k << " + " << deal.block * deal.world << " j + [0, " << deal.block << "), j = 0, 1, ...\n";
+				uploaders.emplace_back([&, k, shard] {
+					try {
+						vh::upload_graph(*all_gpus[k], ref_seq, graph, false);
+						if (interleaved) vh::upload_path_blocks(*all_gpus[k], graph, deal, vh::u32(k));
+						else vh::upload_path_slice(*all_gpus[k], graph, shard);
+					} catch (...) {
+						upload_errors[k] = std::current_exception();
+					}
+				});
 			}
+			for (auto &u : uploaders) u.join();
+			for (auto const &e : upload_errors) if (e) std::rethrow_exception(e);
 		}
 		progress_delegate delegate;
 		delegate.verbose = opt.verbose;
@@ -381,6 +407,7 @@ int main(int argc, char **argv)
 			vh::haplotype_output output(gpu, opt.pipe, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);
 			for (std::size_t k(1); k < all_gpus.size(); ++k) output.add_gpu(*all_gpus[k]);
 			if (sharded) output.set_copy_shards(shards);
+			if (interleaved) output.set_copy_interleave(deal);
 			do_output(output);
 		} else {                                            // main.cc:487-550
 			vh::founder_sequence_greedy_output output(gpu, opt.pipe, opt.dst_chromosome, !opt.omit_reference, opt.unaligned, delegate);

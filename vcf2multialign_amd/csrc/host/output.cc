@@ -6,8 +6,10 @@
 #include <unistd.h>
 
 #include <cerrno>
+#include <condition_variable>
 #include <cstring>
 #include <exception>
+#include <mutex>
 #include <fstream>
 #include <stdexcept>
 #include <streambuf>
@@ -158,8 +160,90 @@ std::string output::prefixed(std::string const &name, char sep) const
 }
 
 
+namespace {
+	// Lets the contexts' sink calls through in row order.  A context whose row is not due waits inside its sink call; the
+	// library meanwhile keeps filling that context's other pinned slot, so the wait costs nothing but the turn itself.
+	struct turnstile {
+		std::mutex mutex;
+		std::condition_variable turn;
+		std::uint64_t next_row{};
+		bool failed{};
+	};
+
+	struct turn_state {
+		turnstile *gate;
+		std::vector<std::uint64_t> const *global_row;   // of each row of this context's batch
+		v2m_sink_fn sink;
+		void *user;
+	};
+
+	int turn_sink(void *user, uint64_t row, char const *bytes, uint64_t length)
+	{
+		auto &st(*static_cast<turn_state *>(user));
+		std::uint64_t const global((*st.global_row)[row]);
+		std::unique_lock<std::mutex> lock(st.gate->mutex);
+		st.gate->turn.wait(lock, [&] { return st.gate->failed || st.gate->next_row == global; });
+		if (st.gate->failed) return 1;
+		int const rc(st.sink(st.user, global, bytes, length));   // (under the lock: one writer at a time, in order)
+		if (rc) st.gate->failed = true; else ++st.gate->next_row;
+		lock.unlock();
+		st.gate->turn.notify_all();
+		return rc;
+	}
+}
+
+
+// splice() over several contexts that hold the chromosome copies dealt round-robin (set_copy_interleave): the sink sees the
+// rows in the batch's order, exactly as from one context.
+void output::splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user)
+{
+	if (rows.any_cuts) throw std::runtime_error("rows that switch copies need the whole path matrix on their GPU");
+	std::vector<gpu_context *> gpus{&m_gpu};
+	gpus.insert(gpus.end(), m_more_gpus.begin(), m_more_gpus.end());
+	std::size_t const g(gpus.size());
+	if (m_copy_interleave.world != g) throw std::runtime_error("the copy interleave was made for another number of GPU contexts");
+	std::vector<std::vector<std::uint32_t>> local_copy(g);
+	std::vector<std::vector<std::uint64_t>> global_row(g);
+	for (std::uint64_t i(0); i < rows.copy_index.size(); ++i) {
+		std::uint32_t const c(rows.copy_index[i]);
+		bool const is_ref(V2M_PLOIDY_MAX == c);
+		std::size_t const k(is_ref ? 0 : m_copy_interleave.owner(c));          // the REF row needs no path bits: first context
+		local_copy[k].push_back(is_ref ? c : std::uint32_t(m_copy_interleave.local(c)));
+		global_row[k].push_back(i);
+	}
+	turnstile gate;
+	std::vector<std::exception_ptr> errors(g);
+	std::vector<std::thread> threads;
+	for (std::size_t k(0); k < g; ++k) {
+		threads.emplace_back([&, k] {
+			try {
+				if (local_copy[k].empty()) return;
+				v2m_row_batch batch{};
+				batch.n_rows = local_copy[k].size();
+				batch.copy_index = local_copy[k].data();
+				turn_state st{&gate, &global_row[k], sink, user};
+				gpus[k]->check(v2m_splice_rows(gpus[k]->get(), &batch, m_should_output_unaligned ? V2M_SPLICE_UNALIGNED : 0u, turn_sink, &st));
+			} catch (...) {
+				errors[k] = std::current_exception();
+				{ std::lock_guard<std::mutex> const lock(gate.mutex); gate.failed = true; }   // nobody waits for this context's rows any longer
+				gate.turn.notify_all();
+			}
+		});
+	}
+	for (auto &t : threads) t.join();
+	// the first error in context order that is not just "my sink was told to stop"
+	for (auto const &e : errors) {
+		if (!e) continue;
+		try { std::rethrow_exception(e); }
+		catch (gpu_error const &ge) { if (V2M_ERR_SINK != ge.code) throw; }
+	}
+	for (auto const &e : errors) if (e) std::rethrow_exception(e);
+}
+
+
 void output::splice(row_set const &rows, v2m_sink_fn sink, void *user)
 {
+	if (m_interleaved && !m_more_gpus.empty()) { splice_in_turns(rows, sink, user); return; }
 	v2m_row_batch batch{};
 	batch.n_rows = rows.copy_index.size();
 	batch.copy_index = rows.copy_index.data();
@@ -385,7 +469,7 @@ void output::output_a2m(variant_graph const &graph, char const *dst_name)       
 		if (!good) throw std::runtime_error(std::string("error while writing to the subprocess for ") + dst_name);
 		return;
 	}
-	if (!m_more_gpus.empty() && !m_should_output_unaligned) {
+	if (!m_more_gpus.empty() && !m_should_output_unaligned && !m_interleaved) {
 		write_a2m_sharded(a2m_rows(graph), dst_name);
 		return;
 	}

@@ -50,6 +50,13 @@ public:
 	// copy, with the copy index re-based to the shard (the REF row to the first context).  Without shards every context is
 	// expected to hold the whole matrix and rows are split evenly.
 	void set_copy_shards(std::vector<copy_shard> shards) { m_copy_shards = std::move(shards); }
+
+	// The other way to share the path matrix, for every output that has to leave in row order (std::ostream targets: pipes,
+	// unaligned A2M; one file per sequence): the contexts hold the chromosome copies dealt round-robin in blocks
+	// (upload_path_blocks()), every context splices ITS rows on its own thread, and the rows are handed to the one writer in
+	// row order straight from the contexts' pinned buffers (no copy, no queue: a turnstile on the row index).  While one
+	// context's rows are being written, the others' next blocks are crossing PCIe.
+	void set_copy_interleave(copy_interleave deal) { m_copy_interleave = deal; m_interleaved = true; }
 	virtual void output_a2m(variant_graph const &graph, std::ostream &stream) = 0;
 
 protected:
@@ -61,6 +68,7 @@ protected:
 		bool any_cuts{};
 	};
 	void splice(row_set const &rows, v2m_sink_fn sink, void *user);
+	void splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user);
 	static std::vector<std::uint32_t> rebased_copies(row_set const &rows, std::uint64_t first, std::uint64_t last, copy_shard shard);
 	void write_a2m(row_set const &rows, std::ostream &stream);
 	void write_a2m_sharded(row_set const &rows, char const *dst_name);
@@ -71,6 +79,8 @@ protected:
 	gpu_context &m_gpu;
 	std::vector<gpu_context *> m_more_gpus;
 	std::vector<copy_shard> m_copy_shards;
+	copy_interleave m_copy_interleave;
+	bool m_interleaved{};
 	char const *m_pipe_cmd{};
 	char const *m_chromosome_id{};
 	output_delegate *m_delegate{};

@@ -276,6 +276,12 @@ int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP
 // Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "ring:R,W,S,D[,K[,slow|nt]]" (slow = ds_bpermute
 // butterfly, nt = nontemporal loads and stores); trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks, "/pf" / "/sf" make the row
 // panels / the column panels (spans) run fastest in item order instead of the shorter dimension.
+#ifdef V2M_TUNING_BUILD
+constexpr bool kTuningBuild = true;
+#else
+constexpr bool kTuningBuild = false;
+#endif
+
 int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst)
 {
 	bool xcd(true);
@@ -295,24 +301,33 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		int const got(std::sscanf(shape.c_str() + 5, "%d,%d,%d,%d,%d,%15s", &R, &W, &S, &D, &K, tail));
 		if (got < 4) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
 		bool const fast(0 != std::strcmp(tail, "slow")), nt(0 == std::strcmp(tail, "nt"));
+		// The product build holds the kernels the library picks among (kTransposeCandidates): 8x8, stream16 and ring:8,8,8,8.  The other
+		// shapes and flavours measured on the way there (tools/tune_transpose.py) are compiled with -DV2M_TUNING_BUILD
+		// only (vcf2multialign_amd/libv2m_hip_tuning.so, loaded with V2M_HIP_LIBRARY by the tuning tool and the variant tests).
+#define V2M_RING_FLAVOUR(r, w, s, d, f, n) launch_transpose_ring<r, w, s, d, f, n>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order)
+#ifdef V2M_TUNING_BUILD
 #define V2M_RING(r, w, s, d)                                                                                         \
 		if (R == r && W == w && S == s && D == d)                                                                    \
-			return !fast ? launch_transpose_ring<r, w, s, d, false, false>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order) \
-				: nt ? launch_transpose_ring<r, w, s, d, true, true>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order)      \
-				     : launch_transpose_ring<r, w, s, d, true, false>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
+			return !fast ? V2M_RING_FLAVOUR(r, w, s, d, false, false) : nt ? V2M_RING_FLAVOUR(r, w, s, d, true, true) : V2M_RING_FLAVOUR(r, w, s, d, true, false);
 		V2M_RING(16, 8, 8, 4) V2M_RING(16, 16, 8, 8) V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4)
 		V2M_RING(8, 4, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 8, 4) V2M_RING(8, 8, 8, 8) V2M_RING(8, 8, 8, 16)
 #undef V2M_RING
-		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not instantiated", shape.c_str());
+#else
+		if (R == 8 && W == 8 && S == 8 && D == 8 && fast && !nt) return V2M_RING_FLAVOUR(8, 8, 8, 8, true, false);
+#endif
+#undef V2M_RING_FLAVOUR
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (the product build has 8x8, stream16 and ring:8,8,8,8; the rest needs -DV2M_TUNING_BUILD)");
 	}
 	if (shape == "stream16") return launch_transpose_stream(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+#ifdef V2M_TUNING_BUILD
 	if (shape == "4x16") return launch_transpose_shape<4, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "16x8") return launch_transpose_shape<16, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "16x4") return launch_transpose_shape<16, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "4x8") return launch_transpose_shape<4, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "8x4") return launch_transpose_shape<8, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "8x16") return launch_transpose_shape<8, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
-	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+#endif
 	return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "unknown transpose kernel '%s'", shape.c_str());
 }
 
@@ -1086,22 +1101,36 @@ int v2m_bind_path_matrix_device(v2m_ctx *ctx, const void *d_paths_by_edge_and_ch
 int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_rows, uint64_t n_cols, uint64_t first_copy, uint64_t n_copies)
 {
 	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (first_copy > n_rows || n_copies > n_rows - first_copy) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "copies [%llu, %llu) are outside the matrix (%llu rows)", (unsigned long long) first_copy, (unsigned long long) (first_copy + n_copies), (unsigned long long) n_rows);
+	// one block: the contiguous slice
+	u64 const block((n_copies + 7) & ~u64(7));
+	return v2m_upload_path_blocks(ctx, src_words, n_rows, n_cols, first_copy, std::max<u64>(block, 8), std::max<u64>(block, 8), first_copy + n_copies);
+}
+
+int v2m_upload_path_blocks(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_rows, uint64_t n_cols, uint64_t first_copy, uint64_t block_copies, uint64_t stride_copies, uint64_t copy_end)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
 	if (!ctx->has_graph) return fail(ctx, V2M_ERR_STATE, "no graph uploaded");
 	if (n_rows % 64 || n_cols % 64)                            // transpose_matrix.cc:53-54
 		return fail(ctx, V2M_ERR_PRECONDITION, "matrix dimensions must be multiples of 64 (got %llu x %llu)", (unsigned long long) n_rows, (unsigned long long) n_cols);
 	if (n_cols < ctx->n_edges) return fail(ctx, V2M_ERR_PRECONDITION, "path matrix has %llu edge columns, the graph %llu edges", (unsigned long long) n_cols, (unsigned long long) ctx->n_edges);
-	if (first_copy % 8) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "first_copy must be a multiple of 8 (whole bytes of the bit-packed columns)");
-	if (first_copy > n_rows || n_copies > n_rows - first_copy) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "copies [%llu, %llu) are outside the matrix (%llu rows)", (unsigned long long) first_copy, (unsigned long long) (first_copy + n_copies), (unsigned long long) n_rows);
+	if (first_copy % 8 || block_copies % 8 || stride_copies % 8 || 0 == block_copies || stride_copies < block_copies)
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "first_copy, block_copies and stride_copies must be multiples of 8 (whole bytes of the bit-packed columns), 0 < block_copies <= stride_copies");
+	if (copy_end > n_rows) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "copies up to %llu are outside the matrix (%llu rows)", (unsigned long long) copy_end, (unsigned long long) n_rows);
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ctx->d_paths = nullptr;
 	ctx->path_rows = ctx->path_cols = ctx->path_pitch = 0;
+
+	// this GPU's copies: blocks j = 0, 1, ... at first_copy + j * stride_copies, the last one possibly cut short by copy_end
+	u64 n_copies(0), n_blocks(0);
+	for (u64 c(first_copy); c < copy_end; c += stride_copies, ++n_blocks) n_copies += std::min(block_copies, copy_end - c);
 	if (0 == n_copies || 0 == n_cols) return V2M_OK;              // nothing to bind: rows of this ctx can only be REF rows
 	if (!src_words) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL matrix pointer");
 
-	u64 const hp((n_copies + 63) / 64 * 64);                      // the slice's row count: this GPU's copies, padded
-	size_t const take((n_copies + 7) / 8), src_col_bytes(n_rows / 8);
-	bool const whole(take == src_col_bytes);
-	// a packed slice gets line-aligned columns too (pitch rounded up to 16 words); the whole matrix is sent as it is
+	u64 const hp((n_copies + 63) / 64 * 64);                      // the share's row count: this GPU's copies, padded
+	size_t const take((n_copies + 7) / 8), src_col_bytes(n_rows / 8), block_bytes(block_copies / 8), stride_bytes(stride_copies / 8);
+	bool const whole(take == src_col_bytes && 1 == n_blocks);
+	// a packed share gets line-aligned columns too (pitch rounded up to 16 words); the whole matrix is sent as it is
 	u64 const src_pitch(whole ? hp / 64 : aligned_pitch(hp / 64));
 	size_t const col_bytes(src_pitch * 8), bytes(col_bytes * n_cols);
 	V2M_HIP_TRY(ctx, ctx->d_slice_src.ensure(bytes));
@@ -1110,7 +1139,8 @@ int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_ro
 		// the whole matrix: one contiguous copy
 		V2M_HIP_TRY(ctx, hipMemcpyAsync(ctx->d_slice_src.p, src_words, bytes, hipMemcpyHostToDevice, ctx->stream));
 	} else {
-		// bytes [first_copy / 8, +take) of every column, packed into pinned slots by a few host threads and sent slot by slot
+		// bytes [first_copy / 8 + j * stride_bytes, + block_bytes) of every column, packed block after block into pinned slots by a few
+		// host threads and sent slot by slot
 		unsigned char const tail_mask((n_copies % 8) ? (unsigned char) ((1u << (n_copies % 8)) - 1) : (unsigned char) 0xFF);
 		size_t const slot_cols(std::max<size_t>(1, std::min<size_t>(n_cols, (size_t(64) << 20) / col_bytes)));
 		for (int i(0); i < 2; ++i) V2M_HIP_TRY(ctx, ctx->host_ring[i].ensure(slot_cols * col_bytes));
@@ -1125,8 +1155,14 @@ int v2m_upload_path_slice(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_ro
 			auto const pack([&](size_t lo, size_t hi) {
 				for (size_t c(lo); c < hi; ++c) {
 					char *const d(stage + c * col_bytes);
-					std::memcpy(d, src + (c0 + c) * src_col_bytes, take);
-					d[take - 1] = char((unsigned char) d[take - 1] & tail_mask);   // bits of copies past the slice are the next GPU's
+					char const *const column(src + (c0 + c) * src_col_bytes);
+					size_t done(0);
+					for (u64 j(0); j < n_blocks; ++j) {
+						size_t const n(std::min(block_bytes, take - done));
+						std::memcpy(d + done, column + j * stride_bytes, n);
+						done += n;
+					}
+					d[take - 1] = char((unsigned char) d[take - 1] & tail_mask);   // bits of copies past the share are another GPU's
 					if (take < col_bytes) std::memset(d + take, 0, col_bytes - take);
 				}
 			});
