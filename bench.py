@@ -55,9 +55,9 @@ def kernel_source_stamp():
 
 
 def _hip_runtime():
-	import ctypes
-	# the HIP runtime already loaded by torch (one runtime per process)
-	return ctypes.CDLL("libamdhip64.so.7")
+	# the HIP runtime already loaded by torch / the library (one runtime per process), whatever its soname
+	from vcf2multialign_amd import _native
+	return _native.hip_runtime()
 
 
 def _hip_memset(torch, ptr, nbytes):

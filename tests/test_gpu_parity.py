@@ -683,7 +683,8 @@ def test_output_buffer_allocate_free_allocate(ctx, v2m, tmp_path):
 	expected = {r: g.output_sequence(g.ref, copy_index=r) for r in set(rows)}
 	want = {r: v2m.checksum_rows_host([body])[0] for r, body in expected.items()}
 	want = np.array([want[r] for r in rows], dtype=np.uint64)
-	rt = ctypes.CDLL("libamdhip64.so.7")
+	from vcf2multialign_amd import _native
+	rt = _native.hip_runtime()                  # (the runtime the process has loaded, not a versioned soname)
 	rt.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
 	for _ in range(3):
 		out = ctx.alloc_output(n_rows * pitch, 2)

@@ -113,6 +113,36 @@ def test_malformed_input_is_an_error(HostGraph, tmp_path):
 		HostGraph(fa, vcf, "1")                     # REF column mismatch (delegate decides; the test delegate refuses)
 
 
+def test_delegate_that_stops_at_a_ref_mismatch(HostGraph, tmp_path):
+	"""variant_graph.cc:307-314: a delegate may answer a REF mismatch with "stop here".  The graph then holds the records before it,
+	a node at the mismatching record's position and the sink (:437-451), and the chromosome-ID mismatches counted are those
+	seen before the stop (:203-207).  A record that goes BACK in position is an error before its REF column is looked at (:293-297)."""
+	import ctypes
+	from vcf2multialign_amd import host
+	L = host._load()
+	L.v2mh_set_stop_at_ref_mismatch.argtypes = [ctypes.c_int]
+	ref = b"ACGTACGTACGTACGT"
+	gt = np.array([[1, 0]])
+	def write(records):
+		fa, vcf = synth.write_inputs(str(tmp_path), ref, records, 1)
+		lines = open(vcf).read().splitlines()
+		body = [l for l in lines if not l.startswith("#")]
+		other = body[0].split("\t"); other[0] = "2"                       # records of another chromosome, before and after the stop
+		open(vcf, "w").write("\n".join([l for l in lines if l.startswith("#")] + ["\t".join(other), body[0], "\t".join(other)] + body[1:] + ["\t".join(other)]) + "\n")
+		return fa, vcf
+	try:
+		L.v2mh_set_stop_at_ref_mismatch(1)
+		fa, vcf = write([(1, b"C", [b"T"], gt), (6, b"T", [b"A"], gt), (9, b"C", [b"G"], gt)])   # (0-based) position 6 holds G, not T
+		h = HostGraph(fa, vcf, "1")
+		assert h.reference_positions.tolist() == [0, 1, 2, 6, 16]            # source, record 1 and its target, the stopping record's node, sink
+		assert len(h.alt_edge_targets) == 1 and h.handled_variants == 2 and h.chr_id_mismatches == 2
+		fa, vcf = write([(6, b"G", [b"T"], gt), (3, b"A", [b"C"], gt)])     # goes back AND has the wrong REF (position 3 holds T): the position wins
+		with pytest.raises(ValueError, match="non-increasing"):
+			HostGraph(fa, vcf, "1")
+	finally:
+		L.v2mh_set_stop_at_ref_mismatch(0)
+
+
 @pytest.mark.parametrize("threads", [1, 2, 5])
 def test_threaded_parse_is_identical_to_sequential(HostGraph, tmp_path, threads):
 	"""Workers parse 8-MB chunks, one thread merges in file order: same graph, same overlap reports in the same order."""
@@ -195,6 +225,18 @@ def test_graph_file_round_trip(HostGraph, tmp_path):
 	with pytest.raises(ValueError, match="do not match the size of the file"):
 		HostGraph.read(bad)
 	bad.write_bytes(good + b"\0" * 8)
+	with pytest.raises(ValueError, match="do not match the size of the file"):
+		HostGraph.read(bad)
+	# ... also when the claimed sizes wrap 64 bits: 2^40 x 2^30 bits is 2^67 bytes = 0 mod 2^64, so with that matrix's block cut
+	# out of the file the unchecked sum would match the file size again and leave a matrix without words (round-2 advisor)
+	c = [int.from_bytes(good[8 + 8 * i:16 + 8 * i], "little") for i in range(10)]
+	matrix_at = 8 + 80 + 8 * (2 * c[0] + c[1] + (c[0] + 1) + (c[1] + 1)) + c[6] // 64 * c[7] * 8   # paths_by_edge_and_chrom_copy (the host leaves the other one out)
+	matrix_bytes = c[8] // 64 * c[9] * 8
+	assert matrix_bytes > 0
+	wrapping = bytearray(good[:matrix_at] + good[matrix_at + matrix_bytes:])
+	wrapping[8 + 64:8 + 72] = (1 << 40).to_bytes(8, "little")
+	wrapping[8 + 72:8 + 80] = (1 << 30).to_bytes(8, "little")
+	bad.write_bytes(bytes(wrapping))
 	with pytest.raises(ValueError, match="do not match the size of the file"):
 		HostGraph.read(bad)
 

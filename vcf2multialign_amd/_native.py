@@ -107,3 +107,15 @@ def load():
 		fn.argtypes = argtypes
 	_lib = lib
 	return lib
+
+
+def hip_runtime():
+	"""The HIP runtime this process already has loaded (torch's copy, or /opt/rocm's through libv2m_hip.so), as a ctypes handle --
+	found by its mapping, not by a versioned soname.  For device <-> host copies in tools, tests and bench.py."""
+	load()
+	with open("/proc/self/maps") as f:
+		for line in f:
+			path = line.split()[-1]
+			if "libamdhip64.so" in os.path.basename(path):
+				return C.CDLL(path)
+	raise ImportError("no libamdhip64 is loaded in this process")

@@ -55,6 +55,8 @@ public:
 	// (variant_graph.cc:300-313): the pending targets up to ref_pos and the record's own node exist, none of its edges, and
 	// the previous record's position is still the "previous position" that finish() measures the sink's distance from.
 	void add_record_node_only(u64 ref_pos);
+	// Whether a record at ref_pos would lie before the previous one (variant_graph.cc:293-297: an error in the reference).
+	bool would_go_back(u64 ref_pos) const { return ref_pos < m_prev_ref_pos; }
 
 	// Genotype of one chromosome copy for the record just added: alt_number is the 1-based GT value
 	// (0 and missing are not passed).  Sets the path bit, reporting an overlap first when the copy is

@@ -193,8 +193,14 @@ void read_graph(char const *path, variant_graph &g)
 		struct stat st;
 		if (0 != ::fstat(fd, &st) || st.st_size < 0) throw std::runtime_error(std::string("unable to size ") + path);
 		auto const pad8([](u64 n) { return (n + 7) & ~u64(7); });   // every block is padded to whole 8-byte words
-		u64 const payload(8 * (2 * c[0] + c[1] + (c[0] + 1) + (c[1] + 1)) + c[6] / 64 * c[7] * 8 + c[8] / 64 * c[9] * 8 + pad8(4 * c[5]) + pad8(c[2]) + pad8(c[4]) + 8);
-		if (u64(st.st_size) < r.offset || payload != u64(st.st_size) - r.offset) throw std::runtime_error(std::string(path) + ": the counts in the header do not match the size of the file (truncated or corrupted graph file)");
+		// (checked arithmetic: each count may be up to 2^40, so the matrix terms can wrap 64 bits -- a header with 2^40 x 2^30 bits
+		// would otherwise add up to a small payload, pass, and leave matrices whose word arrays are empty)
+		bool wrapped(false);
+		auto const mul([&](u64 a, u64 b) { u64 out(0); wrapped |= __builtin_mul_overflow(a, b, &out); return out; });
+		u64 payload(0);
+		for (u64 const block : {8 * (2 * c[0] + c[1] + (c[0] + 1) + (c[1] + 1)), mul(mul(c[6] / 64, c[7]), 8), mul(mul(c[8] / 64, c[9]), 8), pad8(4 * c[5]), pad8(c[2]), pad8(c[4]), u64(8)})
+			wrapped |= __builtin_add_overflow(payload, block, &payload);
+		if (wrapped || u64(st.st_size) < r.offset || payload != u64(st.st_size) - r.offset) throw std::runtime_error(std::string(path) + ": the counts in the header do not match the size of the file (truncated or corrupted graph file)");
 	}
 	g = variant_graph{};
 	g.reference_positions.resize(c[0]);
@@ -204,6 +210,8 @@ void read_graph(char const *path, variant_graph &g)
 	g.alt_edge_label_offsets.resize(c[1] + 1);
 	g.paths_by_chrom_copy_and_edge = bit_matrix::for_overwrite(c[6], c[7]);
 	g.paths_by_edge_and_chrom_copy = bit_matrix::for_overwrite(c[8], c[9]);
+	if (g.paths_by_chrom_copy_and_edge.words.size() != c[6] / 64 * c[7] || g.paths_by_edge_and_chrom_copy.words.size() != c[8] / 64 * c[9])
+		throw std::runtime_error("graph file: path matrix allocation does not match its dimensions");
 	g.ploidy_csum.resize(c[5]);
 	g.alt_edge_label_bytes.resize(c[2]);
 	std::string names(c[4], '\0');

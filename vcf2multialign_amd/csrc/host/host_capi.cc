@@ -38,8 +38,15 @@ struct recording_delegate final : vh::build_graph_delegate {
 	{
 		hg->overlaps.push_back({lineno, ref_pos, std::string(var_id), std::string(sample_name), copy, gt});
 	}
-	bool ref_column_mismatch(vh::u64, vh::u64, std::string_view, std::string_view) override { throw std::runtime_error("REF column mismatch"); }
+	bool stop_at_mismatch{};       // what the reference's delegate may also answer: stop parsing here (variant_graph.cc:312-313)
+	bool ref_column_mismatch(vh::u64, vh::u64, std::string_view, std::string_view) override
+	{
+		if (stop_at_mismatch) return false;
+		throw std::runtime_error("REF column mismatch");
+	}
 };
+
+bool g_stop_at_mismatch(false);
 
 } // namespace
 
@@ -53,6 +60,7 @@ void *v2mh_build_variant_graph(char const *fasta, char const *seq_id, char const
 		recording_delegate d;
 		d.hg = hg;
 		if (exclude_sample) { d.excluded_sample = exclude_sample; d.excluded_copy = exclude_copy; }
+		d.stop_at_mismatch = g_stop_at_mismatch;
 		vh::build_variant_graph(hg->ref, vcf, chr, hg->graph, hg->stats, d, threads);
 		for (auto const &s : hg->graph.sample_names) { hg->sample_blob += s; hg->sample_blob.push_back('\0'); }
 		return hg;
@@ -88,6 +96,9 @@ void *v2mh_graph_from_arrays(
 }
 
 void v2mh_free(void *h) { delete static_cast<host_graph *>(h); }
+
+// How the next v2mh_build_variant_graph() calls answer a REF column mismatch: 0 = it is an error (default), 1 = stop parsing there.
+void v2mh_set_stop_at_ref_mismatch(int stop) { g_stop_at_mismatch = 0 != stop; }
 
 int v2mh_write_graph(void *h, char const *path, char *err, size_t errlen)
 {

@@ -292,6 +292,9 @@ int main(int argc, char **argv)
 			return EXIT_FAILURE;
 		}
 		std::cerr << " Done. Reference length is " << ref_seq.size() << ".\n";
+		// (the contexts are up by now -- 0.2 s, overlapped with the FASTA read: a missing or unusable GPU, or a bad --device, ends
+		// the run here, before the variants are parsed, not minutes later)
+		(void) first_gpu();
 
 		vh::variant_graph graph;
 		if (opt.input_graph) {                                  // main.cc:392-401

@@ -101,6 +101,7 @@ struct parsed_record {
 	std::string_view id, ref;
 	u32 alt_begin, n_alts;
 	u64 geno_begin, geno_end;
+	u64 chr_mismatches_before;   // records of other chromosomes seen in the chunk before this one
 };
 
 struct parsed_chunk {
@@ -155,6 +156,7 @@ void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &
 			parsed_record rec{};
 			rec.line_in_chunk = out.n_lines;
 			rec.data_line_in_chunk = out.n_data_lines;
+			rec.chr_mismatches_before = out.chr_mismatches;
 			rec.id = id;
 			rec.ref = ref;
 			if (pos_f.empty()) throw chunk_error{out.n_lines, "empty POS"};
@@ -403,10 +405,15 @@ void build_variant_graph(
 			cur_lineno = lineno_base + rec.line_in_chunk;
 			cur_id = rec.id;
 			u64 const this_var(var_idx + rec.data_line_in_chunk);
+			// the reference's order: the position check (variant_graph.cc:293-297) comes before the REF comparison (:307-314)
+			if (builder.would_go_back(rec.ref_pos))
+				throw std::runtime_error("variant " + std::to_string(this_var) + " has non-increasing position");
 			{                                                                            // :307-314
 				std::string_view const expected(rec.ref_pos <= ref_sv.size() ? ref_sv.substr(rec.ref_pos, rec.ref.size()) : std::string_view{});
 				if (rec.ref != expected && !delegate.ref_column_mismatch(this_var, rec.ref_pos, rec.ref, expected)) {
-					// the reference stops parsing here (variant_graph.cc:312-313) and still adds the sink node (:437-451)
+					// the reference stops parsing here (variant_graph.cc:312-313) and still adds the sink node (:437-451); the
+					// records of other chromosomes it had passed by then have been counted (:203-207)
+					stats.chr_id_mismatches += rec.chr_mismatches_before;
 					builder.add_record_node_only(rec.ref_pos);
 					builder.finish(ref_seq.size());
 					return;

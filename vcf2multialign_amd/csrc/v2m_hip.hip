@@ -514,13 +514,18 @@ int resolve_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 ro
 		if (count) V2M_HIP_TRY(ctx, hipMemcpyAsync(dst.p, src, count * sizeof(u32), hipMemcpyHostToDevice, ctx->stream));
 		return V2M_OK;
 	});
-	if (int const rc = upload(ctx->d_seg_offsets, pr.seg_offsets, n_rows + 1)) return rc;
-	if (int const rc = upload(ctx->d_seg_edge_begin, pr.seg_edge_begin, pr.n_segments)) return rc;
-	if (int const rc = upload(ctx->d_seg_copy, pr.seg_copy, pr.n_segments)) return rc;
-	// the staging area the tables came from is free again once these copies have run; the other one takes the next slice
-	V2M_HIP_TRY(ctx, hipEventRecord(ctx->ev_row_stage[ctx->row_stage_next], ctx->stream));
-	ctx->row_stage_in_flight[ctx->row_stage_next] = true;
+	// The staging area the tables came from is free again once these copies have run; the other one takes the next slice.  The
+	// area counts as in flight from the first copy on, whether or not all three get queued: a failed call must not leave
+	// copies behind that the next user of the area does not wait for.
+	int const stage(ctx->row_stage_next);
+	ctx->row_stage_in_flight[stage] = true;
 	ctx->row_stage_next ^= 1;
+	int upload_rc(upload(ctx->d_seg_offsets, pr.seg_offsets, n_rows + 1));
+	if (!upload_rc) upload_rc = upload(ctx->d_seg_edge_begin, pr.seg_edge_begin, pr.n_segments);
+	if (!upload_rc) upload_rc = upload(ctx->d_seg_copy, pr.seg_copy, pr.n_segments);
+	hipError_t const recorded(hipEventRecord(ctx->ev_row_stage[stage], ctx->stream));
+	if (upload_rc) return upload_rc;
+	V2M_HIP_TRY(ctx, recorded);
 	V2M_HIP_TRY(ctx, ctx->d_eff.ensure(n_rows * eff_words * sizeof(u64)));
 	V2M_HIP_TRY(ctx, ctx->d_needs_serial.ensure(n_rows * sizeof(u32)));
 	V2M_HIP_TRY(ctx, hipMemsetAsync(ctx->d_needs_serial.p, 0, n_rows * sizeof(u32), ctx->stream));
@@ -1025,7 +1030,7 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 	V2M_HIP_TRY(ctx, hipGetLastError());
 
 	ctx->d_paths = nullptr;
-	ctx->path_rows = ctx->path_cols = 0;
+	ctx->path_rows = ctx->path_cols = ctx->path_pitch = 0;
 	if (g->paths_by_chrom_copy_and_edge) {
 		size_t const bytes(g->path_rows / 64 * g->path_cols * sizeof(u64));
 		V2M_HIP_TRY(ctx, ctx->owned_paths.ensure(std::max<size_t>(bytes, 16)));
