@@ -205,15 +205,21 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 // bytes of it) and writes them out through a wave-private LDS slab, so that 16 consecutive lanes store one
 // destination column's 128 bytes.  Both HBM sides move whole 128-B runs.
 constexpr int kTsR = 16, kTsC = 16;
-constexpr int kTsDepth = 4;                          // source sub-panels in flight per workgroup (registers)
 
-__global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
+// kTsDepth: source sub-panels in flight per workgroup (registers).  kSlabCols: destination columns of a wave that pass
+// through its write-out slab at a time (64 = all of a tile's at once; 32 = two passes over a slab half the size, which
+// takes the kernel from 52 KB of LDS -- 3 workgroups per CU -- to 35 KB -- 4).
+template <int kTsDepth, int kSlabCols, int kWaves = 4>
+__global__ __launch_bounds__(64 * kWaves) void transpose_bits_stream_kernel(
 	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,
 	u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
 {
-	constexpr int kA = kTsR / 4;                         // row-words per wave
+	static_assert(64 % kSlabCols == 0 && kSlabCols >= 16, "the slab takes a whole fraction of a tile's 64 destination columns");
+	constexpr int kThreads = 64 * kWaves;
+	static_assert(kTsR % kWaves == 0 && (64 * kTsR) % kThreads == 0, "whole row-words per wave, whole words per thread");
+	constexpr int kA = kTsR / kWaves;                    // row-words per wave
 	__shared__ u64 in[2][64][kTsR + 1];
-	__shared__ u64 slab[kTrThreads / 64][64][kTsC + 1];
+	__shared__ u64 slab[kWaves][kSlabCols][kTsC + 1];
 
 	int const t = threadIdx.x;
 	int const lane = t & 63;
@@ -228,13 +234,13 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 	// kTsDepth sub-panels are kept in flight in registers (the kernel is bound by bytes in flight, not by the shuffles).
 	// Every load is issued unconditionally from an address clamped into the matrix and zeroed at the stash where it lies
 	// outside: loads under branches made the compiler drain the whole load queue at every barrier (see the ring kernel).
-	constexpr int kPer = (64 * kTsR) / kTrThreads;
+	constexpr int kPer = (64 * kTsR) / kThreads;
 	u64 stage[kTsDepth][kPer];
 	u64 const last_col = n_cols - 1;
 	auto fetch = [&](int cg, u64 (&st)[kPer]) {
 #pragma unroll
 		for (int k = 0; k < kPer; ++k) {
-			int const idx = t + kTrThreads * k;
+			int const idx = t + kThreads * k;
 			int const col = idx / kTsR, w = idx % kTsR;
 			u64 const gcol = (cg0 + cg) * 64 + col;
 			st[k] = src[(gcol < n_cols ? gcol : last_col) * src_pitch + (rw0 + w < SW ? rw0 + w : SW - 1)];
@@ -243,7 +249,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 	auto stash = [&](int buf, int cg, u64 const (&st)[kPer]) {
 #pragma unroll
 		for (int k = 0; k < kPer; ++k) {
-			int const idx = t + kTrThreads * k;
+			int const idx = t + kThreads * k;
 			int const col = idx / kTsR, w = idx % kTsR;
 			in[buf][col][w] = ((cg0 + cg) * 64 + col < n_cols && rw0 + w < SW) ? st[k] : 0;
 		}
@@ -268,15 +274,22 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_stream_kernel(
 	for (int a = 0; a < kA; ++a) {
 		u64 const rw = rw0 + kA * wave + a;
 #pragma unroll
-		for (int cg = 0; cg < kTsC; ++cg)
-			slab[wave][lane][cg] = y[a][cg];
-		if (rw < SW) {
+		for (int part = 0; part < 64 / kSlabCols; ++part) {
+			// the destination columns [kSlabCols * part, + kSlabCols) of the tile: their lanes drop their 16 words into the slab ...
+			if (kSlabCols == 64 || lane / kSlabCols == part) {
 #pragma unroll
-			for (int k = 0; k < kTsC; ++k) {
-				int const idx = lane + 64 * k;
-				int const dcol = idx / kTsC, cw = idx % kTsC;
-				if (cg0 + cw < DW)
-					dst[(rw * 64 + dcol) * dst_pitch + cg0 + cw] = slab[wave][dcol][cw];
+				for (int cg = 0; cg < kTsC; ++cg)
+					slab[wave][lane % kSlabCols][cg] = y[a][cg];
+			}
+			// ... and all 64 lanes store them, 16 consecutive lanes one column's 128 bytes
+			if (rw < SW) {
+#pragma unroll
+				for (int k = 0; k < kTsC * kSlabCols / 64; ++k) {
+					int const idx = lane + 64 * k;
+					int const dcol = idx / kTsC, cw = idx % kTsC;
+					if (cg0 + cw < DW)
+						dst[(rw * 64 + kSlabCols * part + dcol) * dst_pitch + cg0 + cw] = slab[wave][dcol][cw];
+				}
 			}
 		}
 	}
