@@ -15,14 +15,16 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def isa(tmp_path_factory):
+@pytest.fixture(scope="module", params=["product", "tuning"])
+def isa(request, tmp_path_factory):
+	"""The emitted ISA of the product build and of the tuning build (-DV2M_TUNING_BUILD: every transpose variant that can be timed)."""
 	from vcf2multialign_amd import build
 	hipcc = build.find_hipcc()
 	if hipcc is None:
 		pytest.skip("hipcc not found")
 	out = tmp_path_factory.mktemp("isa") / "v2m_hip.s"
-	subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-o", str(out), build.HIP_SOURCES[0]], cwd=ROOT)
+	extra = ["-DV2M_TUNING_BUILD"] if request.param == "tuning" else []
+	subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only"] + extra + ["-o", str(out), build.HIP_SOURCES[0]], cwd=ROOT)
 	kernels, name, cur = {}, None, []
 	for line in out.read_text().split("\n"):
 		m = re.match(r"^(_ZN3v2m\w+):", line)
@@ -35,7 +37,9 @@ def isa(tmp_path_factory):
 			if "s_endpgm" in line:
 				kernels[name] = cur
 				name = None
-	assert len(kernels) > 20
+	assert len(kernels) > (20 if request.param == "tuning" else 12)
+	if request.param == "product":   # the measured-only shapes are not in the product library
+		assert sum("transpose_bits" in k for k in kernels) == 3, sorted(k for k in kernels if "transpose_bits" in k)
 	kernels["__text__"] = out.read_text()
 	return kernels
 
@@ -72,6 +76,6 @@ def test_no_scratch_and_no_mfma(isa):
 	"""Integer copy / index work: no kernel spills to scratch memory, none uses the matrix cores."""
 	text = isa["__text__"]
 	sizes = re.findall(r"\.amdhsa_kernel (_ZN3v2m\w+).*?\.amdhsa_private_segment_fixed_size (\d+)", text, flags=re.S)
-	assert len(sizes) > 20
+	assert len(sizes) >= 16 and len(sizes) == len(isa) - 1
 	assert [n for n, size in sizes if int(size) != 0] == []
 	assert "v_mfma" not in text
