@@ -17,7 +17,7 @@ V2M_NT_STORES=1 timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv
 echo "pmc write done"
 V2M_NT_STORES=1 timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -o f -- python3 bench.py $PMC_ARGS > $OUT/pmc_f.json 2> $OUT/pmc_f.err
 echo "pmc fetch done"
-python3 tools/pmc_summary.py $OUT/pmc_hbm.json "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE (separate passes, one step of bench.py's default run each; counter unit KiB; hbm_bytes = 1024*(WRITE_SIZE + 2*FETCH_SIZE), the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md). Store flavour fixed (V2M_NT_STORES=1): the splice average covers the step's own launches only." WRITE_SIZE=$OUT/pmc_w FETCH_SIZE=$OUT/pmc_f "record=config3,$(python3 -c "import json;print(json.loads(open('$OUT/pmc_w.json').read().strip().splitlines()[-1])['config']['batch_rows'])"),1,${PROFILE_DEST:-profiles/r02}/config3_1gpu_pmc_hbm.json"
+python3 tools/pmc_summary.py $OUT/pmc_hbm.json "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE (separate passes, one step of bench.py's default run each; counter unit KiB; hbm_bytes = 1024*(WRITE_SIZE + 2*FETCH_SIZE), the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md). Store flavour fixed (V2M_NT_STORES=1): the splice average covers the step's own launches only." WRITE_SIZE=$OUT/pmc_w FETCH_SIZE=$OUT/pmc_f "record=config3,$(python3 -c "import json;print(json.loads(open('$OUT/pmc_w.json').read().strip().splitlines()[-1])['config']['batch_rows'])"),1,${PROFILE_DEST:-profiles/r03}/config3_1gpu_pmc_hbm.json"
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 rm -rf $OUT/pmc_w $OUT/pmc_f
 timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
