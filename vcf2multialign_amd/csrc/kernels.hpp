@@ -204,19 +204,20 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 // its 4 row-words in registers across the 16 groups (lane = destination column, 16 words = 128 contiguous
 // bytes of it) and writes them out through a wave-private LDS slab, so that 16 consecutive lanes store one
 // destination column's 128 bytes.  Both HBM sides move whole 128-B runs.
-constexpr int kTsR = 16, kTsC = 16;
 
 // kTsDepth: source sub-panels in flight per workgroup (registers).  kSlabCols: destination columns of a wave that pass
 // through its write-out slab at a time (64 = all of a tile's at once; 32 = two passes over a slab half the size, which
 // takes the kernel from 52 KB of LDS -- 3 workgroups per CU -- to 35 KB -- 4).
-template <int kTsDepth, int kSlabCols, int kWaves = 4>
+// kTsR x kTsC: row-words x column groups of a workgroup's block (16 x 16: a 128-B line on both sides; 8 x 32: 64-B source runs,
+// 256-B destination runs, for a dense destination whose columns start at arbitrary 8-byte offsets).
+template <int kTsDepth, int kSlabCols, int kWaves = 4, int kTsR = 16, int kTsC = 16>
 __global__ __launch_bounds__(64 * kWaves) void transpose_bits_stream_kernel(
 	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,
 	u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
 {
 	static_assert(64 % kSlabCols == 0 && kSlabCols >= 16, "the slab takes a whole fraction of a tile's 64 destination columns");
 	constexpr int kThreads = 64 * kWaves;
-	static_assert(kTsR % kWaves == 0 && (64 * kTsR) % kThreads == 0, "whole row-words per wave, whole words per thread");
+	static_assert(kTsR % kWaves == 0 && (64 * kTsR) % kThreads == 0 && (kTsC * kSlabCols) % 64 == 0, "whole row-words per wave, whole words per thread");
 	constexpr int kA = kTsR / kWaves;                    // row-words per wave
 	__shared__ u64 in[2][64][kTsR + 1];
 	__shared__ u64 slab[kWaves][kSlabCols][kTsC + 1];

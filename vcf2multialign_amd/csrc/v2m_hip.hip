@@ -240,15 +240,15 @@ int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 S
 	return V2M_OK;
 }
 
-template <int kDepth, int kSlabCols, int kWaves = 4>
+template <int kDepth, int kSlabCols, int kWaves = 4, int kTsR = 16, int kTsC = 16>
 int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, bool xcd, int order)
 {
-	u64 const P((SW + v2m::kTsR - 1) / v2m::kTsR), Q((DW + v2m::kTsC - 1) / v2m::kTsC);
+	u64 const P((SW + kTsR - 1) / kTsR), Q((DW + kTsC - 1) / kTsC);
 	xcd_grid g;
 	if (P > 0xFFFFFFFFull || Q > 0xFFFFFFFFull || !make_xcd_grid(P * Q, xcd, g)) return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL((v2m::transpose_bits_stream_kernel<kDepth, kSlabCols, kWaves>), dim3(g.blocks), dim3(64 * kWaves), 0, ctx->stream, d_src, d_dst, SW, DW, SP, DP, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
+		hipLaunchKernelGGL((v2m::transpose_bits_stream_kernel<kDepth, kSlabCols, kWaves, kTsR, kTsC>), dim3(g.blocks), dim3(64 * kWaves), 0, ctx->stream, d_src, d_dst, SW, DW, SP, DP, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
@@ -330,6 +330,10 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 	if (shape == "stream16:4,16,8") return launch_transpose_stream<4, 16, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "stream16:2,16,8") return launch_transpose_stream<2, 16, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "stream16:4,64,8") return launch_transpose_stream<4, 64, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "stream8x32") return launch_transpose_stream<4, 32, 4, 8, 32>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "stream8x32:8") return launch_transpose_stream<4, 16, 8, 8, 32>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "stream32x8") return launch_transpose_stream<4, 64, 4, 32, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (shape == "stream4x64") return launch_transpose_stream<4, 16, 4, 4, 64>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 #endif
 	if (shape == "8x8") return launch_transpose_shape<8, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 #ifdef V2M_TUNING_BUILD
