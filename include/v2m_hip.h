@@ -228,6 +228,31 @@ int v2m_free_output(v2m_ctx *ctx, void *d_ptr);
 /* Upper bound of any unaligned row's length for the uploaded graph. */
 uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx);
 
+/* ---- founder search: the chunk walks ---------------------------------- */
+
+/* The edge-by-edge part of find_initial_cut_positions_lambda_min (libvcf2multialign/find_cut_positions.cc:126-176): the pBWT
+ * steps of pbwt_context::update_divergence (include/vcf2multialign/pbwt.hh:77-134) and, at every candidate cut node, the walk
+ * over the distinct divergence values from the largest down (find_cut_positions.cc:134-165) -- for chunks of consecutive
+ * candidates whose start state the caller has built (the state after k edges is the copies sorted by their reversed k-edge
+ * prefixes plus their divergence values; csrc/host/founder.cc builds it from the transposed matrix).  One workgroup walks
+ * one chunk; the score updates of find_cut_positions.cc:55-63, which depend on each other, stay with the caller.
+ *
+ * The ctx must hold the uploaded graph WITH its path matrix (v2m_upload_graph with paths_by_chrom_copy_and_edge): the call
+ * transposes it back to edge-major bits on the device.  n_copies <= 8192 (V2M_ERR_UNSUPPORTED beyond).
+ *   cand_edge[c], cand_aligned_pos[c]   of all n_candidates candidates: the index of the node's first ALT edge (ascending, one
+ *                                       candidate per distinct edge index, :129) and the node's aligned position (:151)
+ *   chunk_first[k] .. chunk_first[k+1]  the candidates of chunk k (n_chunks + 1 entries, ascending, chunk_first[0] >= 1)
+ *   start_order, start_divergence       [n_chunks][n_copies]: the state after the first cand_edge[chunk_first[k]] edges;
+ *                                       divergence values BIASED by one (0 = the reference's DIVERGENCE_MAX, pbwt.hh:25-42)
+ * Outputs (host): for chunk k up to trial_capacity pairs at trial_pred / trial_class_count + k * trial_capacity -- (earlier
+ * candidate, class count) in the order the reference's loop tries them --, trial_end[c] = the pairs of c's chunk up to and
+ * including candidate c, and chunk_status[k] = 0, or 1 when the chunk was left undone (more than 1024 distinct earlier
+ * candidates at one node, or trial_capacity exceeded): the caller walks that chunk itself.  Synchronous. */
+int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
+	uint64_t n_candidates, const uint32_t *cand_edge, const uint64_t *cand_aligned_pos,
+	uint64_t n_chunks, const uint64_t *chunk_first, const uint32_t *start_order, const uint32_t *start_divergence,
+	uint64_t trial_capacity, uint32_t *trial_pred, uint32_t *trial_class_count, uint64_t *trial_end, uint32_t *chunk_status);
+
 /* ---- verification helper ------------------------------------------------------------------ */
 
 /* 64-bit position-sensitive checksum of each of n_rows device rows (row i = d_rows + i*row_pitch,

@@ -1,0 +1,107 @@
+"""The founder cut search with its chunk walks on the GPU (v2m_pbwt_cut_trials: pBWT steps of pbwt.hh:77-134 and the
+per-candidate value walk of find_cut_positions.cc:134-165, one workgroup per chunk) against the host's search, the oracle's
+literal restatement and the cut positions the reference's own test pins (tests/founder_sequences.cc:130-186)."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import synth
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def v2m():
+	import vcf2multialign_amd as v
+	return v
+
+
+@pytest.fixture(scope="module")
+def HostGraph():
+	from vcf2multialign_amd.host import HostGraph
+	return HostGraph
+
+
+def _gpu_cuts(v2m, HostGraph, og, fa, vcf, min_distance, threads=3):
+	hg = HostGraph(fa, vcf, "1")
+	hg.set_transposed_paths(og.paths_by_chrom_copy_and_edge, og.path_rows, og.path_cols)
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(v2m.VariantGraph.from_object(og), og.ref)           # with the transposed path matrix
+		return hg.find_cut_positions_gpu(ctx, min_distance, threads), hg
+
+
+def _cases():
+	with open(os.path.join(HERE, "golden", "reference_goldens.json")) as f:
+		return json.load(f)["founder_sequences"]
+
+
+@pytest.mark.parametrize("case", _cases(), ids=lambda c: c["vcf"] + "+" + c["fasta"])
+def test_reference_cut_positions(v2m, HostGraph, case, fixtures_dir):
+	d = os.path.join(fixtures_dir, "founder-sequences")
+	fa, vcf = os.path.join(d, case["fasta"]), os.path.join(d, case["vcf"])
+	og = oracle.build_variant_graph(fa, vcf, case["chromosome"])
+	(cuts, score), _ = _gpu_cuts(v2m, HostGraph, og, fa, vcf, case["minimum_distance"])
+	assert cuts == case["cut_positions"]                               # REQUIRE(expected_cut_positions == output.cut_positions())
+
+
+@pytest.mark.parametrize("seed,ref_len,n_variants,n_samples,kw", [
+	(1, 3000, 120, 6, dict()),
+	(2, 5000, 400, 9, dict(multi_allelic=0.3)),
+	(3, 20000, 900, 40, dict(mix=(0.6, 0.2, 0.2))),
+	(4, 8000, 300, 3, dict(density=0.5)),
+	(5, 8000, 300, 70, dict(density=0.02)),
+	(6, 60000, 500, 12, dict(long_every=50)),
+	(7, 2000, 60, 1, dict(ploidy=1)),
+	(8, 30000, 2500, 33, dict(multi_allelic=0.1, mix=(0.7, 0.15, 0.15))),
+	(9, 200000, 20000, 600, dict(mix=(0.8, 0.1, 0.1))),                  # 1200 copies, several chunks of thousands of edges
+], ids=lambda v: str(v) if isinstance(v, int) else None)
+def test_random_inputs(v2m, HostGraph, tmp_path, seed, ref_len, n_variants, n_samples, kw):
+	rng = np.random.default_rng(1000 + seed)
+	ref = synth.random_reference(rng, ref_len)
+	recs = synth.random_records(rng, ref, n_variants, n_samples, **kw)
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, n_samples)
+	og = oracle.build_variant_graph(fa, vcf, "1")
+	assert og.edge_count > 0
+	for min_distance in (0, 10, 50, 1000, 10 * ref_len):
+		got, hg = _gpu_cuts(v2m, HostGraph, og, fa, vcf, min_distance)
+		assert hg.gpu_chunks_walked >= 1 and hg.gpu_chunks_left == 0        # the GPU walked every chunk
+		want = hg.find_founders(1, min_distance, threads=1)                 # the host's sequential search (== the oracle's, test_host_founders.py)
+		assert (got is None) == (want is None), min_distance
+		if want is not None:
+			assert got[0] == want[0] and got[1] == want[2], min_distance
+	if seed <= 8:                                                            # and the oracle's literal restatement directly
+		exp = og.find_founders(2, 50)
+		got, _ = _gpu_cuts(v2m, HostGraph, og, fa, vcf, 50)
+		assert (exp is None and got is None) or (got[0] == exp[0] and got[1] == exp[2])
+
+
+def test_chunks_the_gpu_leaves_undone_are_walked_on_the_host(v2m, HostGraph, tmp_path, monkeypatch):
+	"""A chunk whose pairs do not fit the buffer it was given comes back marked; the host walks it: same cut positions."""
+	rng = np.random.default_rng(77)
+	ref = synth.random_reference(rng, 100000)
+	recs = synth.random_records(rng, ref, 8000, 150, mix=(0.8, 0.1, 0.1))
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, 150)
+	og = oracle.build_variant_graph(fa, vcf, "1")
+	want, hg = _gpu_cuts(v2m, HostGraph, og, fa, vcf, 20)
+	assert hg.gpu_chunks_left == 0 and hg.gpu_chunks_walked > 1
+	monkeypatch.setenv("V2M_FOUNDER_TRIAL_CAPACITY", "2000")
+	got, hg = _gpu_cuts(v2m, HostGraph, og, fa, vcf, 20)
+	assert hg.gpu_chunks_left >= 1
+	assert got == want
+
+
+def test_refuses_what_it_cannot_hold(v2m):
+	"""More chromosome copies than a workgroup's LDS holds, or no path matrix on the device: an error, not a silent fallback."""
+	from vcf2multialign_amd import _native as N
+	import ctypes as C
+	with v2m.Context(0) as ctx:
+		a = (C.c_uint64 * 4)(1, 2, 0, 0)
+		u = (C.c_uint32 * 4)()
+		rc = ctx._lib.v2m_pbwt_cut_trials(ctx._h, 4, 0, 2, u, a, 1, a, u, u, 16, u, u, a, u)
+		assert rc == N.V2M_ERR_STATE

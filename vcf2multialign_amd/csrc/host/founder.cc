@@ -6,9 +6,11 @@
 #include <mutex>
 #include <exception>
 #include <thread>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <numeric>
 #include <stdexcept>
 
@@ -905,6 +907,135 @@ u32 find_cut_positions_chunked(variant_graph const &graph, u64 min_distance, std
 }
 
 } // namespace
+
+
+namespace {
+
+// find_cut_positions_chunked() with the chunk walks done by `walker`: candidates and chunks as there, every chunk's start
+// state built on the host threads first, one call for all the walks, then the score updates in candidate order.
+u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads, cut_trial_walker &walker)
+{
+	out.clear();
+	u32 const copies(graph.total_chromosome_copies());
+	u64 const n_edges(graph.edge_count());
+	check_edge_range(graph);
+
+	std::vector<cut_candidate> cuts;
+	cuts.push_back({0, kEdgeMax, 0, 0});
+	{
+		u64 rightmost_target(0), edge(0), last_cut_edge(kEdgeMax);
+		for (u64 node(0); node < graph.node_count(); ++node) {
+			if (rightmost_target <= node && last_cut_edge != edge) {
+				cuts.push_back({edge, kEdgeMax, node, copies});
+				last_cut_edge = edge;
+			}
+			for (u64 e(graph.alt_edge_count_csum[node]); e < graph.alt_edge_count_csum[node + 1]; ++e, ++edge)
+				rightmost_target = std::max(rightmost_target, graph.alt_edge_targets[e]);
+		}
+	}
+	if (cuts.size() >= u64(UINT32_MAX)) throw std::length_error("founder search: candidate indices are kept in 32 bits");
+	std::size_t const n_cand(cuts.size());
+	if (n_cand <= 1) return collect_cut_positions(cuts, graph, out);
+
+	// chunks of candidates with about the same number of edges each: one workgroup walks one chunk, so there are at least a
+	// few hundred of them when the graph is large enough (a start state costs the host tens of ms: not many more than that)
+	std::size_t const wanted(std::min<std::size_t>(std::max<std::size_t>(std::size_t(threads) * 8, std::size_t(n_edges / 8192) + 1), n_cand - 1));
+	std::vector<u64> chunk_first;
+	for (std::size_t j(1), k(1); j <= wanted && k < n_cand; ++j) {
+		u64 const edge_goal(n_edges * j / wanted);
+		std::size_t end(k + 1);
+		while (end < n_cand && cuts[end].edge < edge_goal) ++end;
+		if (j == wanted) end = n_cand;
+		chunk_first.push_back(k);
+		k = end;
+	}
+	chunk_first.push_back(n_cand);
+	std::size_t const n_chunks(chunk_first.size() - 1);
+
+	std::vector<u32> cand_edge(n_cand);
+	std::vector<u64> cand_aligned(n_cand);
+	for (std::size_t c(0); c < n_cand; ++c) { cand_edge[c] = u32(cuts[c].edge); cand_aligned[c] = graph.aligned_positions[cuts[c].node]; }
+
+	// start states, on the host threads
+	std::unique_ptr<u32[]> start_order(new u32[n_chunks * copies]), start_div(new u32[n_chunks * copies]);
+	{
+		std::atomic<std::size_t> next_chunk(0);
+		std::exception_ptr error;
+		std::mutex error_mutex;
+		auto const work([&] {
+			try {
+				edge_pbwt pbwt(copies, nullptr);
+				for (std::size_t c; (c = next_chunk.fetch_add(1)) < n_chunks;) {
+					pbwt = edge_pbwt(copies, nullptr);
+					pbwt_state_at(graph, cuts[chunk_first[c]].edge, pbwt);
+					std::copy(pbwt.order.begin(), pbwt.order.end(), start_order.get() + c * copies);
+					std::copy(pbwt.divergence.begin(), pbwt.divergence.end(), start_div.get() + c * copies);
+				}
+			} catch (...) {
+				std::lock_guard<std::mutex> const lock(error_mutex);
+				if (!error) error = std::current_exception();
+			}
+		});
+		std::vector<std::thread> pool;
+		for (unsigned t(1); t < std::max(1u, threads); ++t) pool.emplace_back(work);
+		work();
+		for (auto &t : pool) t.join();
+		if (error) std::rethrow_exception(error);
+	}
+
+	// the walks
+	u64 max_chunk_candidates(0);
+	for (std::size_t c(0); c < n_chunks; ++c) max_chunk_candidates = std::max<u64>(max_chunk_candidates, chunk_first[c + 1] - chunk_first[c]);
+	u64 capacity(std::max<u64>(4096, 192 * max_chunk_candidates));            // (about 100 pairs per candidate on 1KG-like input)
+	if (char const *const e = std::getenv("V2M_FOUNDER_TRIAL_CAPACITY")) if (*e) capacity = std::max<u64>(1, std::strtoull(e, nullptr, 10));   // test knob: forces chunks back to the host
+	std::unique_ptr<u32[]> trial_pred(new u32[n_chunks * capacity]), trial_class(new u32[n_chunks * capacity]);
+	std::vector<u64> trial_end(n_cand, 0);
+	std::vector<u32> status(n_chunks, 1);
+	walker.walk(copies, min_distance, cand_edge, cand_aligned, chunk_first, start_order.get(), start_div.get(), capacity, trial_pred.get(), trial_class.get(), trial_end.data(), status.data());
+
+	// the score updates, in candidate order (find_cut_positions.cc:55-63); chunks the walker left undone are walked here
+	std::vector<u32> first_candidate_from_edge;
+	walker.chunks_walked = walker.chunks_left = 0;
+	for (std::size_t c(0); c < n_chunks; ++c) {
+		++(0 == status[c] ? walker.chunks_walked : walker.chunks_left);
+		if (0 == status[c]) {
+			u32 const *const pred(trial_pred.get() + c * capacity), *const cls(trial_class.get() + c * capacity);
+			u64 t(0);
+			for (std::size_t j(chunk_first[c]); j < chunk_first[c + 1]; ++j) {
+				cut_candidate &current(cuts[j]);
+				for (u64 const t_end(trial_end[j]); t < t_end; ++t) current.improve(cls[t], cuts[pred[t]]);
+			}
+			continue;
+		}
+		if (first_candidate_from_edge.empty()) {
+			first_candidate_from_edge.resize(n_edges + 1);
+			std::size_t k(0);
+			for (u64 e(0); e <= n_edges; ++e) { while (k < cuts.size() && cuts[k].edge < e) ++k; first_candidate_from_edge[e] = u32(k); }
+		}
+		cut_search_chunk chunk;
+		chunk.first = chunk_first[c];
+		chunk.end = chunk_first[c + 1];
+		scan_cut_search_chunk(graph, min_distance, cuts, first_candidate_from_edge, chunk);
+		std::size_t t(0);
+		for (std::size_t j(chunk.first); j < chunk.end; ++j)
+			for (std::size_t const t_end(chunk.trial_end[j - chunk.first]); t < t_end; ++t) cuts[j].improve(chunk.trials[t].class_count, cuts[chunk.trials[t].pred]);
+	}
+	return collect_cut_positions(cuts, graph, out);
+}
+
+} // namespace
+
+
+u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads, cut_trial_walker *walker)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	if (0 == threads) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	auto const &transposed(graph.paths_by_chrom_copy_and_edge);
+	bool const have_transposed(transposed.cols >= copies && transposed.rows >= graph.edge_count() && !transposed.words.empty());
+	if (!walker || 0 == copies || copies > walker->max_copies() || 0 == graph.edge_count() || !have_transposed)
+		return find_cut_positions(graph, min_distance, out, threads);
+	return find_cut_positions_walked(graph, min_distance, out, threads, *walker);
+}
 
 
 u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads)

@@ -25,6 +25,24 @@ constexpr u32 kCutPositionScoreMax = UINT32_MAX;   // find_cut_positions.hh:17
 // threads: as for find_matchings below.
 u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &cut_positions, unsigned threads = 1);
 
+// Something that walks chunks of the cut search elsewhere (the GPU: gpu_path.cc:gpu_cut_trial_walker over v2m_pbwt_cut_trials):
+// given every chunk's start state it produces, per chunk, the (earlier candidate, class count) pairs the reference's loop
+// would try at each candidate (find_cut_positions.cc:134-165), or marks the chunk as left undone.
+struct cut_trial_walker {
+	virtual ~cut_trial_walker() {}
+	virtual u64 max_copies() const = 0;
+	// cand_edge / cand_aligned: all candidates; chunk_first: n_chunks + 1 candidate indices; start_*: [n_chunks][n_copies];
+	// trial_pred / trial_class: n_chunks x capacity; trial_end: per candidate, within its chunk; status: per chunk, 0 = done
+	virtual void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
+		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
+		u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status) = 0;
+	// what the last search did: chunks walked by the walker / walked here after all
+	u64 chunks_walked{}, chunks_left{};
+};
+// The same search with the chunk walks handed to `walker` (the start states are still built here, on `threads` threads, and
+// the score updates stay sequential); chunks the walker leaves undone, and graphs it cannot take, are walked here.
+u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &cut_positions, unsigned threads, cut_trial_walker *walker);
+
 // Greedy assignment of path equivalence classes to founders.  assigned_samples receives the
 // (cut_positions.size() - 1) x founder_count matrix, column-major, one column per founder; slots that stay
 // unassigned hold kPloidyMax.  Returns false when there is nothing to match.

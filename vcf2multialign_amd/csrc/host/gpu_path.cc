@@ -10,7 +10,7 @@ gpu_context::gpu_context(int device)
 	if (V2M_OK != rc) throw gpu_error(rc, v2m_last_error(nullptr));
 }
 
-gpu_context::~gpu_context() { v2m_ctx_destroy(m_ctx); }
+gpu_context::~gpu_context() { if (m_owned) v2m_ctx_destroy(m_ctx); }
 
 void gpu_context::check(int rc) const
 {
@@ -56,6 +56,15 @@ void upload_path_blocks(gpu_context &gpu, variant_graph const &g, copy_interleav
 	auto const &m(g.paths_by_edge_and_chrom_copy);
 	u64 const first(std::min<u64>(m.rows, deal.block * rank));
 	gpu.check(v2m_upload_path_blocks(gpu.get(), m.words.empty() ? nullptr : m.words.data(), m.rows, m.cols, first, deal.block, deal.block * deal.world, m.rows));
+}
+
+
+void gpu_cut_trial_walker::walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
+	std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
+	u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status)
+{
+	m_gpu.check(v2m_pbwt_cut_trials(m_gpu.get(), n_copies, min_distance, cand_edge.size(), cand_edge.data(), cand_aligned.data(),
+		chunk_first.size() - 1, chunk_first.data(), start_order, start_divergence, capacity, trial_pred, trial_class, trial_end, status));
 }
 
 

@@ -5,6 +5,7 @@
 #include <string>
 
 #include "../../../include/v2m_hip.h"
+#include "founder.hh"
 #include "readers.hh"
 #include "variant_graph.hh"
 
@@ -18,6 +19,8 @@ struct gpu_error : std::runtime_error {
 class gpu_context {
 public:
 	explicit gpu_context(int device = 0);
+	struct borrowed {};
+	gpu_context(v2m_ctx *ctx, borrowed) : m_ctx(ctx), m_owned(false) {}   // somebody else's context (the Python binding's, in tests)
 	~gpu_context();
 	gpu_context(gpu_context const &) = delete;
 	gpu_context &operator=(gpu_context const &) = delete;
@@ -25,6 +28,7 @@ public:
 	void check(int rc) const;   // throws gpu_error with v2m_last_error()
 private:
 	v2m_ctx *m_ctx{};
+	bool m_owned{true};
 };
 
 // transpose_matrix (include/vcf2multialign/transpose_matrix.hh:14) on the GPU.
@@ -64,5 +68,18 @@ struct copy_interleave {
 	u64 local(u64 copy) const { return (copy / (block * world)) * block + copy % block; }   // the copy's index in its owner's matrix
 };
 void upload_path_blocks(gpu_context &gpu, variant_graph const &graph, copy_interleave deal, u32 rank);
+
+// The chunk walks of the founder cut search on the GPU (v2m_pbwt_cut_trials).  The context must hold the uploaded graph with
+// its path matrix (upload_graph(..., true)).
+class gpu_cut_trial_walker final : public cut_trial_walker {
+public:
+	explicit gpu_cut_trial_walker(gpu_context &gpu) : m_gpu(gpu) {}
+	u64 max_copies() const override { return 8192; }
+	void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
+		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
+		u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status) override;
+private:
+	gpu_context &m_gpu;
+};
 
 } // namespace v2m::host

@@ -170,6 +170,27 @@ uint64_t v2mh_find_founders_mt(void *h, uint64_t min_distance, uint32_t founder_
 	return cuts.size();
 }
 
+// find_cut_positions with the chunk walks on the GPU context `ctx` (a v2m_ctx * that holds this graph with its path matrix).
+// Returns the number of cut positions (0: no solution); cuts_out must hold node_count entries.
+uint64_t v2mh_find_cut_positions_gpu(void *h, void *ctx, uint64_t min_distance, unsigned threads, uint64_t *cuts_out, uint32_t *score_out, uint64_t *chunks_walked_and_left, char *err, size_t errlen)
+{
+	try {
+		vh::gpu_context gpu(static_cast<v2m_ctx *>(ctx), vh::gpu_context::borrowed{});
+		vh::gpu_cut_trial_walker walker(gpu);
+		std::vector<vh::u64> cuts;
+		vh::u32 const score(vh::find_cut_positions(HG(h).graph, min_distance, cuts, threads, &walker));
+		if (score_out) *score_out = score;
+		if (chunks_walked_and_left) { chunks_walked_and_left[0] = walker.chunks_walked; chunks_walked_and_left[1] = walker.chunks_left; }
+		if (vh::kCutPositionScoreMax == score) return 0;
+		std::copy(cuts.begin(), cuts.end(), cuts_out);
+		return cuts.size();
+	} catch (std::exception const &e) {
+		if (err && errlen) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+		if (score_out) *score_out = vh::kCutPositionScoreMax;
+		return 0;
+	}
+}
+
 uint64_t v2mh_find_founders(void *h, uint64_t min_distance, uint32_t founder_count, int keep_ref_edges,
 	uint64_t *cuts_out, uint32_t *assigned_out, uint64_t assigned_capacity, uint32_t *score_out)
 {

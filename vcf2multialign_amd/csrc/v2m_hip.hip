@@ -19,6 +19,7 @@
 
 #include "../../include/v2m_hip.h"
 #include "kernels.hpp"
+#include "founder_kernels.hpp"
 
 using v2m::u32;
 using v2m::u64;
@@ -1207,6 +1208,70 @@ int v2m_upload_path_blocks(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_r
 uint64_t v2m_aligned_length(const v2m_ctx *ctx) { return (ctx && ctx->has_graph) ? ctx->aligned_len : 0; }
 uint64_t v2m_min_row_pitch(const v2m_ctx *ctx) { return (ctx && ctx->has_graph) ? ((ctx->aligned_len + 255) & ~u64(255)) : 0; }
 uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx) { return (ctx && ctx->has_graph) ? ctx->ref_len + ctx->label_bytes : 0; }
+
+
+// ---- founder search: chunk walks ------------------------------------------------------------------
+
+int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
+	uint64_t n_candidates, const uint32_t *cand_edge, const uint64_t *cand_aligned_pos,
+	uint64_t n_chunks, const uint64_t *chunk_first, const uint32_t *start_order, const uint32_t *start_divergence,
+	uint64_t trial_capacity, uint32_t *trial_pred, uint32_t *trial_class_count, uint64_t *trial_end, uint32_t *chunk_status)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (!ctx->has_graph || !ctx->d_paths) return fail(ctx, V2M_ERR_STATE, "the founder search needs an uploaded graph with its path matrix");
+	if (0 == n_chunks) return V2M_OK;
+	if (!cand_edge || !cand_aligned_pos || !chunk_first || !start_order || !start_divergence || !trial_pred || !trial_class_count || !trial_end || !chunk_status)
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL array");
+	if (0 == n_copies || n_copies > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk holds at most %d chromosome copies (got %llu)", v2m::kPbwtMaxCopies, (unsigned long long) n_copies);
+	if (n_copies > ctx->path_cols) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the bound path matrix has %llu copies, %llu asked for", (unsigned long long) ctx->path_cols, (unsigned long long) n_copies);
+	if (n_candidates >= 0xFFFFFFFFull || ctx->n_edges >= 0xFFFFFFFDull) return fail(ctx, V2M_ERR_UNSUPPORTED, "candidate and edge indices are kept in 32 bits");
+	if (chunk_first[0] < 1 || chunk_first[n_chunks] > n_candidates) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds outside the candidate list");
+	for (u64 k(0); k < n_chunks; ++k) if (chunk_first[k] > chunk_first[k + 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds must not decrease");
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+	// edge-major bits: the bound matrix (rows = edges, columns = copies) transposed back on the device
+	u64 const rows(ctx->path_rows), cols(ctx->path_cols);              // both multiples of 64
+	dev_buf d_by_edge, d_first, d_cand_edge, d_cand_aln, d_chunk_first, d_order, d_div, d_pred, d_class, d_end, d_status;
+	V2M_HIP_TRY(ctx, d_by_edge.ensure(rows * (cols / 64) * sizeof(u64)));
+	if (int const rc = launch_transpose(ctx, ctx->d_paths, rows, cols, d_by_edge.as<u64>(), ctx->path_pitch, 0)) return rc;
+
+	auto const up([&](dev_buf &dst, void const *src, size_t bytes) -> int {
+		V2M_HIP_TRY(ctx, dst.ensure(std::max<size_t>(bytes, 16)));
+		if (bytes) V2M_HIP_TRY(ctx, hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+		return V2M_OK;
+	});
+	if (int const rc = up(d_cand_edge, cand_edge, n_candidates * sizeof(u32))) return rc;
+	if (int const rc = up(d_cand_aln, cand_aligned_pos, n_candidates * sizeof(u64))) return rc;
+	if (int const rc = up(d_chunk_first, chunk_first, (n_chunks + 1) * sizeof(u64))) return rc;
+	if (int const rc = up(d_order, start_order, n_chunks * n_copies * sizeof(u32))) return rc;
+	if (int const rc = up(d_div, start_divergence, n_chunks * n_copies * sizeof(u32))) return rc;
+	u32 const n_edges(u32(ctx->n_edges));
+	V2M_HIP_TRY(ctx, d_first.ensure((u64(n_edges) + 1) * sizeof(u32)));
+	V2M_HIP_TRY(ctx, d_pred.ensure(std::max<u64>(16, n_chunks * trial_capacity * sizeof(u32))));
+	V2M_HIP_TRY(ctx, d_class.ensure(std::max<u64>(16, n_chunks * trial_capacity * sizeof(u32))));
+	V2M_HIP_TRY(ctx, d_end.ensure(n_candidates * sizeof(u64)));
+	V2M_HIP_TRY(ctx, d_status.ensure(n_chunks * sizeof(u32)));
+	V2M_HIP_TRY(ctx, hipMemsetAsync(d_status.p, 0xFF, n_chunks * sizeof(u32), ctx->stream));
+	hipLaunchKernelGGL(v2m::pbwt_first_candidate_kernel, dim3(unsigned((u64(n_edges) + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
+		d_cand_edge.as<u32>(), u32(n_candidates), n_edges, d_first.as<u32>());
+	hipLaunchKernelGGL(v2m::pbwt_cut_trials_kernel, dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
+		d_by_edge.as<u64>(), u32(cols / 64), u32(n_copies), n_edges, d_first.as<u32>(), d_cand_edge.as<u32>(), d_cand_aln.as<u64>(), min_distance,
+		d_chunk_first.as<u64>(), d_order.as<u32>(), d_div.as<u32>(), trial_capacity, d_pred.as<u32>(), d_class.as<u32>(), d_end.as<u64>(), d_status.as<u32>());
+	V2M_HIP_TRY(ctx, hipGetLastError());
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_end, d_end.p, n_candidates * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	// only what the chunks produced comes back
+	for (u64 k(0); k < n_chunks; ++k) {
+		if (0 != chunk_status[k] || chunk_first[k] == chunk_first[k + 1]) { if (0 != chunk_status[k]) chunk_status[k] = 1; continue; }
+		u64 const n(trial_end[chunk_first[k + 1] - 1]);
+		if (n > trial_capacity) { chunk_status[k] = 1; continue; }
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_pred + k * trial_capacity, d_pred.as<u32>() + k * trial_capacity, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_class_count + k * trial_capacity, d_class.as<u32>() + k * trial_capacity, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+	}
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return V2M_OK;
+}
 
 
 // ---- rows -----------------------------------------------------------------------------------

@@ -170,6 +170,25 @@ class HostGraph:
 		assert w.size == rows // 64 * cols
 		_load().v2mh_set_paths_by_chrom_copy_and_edge(self._h, w.ctypes.data, rows, cols)
 
+	def find_cut_positions_gpu(self, ctx, min_distance=0, threads=0):
+		"""find_cut_positions with the chunk walks on the GPU (v2m_pbwt_cut_trials): `ctx` is a vcf2multialign_amd.Context that holds
+		this graph WITH its transposed path matrix.  Returns (cut_positions, score) or None."""
+		L = _load()
+		L.v2mh_find_cut_positions_gpu.restype = C.c_uint64
+		L.v2mh_find_cut_positions_gpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p, C.c_char_p, C.c_size_t]
+		n = len(self.reference_positions)
+		cuts = np.zeros(n, dtype=np.uint64)
+		score = C.c_uint32()
+		err = C.create_string_buffer(512)
+		chunks = (C.c_uint64 * 2)()
+		k = L.v2mh_find_cut_positions_gpu(self._h, ctx._h, min_distance, threads, cuts.ctypes.data, C.byref(score), chunks, err, len(err))
+		if err.value:
+			raise RuntimeError(err.value.decode())
+		self.gpu_chunks_walked, self.gpu_chunks_left = int(chunks[0]), int(chunks[1])   # by the GPU / by the host after all
+		if k == 0:
+			return None
+		return cuts[:k].tolist(), score.value
+
 	def find_founders(self, founder_count, min_distance=0, keep_ref_edges=False, threads=1):
 		"""find_cut_positions + find_matchings (host algorithms).  Returns (cut_positions, assigned_samples column-major, score)
 		or None when there is no solution.  threads > 1 (0 = automatic) spreads the matching's pBWT over threads."""
