@@ -253,6 +253,24 @@ int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	uint64_t n_chunks, const uint64_t *chunk_first, const uint32_t *start_order, const uint32_t *start_divergence,
 	uint64_t trial_capacity, uint32_t *trial_pred, uint32_t *trial_class_count, uint64_t *trial_end, uint32_t *chunk_status);
 
+/* The same for founder_sequence_greedy_output::find_matchings (libvcf2multialign/founder_sequence_greedy_output.cc:154-512): the
+ * pBWT steps between cut positions and, at every cut, what the reference's loop :215-251 collects -- the number of path classes
+ * of the block that ends there, the first copy in pBWT order and whether it followed REF edges only (:454-462), and the joined
+ * classes {class in the previous block, class in this block, copies} of the two-block span, in pBWT order (the caller sorts
+ * them by size, :256, and runs the greedy assignment, :254-457, which is strictly sequential).
+ *   cut_edge[j]                   ALT edges before cut node j (alt_edge_count_csum[cut_positions[j]]), ascending, n_cuts entries
+ *   chunk_first_cut[k] .. [k+1]   the cuts chunk k handles (>= 1); start_edge[k] <= cut_edge[chunk_first_cut[k] - 1]: the given
+ *                                 state (start_order / start_divergence, [n_chunks][n_copies], divergence biased) is the one after
+ *                                 that many edges; the kernel walks on to the cut before the chunk's first one by itself
+ * Outputs (host): per chunk up to pool_capacity joined classes at pool_lhs / pool_rhs / pool_size + k * pool_capacity
+ * (0xFFFFFFFF = PLOIDY_MAX, "no class"); per cut j >= 1 rec_pool_end[j] (the chunk's joined classes up to and including cut j),
+ * rec_distinct[j], rec_first_class[j], rec_first_is_ref[j]; chunk_status[k] = 0, or 1 when the chunk was left undone
+ * (pool_capacity exceeded).  Same requirements on the ctx as v2m_pbwt_cut_trials.  Synchronous. */
+int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const uint32_t *cut_edge,
+	uint64_t n_chunks, const uint64_t *chunk_first_cut, const uint32_t *start_edge, const uint32_t *start_order, const uint32_t *start_divergence,
+	uint64_t pool_capacity, uint32_t *pool_lhs, uint32_t *pool_rhs, uint32_t *pool_size,
+	uint64_t *rec_pool_end, uint32_t *rec_distinct, uint32_t *rec_first_class, uint32_t *rec_first_is_ref, uint32_t *chunk_status);
+
 /* ---- verification helper ------------------------------------------------------------------ */
 
 /* 64-bit position-sensitive checksum of each of n_rows device rows (row i = d_rows + i*row_pitch,

@@ -48,6 +48,14 @@ def test_reference_cut_positions(v2m, HostGraph, case, fixtures_dir):
 	og = oracle.build_variant_graph(fa, vcf, case["chromosome"])
 	(cuts, score), _ = _gpu_cuts(v2m, HostGraph, og, fa, vcf, case["minimum_distance"])
 	assert cuts == case["cut_positions"]                               # REQUIRE(expected_cut_positions == output.cut_positions())
+	# ... and the matchings (v2m_pbwt_cut_records + the host's greedy assignment)
+	hg = HostGraph(fa, vcf, case["chromosome"])
+	hg.set_transposed_paths(og.paths_by_chrom_copy_and_edge, og.path_rows, og.path_cols)
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(v2m.VariantGraph.from_object(og), og.ref)
+		cuts, assigned, _ = hg.find_founders_gpu(ctx, case["founder_count"], case["minimum_distance"])
+	assert cuts == case["cut_positions"]
+	assert assigned == case["assigned_samples_column_major"]           # REQUIRE(expected_matchings == output.assigned_samples())
 
 
 @pytest.mark.parametrize("seed,ref_len,n_variants,n_samples,kw", [
@@ -75,6 +83,19 @@ def test_random_inputs(v2m, HostGraph, tmp_path, seed, ref_len, n_variants, n_sa
 		assert (got is None) == (want is None), min_distance
 		if want is not None:
 			assert got[0] == want[0] and got[1] == want[2], min_distance
+	# the matchings: cut search + matching with the chunk walks of both on the GPU == the host's sequential loops
+	hg = HostGraph(fa, vcf, "1")
+	hg.set_transposed_paths(og.paths_by_chrom_copy_and_edge, og.path_rows, og.path_cols)
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(v2m.VariantGraph.from_object(og), og.ref)
+		for founders, min_distance, keep in ((1, 0, False), (2, 0, False), (3, 10, True), (7, 50, False), (25, 50, False), (4, 1000, True)):
+			want = hg.find_founders(founders, min_distance, keep_ref_edges=keep, threads=1)
+			got = hg.find_founders_gpu(ctx, founders, min_distance, keep_ref_edges=keep, threads=3)
+			assert got == want, (founders, min_distance, keep)
+			if want is not None and len(want[0]) > 2:
+				assert hg.gpu_chunks[1] == 0 and hg.gpu_chunks[3] == 0 and hg.gpu_chunks[2] >= 1, hg.gpu_chunks
+				# given cut positions (--input-cut-positions): the states are built for the matching alone
+				assert hg.find_founders_gpu(ctx, founders, min_distance, keep_ref_edges=keep, threads=2, cut_positions=want[0])[1] == want[1]
 	if seed <= 8:                                                            # and the oracle's literal restatement directly
 		exp = og.find_founders(2, 50)
 		got, _ = _gpu_cuts(v2m, HostGraph, og, fa, vcf, 50)
@@ -94,6 +115,14 @@ def test_chunks_the_gpu_leaves_undone_are_walked_on_the_host(v2m, HostGraph, tmp
 	got, hg = _gpu_cuts(v2m, HostGraph, og, fa, vcf, 20)
 	assert hg.gpu_chunks_left >= 1
 	assert got == want
+	monkeypatch.delenv("V2M_FOUNDER_TRIAL_CAPACITY")
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(v2m.VariantGraph.from_object(og), og.ref)
+		full = hg.find_founders_gpu(ctx, 6, 20, threads=4)
+		assert hg.gpu_chunks[3] == 0 and full == hg.find_founders(6, 20, threads=1)
+		monkeypatch.setenv("V2M_FOUNDER_POOL_CAPACITY", "300")
+		assert hg.find_founders_gpu(ctx, 6, 20, threads=4) == full
+		assert hg.gpu_chunks[3] >= 1                                       # some chunks' joined classes did not fit: walked on the host
 
 
 def test_refuses_what_it_cannot_hold(v2m):

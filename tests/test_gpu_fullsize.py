@@ -324,6 +324,19 @@ def test_config4_full_size(env):
 		res1 = hg.find_founders(founders, min_dist, keep_ref_edges=False, threads=1)
 		crc = lambda r: (zlib.crc32(np.asarray(r[0], dtype=np.uint64).tobytes()), zlib.crc32(np.asarray(r[1], dtype=np.uint32).tobytes()), r[2])
 		assert crc(res1) == crc(res)                                  # the chunked multi-thread search == the sequential loop
+		# ... == the search with its chunk walks on the GPU (v2m_pbwt_cut_trials): every chunk walked there, same cuts, same score
+		import time
+		t0 = time.time()
+		gpu_cuts, gpu_score = hg.find_cut_positions_gpu(ctx, min_dist, threads=16)
+		print("config 4 cut search with GPU chunk walks: %.2f s, %d chunks on the GPU, %d on the host" % (time.time() - t0, hg.gpu_chunks_walked, hg.gpu_chunks_left))
+		assert hg.gpu_chunks_walked > 100 and hg.gpu_chunks_left == 0
+		assert zlib.crc32(np.asarray(gpu_cuts, dtype=np.uint64).tobytes()) == crc(res)[0] and gpu_score == score
+		# ... and both searches that way (v2m_pbwt_cut_records for the matching): same cuts, same 672 495 x 25 matchings, same score
+		t0 = time.time()
+		res_gpu = hg.find_founders_gpu(ctx, founders, min_dist, keep_ref_edges=False, threads=16)
+		print("config 4 cut search + matching with GPU chunk walks: %.2f s, chunks (search GPU, host; matching GPU, host) = %s" % (time.time() - t0, hg.gpu_chunks))
+		assert hg.gpu_chunks[1] == 0 and hg.gpu_chunks[3] == 0 and hg.gpu_chunks[2] > 100
+		assert crc(res_gpu) == crc(res)
 
 		batch_rows = [v2m.PLOIDY_MAX] + [list(zip(cuts[:-1], assigned[f * n_seg:(f + 1) * n_seg])) for f in range(founders)]
 		pitch = ctx.min_row_pitch

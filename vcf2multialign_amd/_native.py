@@ -68,6 +68,8 @@ SIGNATURES = {
 	"v2m_splice_rows_device": (C.c_int, [C.c_void_p, C.POINTER(RowBatchStruct), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
 	"v2m_pbwt_cut_trials": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
 		C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+	"v2m_pbwt_cut_records": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+		C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
 	"v2m_alloc_output": (C.c_int, [C.c_void_p, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
 	"v2m_free_output": (C.c_int, [C.c_void_p, C.c_void_p]),
 	"v2m_checksum_rows_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p]),

@@ -65,6 +65,65 @@ __device__ __forceinline__ pbwt_scan_item scan_shfl_up(pbwt_scan_item const &x, 
 	return y;
 }
 
+// One step of Durbin's algorithm 2 for edge `edge` (pbwt.hh:77-134) by the whole workgroup: state order[cur] / divergence[cur]
+// -> order[cur ^ 1] / divergence[cur ^ 1].  Thread t owns the copies [my_begin, my_end) of the order.  Returns how many copies do
+// NOT use the edge (workgroup-uniform).  Contains three barriers; the caller flips `cur`.
+__device__ __forceinline__ uint32_t pbwt_step(
+	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge,
+	unsigned short (*order)[kPbwtMaxCopies], uint32_t (*divergence)[kPbwtMaxCopies], uint64_t *column, pbwt_scan_item *wave_items,
+	int cur, uint32_t my_begin, uint32_t my_end, int t, int lane, int wave)
+{
+	for (uint32_t w = t; w < words_per_edge; w += kPbwtThreads) column[w] = paths_by_edge[(uint64_t) edge * words_per_edge + w];
+	__syncthreads();
+	unsigned short const *const ord = order[cur];
+	uint32_t const *const dv = divergence[cur];
+	// what this thread's run of copies does to the zero count and to the two running maxima
+	pbwt_scan_item mine{0u, max_chain{0u, 0u}, max_chain{0u, 0u}};
+	uint32_t flags = 0;
+	for (uint32_t i = my_begin; i < my_end; ++i) {
+		uint32_t const copy = ord[i], d = dv[i];
+		uint32_t const f = (uint32_t) (column[copy >> 6] >> (copy & 63)) & 1u;
+		flags |= f << (i - my_begin);
+		pbwt_scan_item one;
+		one.zeros = 1u - f;
+		one.p = f ? max_chain{d, 0u} : max_chain{1u, 1u};      // a copy of class 0 takes p and leaves biased 0 behind
+		one.q = f ? max_chain{1u, 1u} : max_chain{d, 0u};
+		mine = scan_combine(mine, one);
+	}
+	// exclusive scan over the threads: inside the wave, then over the waves' totals
+	pbwt_scan_item incl = mine;
+#pragma unroll
+	for (int delta = 1; delta < 64; delta <<= 1) {
+		pbwt_scan_item const up = scan_shfl_up(incl, delta);
+		if (lane >= delta) incl = scan_combine(up, incl);
+	}
+	if (lane == 63) wave_items[wave] = incl;
+	__syncthreads();
+	pbwt_scan_item before{0u, max_chain{0u, 0u}, max_chain{0u, 0u}};      // identity: no copies
+	uint32_t zeros_total = 0;
+	for (int w = 0; w < kPbwtWaves; ++w) {
+		pbwt_scan_item const wi = wave_items[w];
+		if (w < wave) before = scan_combine(before, wi);
+		zeros_total += wi.zeros;
+	}
+	pbwt_scan_item const lane_before = scan_shfl_up(incl, 1);
+	if (lane) before = scan_combine(before, lane_before);
+	// second pass: place the copies (stable partition) with their new divergence values
+	uint32_t p = chain_apply(before.p, edge + 2u), q = chain_apply(before.q, edge + 2u);   // biased edge + 1 (pbwt.hh:93)
+	uint32_t zero_at = before.zeros, one_at = zeros_total + (my_begin - before.zeros);
+	unsigned short *const out_ord = order[cur ^ 1];
+	uint32_t *const out_dv = divergence[cur ^ 1];
+	for (uint32_t i = my_begin; i < my_end; ++i) {
+		uint32_t const copy = ord[i], d = dv[i];
+		p = p > d ? p : d;
+		q = q > d ? q : d;
+		if (!((flags >> (i - my_begin)) & 1u)) { out_ord[zero_at] = (unsigned short) copy; out_dv[zero_at] = p; ++zero_at; p = 1u; }
+		else { out_ord[one_at] = (unsigned short) copy; out_dv[one_at] = q; ++one_at; q = 1u; }
+	}
+	__syncthreads();
+	return zeros_total;
+}
+
 // One workgroup per chunk.  See v2m_pbwt_cut_trials() in include/v2m_hip.h for the arguments.
 __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 	uint64_t const *__restrict__ paths_by_edge,          // edge-major bits: column e = words [e * words_per_edge, +words_per_edge), bit c = copy c
@@ -112,54 +171,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		// ---- the edges before this candidate's node (find_cut_positions.cc:170-176 over pbwt.hh:77-134) -----------------
 		uint32_t const upto = cand_edge[cand];
 		for (; edge < upto; ++edge) {
-			for (uint32_t w = t; w < words_per_edge; w += kPbwtThreads) column[w] = paths_by_edge[(uint64_t) edge * words_per_edge + w];
-			__syncthreads();
-			unsigned short const *const ord = order[cur];
-			uint32_t const *const dv = divergence[cur];
-			// what this thread's run of copies does to the zero count and to the two running maxima
-			pbwt_scan_item mine{0u, max_chain{0u, 0u}, max_chain{0u, 0u}};
-			uint32_t flags = 0;
-			for (uint32_t i = my_begin; i < my_end; ++i) {
-				uint32_t const copy = ord[i], d = dv[i];
-				uint32_t const f = (uint32_t) (column[copy >> 6] >> (copy & 63)) & 1u;
-				flags |= f << (i - my_begin);
-				pbwt_scan_item one;
-				one.zeros = 1u - f;
-				one.p = f ? max_chain{d, 0u} : max_chain{1u, 1u};      // a copy of class 0 takes p and leaves biased 0 behind
-				one.q = f ? max_chain{1u, 1u} : max_chain{d, 0u};
-				mine = scan_combine(mine, one);
-			}
-			// exclusive scan over the threads: inside the wave, then over the waves' totals
-			pbwt_scan_item incl = mine;
-#pragma unroll
-			for (int delta = 1; delta < 64; delta <<= 1) {
-				pbwt_scan_item const up = scan_shfl_up(incl, delta);
-				if (lane >= delta) incl = scan_combine(up, incl);
-			}
-			if (lane == 63) wave_items[wave] = incl;
-			__syncthreads();
-			pbwt_scan_item before{0u, max_chain{0u, 0u}, max_chain{0u, 0u}};      // identity: no copies
-			uint32_t zeros_total = 0;
-			for (int w = 0; w < kPbwtWaves; ++w) {
-				pbwt_scan_item const wi = wave_items[w];
-				if (w < wave) before = scan_combine(before, wi);
-				zeros_total += wi.zeros;
-			}
-			pbwt_scan_item const lane_before = scan_shfl_up(incl, 1);
-			if (lane) before = scan_combine(before, lane_before);
-			// second pass: place the copies (stable partition) with their new divergence values
-			uint32_t p = chain_apply(before.p, edge + 2u), q = chain_apply(before.q, edge + 2u);   // biased edge + 1 (pbwt.hh:93)
-			uint32_t zero_at = before.zeros, one_at = zeros_total + (my_begin - before.zeros);
-			unsigned short *const out_ord = order[cur ^ 1];
-			uint32_t *const out_dv = divergence[cur ^ 1];
-			for (uint32_t i = my_begin; i < my_end; ++i) {
-				uint32_t const copy = ord[i], d = dv[i];
-				p = p > d ? p : d;
-				q = q > d ? q : d;
-				if (!((flags >> (i - my_begin)) & 1u)) { out_ord[zero_at] = (unsigned short) copy; out_dv[zero_at] = p; ++zero_at; p = 1u; }
-				else { out_ord[one_at] = (unsigned short) copy; out_dv[one_at] = q; ++one_at; q = 1u; }
-			}
-			__syncthreads();
+			pbwt_step(paths_by_edge, words_per_edge, edge, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
 			cur ^= 1;
 		}
 
@@ -260,6 +272,170 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		}
 		if (t == 0) trial_end[cand] = n_trials;
 		__syncthreads();                                                // sorted_* are rewritten by the next candidate
+	}
+	if (t == 0) chunk_status[chunk] = 0u;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same walk for find_matchings (founder_sequence_greedy_output.cc:154-512): at every cut position the path classes of the
+// block that ends there and of the two-block span that ends there (:215-251).  A class starts at every copy (in pBWT order)
+// whose divergence value lies past the block's / the span's first edge; the host's loop is a running "last such copy" plus a
+// run-length count, i.e. a max-scan and a compaction.  The greedy assignment itself (:254-457) is strictly sequential and
+// stays on the host, which also sorts each cut's joined classes (std::sort on the same input in the same order as the
+// reference, so ties fall the same way).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr uint32_t kPbwtNoClass = 0xFFFFu;            // the host's kPloidyMax in the 16-bit class arrays
+
+struct class_scan_item {
+	int last_block_start;     // last index with a block-class boundary, -1 = none yet
+	uint32_t block_starts;    // boundaries of the block (prev_cut_edge < d)
+	uint32_t span_starts;     // boundaries of the two-block span (cut_pair_edge < d)
+};
+
+__device__ __forceinline__ class_scan_item class_combine(class_scan_item const &a, class_scan_item const &b)
+{
+	return class_scan_item{b.last_block_start > a.last_block_start ? b.last_block_start : a.last_block_start, a.block_starts + b.block_starts, a.span_starts + b.span_starts};
+}
+
+__device__ __forceinline__ class_scan_item class_shfl_up(class_scan_item const &x, int delta)
+{
+	return class_scan_item{__shfl_up(x.last_block_start, delta, 64), __shfl_up(x.block_starts, delta, 64), __shfl_up(x.span_starts, delta, 64)};
+}
+
+// "threshold < unbiased(d)" with d biased: 0 is the reference's DIVERGENCE_MAX ("no match yet": starts a class)
+__device__ __forceinline__ bool past_edge(uint32_t d, uint32_t threshold) { return 0u == d || d - 1u > threshold; }
+
+__global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
+	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t n_copies,
+	uint32_t const *__restrict__ cut_edge,                // [n_cuts]: edges before each cut node
+	uint64_t const *__restrict__ chunk_first_cut,         // [n_chunks + 1]: chunk k handles the cuts [first[k], first[k + 1]); first[k] >= 1
+	uint32_t const *__restrict__ start_edge,              // [n_chunks]: the given state is the one after this many edges (<= cut_edge[first[k] - 1])
+	uint32_t const *__restrict__ start_order, uint32_t const *__restrict__ start_divergence,   // [n_chunks][n_copies]
+	uint64_t pool_capacity, uint32_t *__restrict__ pool_lhs, uint32_t *__restrict__ pool_rhs, uint32_t *__restrict__ pool_size,   // [n_chunks][pool_capacity]
+	uint64_t *__restrict__ rec_pool_end,                  // [n_cuts]: joined classes of the chunk up to and including this cut
+	uint32_t *__restrict__ rec_distinct, uint32_t *__restrict__ rec_first_class, uint32_t *__restrict__ rec_first_is_ref,   // [n_cuts]
+	uint32_t *__restrict__ chunk_status)
+{
+	__shared__ unsigned short order[2][kPbwtMaxCopies];
+	__shared__ uint32_t divergence[2][kPbwtMaxCopies];
+	__shared__ uint64_t column[kPbwtMaxCopies / 64];
+	__shared__ pbwt_scan_item wave_items[kPbwtWaves];
+	__shared__ class_scan_item class_items[kPbwtWaves];
+	__shared__ unsigned short copy_class[2][kPbwtMaxCopies];      // per copy: the representative of its class at the last / the previous cut
+	__shared__ unsigned short span_start_index[kPbwtMaxCopies];   // per joined class: where it starts in the order
+
+	int const t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	uint32_t const chunk = blockIdx.x;
+	uint64_t const cut_begin = chunk_first_cut[chunk], cut_end = chunk_first_cut[chunk + 1];
+	if (cut_begin >= cut_end) { if (t == 0) chunk_status[chunk] = 0u; return; }
+	uint32_t const per = (n_copies + kPbwtThreads - 1) / kPbwtThreads;
+	uint32_t const my_begin = (uint32_t) t * per < n_copies ? (uint32_t) t * per : n_copies;
+	uint32_t const my_end = my_begin + per < n_copies ? my_begin + per : n_copies;
+
+	for (uint32_t i = t; i < n_copies; i += kPbwtThreads) {
+		order[0][i] = (unsigned short) start_order[(uint64_t) chunk * n_copies + i];
+		divergence[0][i] = start_divergence[(uint64_t) chunk * n_copies + i];
+		copy_class[0][i] = (unsigned short) kPbwtNoClass;
+		copy_class[1][i] = (unsigned short) kPbwtNoClass;
+	}
+	__syncthreads();
+
+	int cur = 0, rhs = 0;                                  // copy_class[rhs]: the classes the last cut left behind
+	uint32_t edge = start_edge[chunk];
+	// up to the cut before the chunk's first one; the classes it left behind (founder.cc:scan_cut_chunk)
+	uint64_t const start_cut = cut_begin - 1;
+	for (uint32_t const upto = cut_edge[start_cut]; edge < upto; ++edge) {
+		pbwt_step(paths_by_edge, words_per_edge, edge, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
+		cur ^= 1;
+	}
+
+	// The classes of a threshold: every copy's representative = the copy at the last boundary at or before it.
+	// with_span: also the joined classes of the two-block span, written to the pool.  Returns false when the pool is full.
+	uint64_t n_pool = 0;
+	uint32_t *const my_lhs = pool_lhs + (uint64_t) chunk * pool_capacity, *const my_rhs = pool_rhs + (uint64_t) chunk * pool_capacity, *const my_size = pool_size + (uint64_t) chunk * pool_capacity;
+	auto const classes_at_cut = [&](uint32_t block_threshold, bool with_span, uint32_t span_threshold, uint32_t &distinct_out) -> bool {
+		unsigned short const *const ord = order[cur];
+		uint32_t const *const dv = divergence[cur];
+		class_scan_item mine{-1, 0u, 0u};
+		for (uint32_t i = my_begin; i < my_end; ++i) {
+			uint32_t const d = dv[i];
+			if (past_edge(d, block_threshold)) { mine.last_block_start = (int) i; ++mine.block_starts; }
+			if (with_span && past_edge(d, span_threshold)) ++mine.span_starts;
+		}
+		class_scan_item incl = mine;
+#pragma unroll
+		for (int delta = 1; delta < 64; delta <<= 1) {
+			class_scan_item const up = class_shfl_up(incl, delta);
+			if (lane >= delta) incl = class_combine(up, incl);
+		}
+		if (lane == 63) class_items[wave] = incl;
+		__syncthreads();
+		class_scan_item before{-1, 0u, 0u}, total{-1, 0u, 0u};
+		for (int w = 0; w < kPbwtWaves; ++w) {
+			class_scan_item const wi = class_items[w];
+			if (w < wave) before = class_combine(before, wi);
+			total = class_combine(total, wi);
+		}
+		class_scan_item const lane_before = class_shfl_up(incl, 1);
+		if (lane) before = class_combine(before, lane_before);
+		distinct_out = total.block_starts;
+		bool const fits = !with_span || n_pool + total.span_starts <= pool_capacity;     // (workgroup-uniform)
+		// second pass: representatives, class arrays, joined-class heads
+		int last = before.last_block_start;
+		uint32_t span_at = before.span_starts;
+		unsigned short const *const lhs_class = copy_class[rhs];       // (the previous cut's classes: read)
+		unsigned short *const rhs_class = copy_class[rhs ^ 1];         // (this cut's: written; the arrays swap roles below)
+		for (uint32_t i = my_begin; i < my_end; ++i) {
+			uint32_t const d = dv[i], copy = ord[i];
+			if (past_edge(d, block_threshold)) last = (int) i;
+			uint32_t const rep = last >= 0 ? (uint32_t) ord[last] : kPbwtNoClass;
+			if (with_span && fits && past_edge(d, span_threshold)) {
+				uint32_t const l = lhs_class[copy];
+				my_lhs[n_pool + span_at] = kPbwtNoClass == l ? 0xFFFFFFFFu : l;
+				my_rhs[n_pool + span_at] = kPbwtNoClass == rep ? 0xFFFFFFFFu : rep;
+				span_start_index[span_at] = (unsigned short) i;
+				++span_at;
+			}
+			rhs_class[copy] = (unsigned short) rep;
+		}
+		__syncthreads();
+		if (with_span && fits) {
+			for (uint32_t j = t; j < total.span_starts; j += kPbwtThreads)
+				my_size[n_pool + j] = (j + 1 < total.span_starts ? (uint32_t) span_start_index[j + 1] : n_copies) - (uint32_t) span_start_index[j];
+			n_pool += total.span_starts;
+		}
+		rhs ^= 1;
+		__syncthreads();                                                // class_items / span_start_index are rewritten by the next call
+		return fits;
+	};
+
+	if (start_cut >= 1) {
+		uint32_t ignored;
+		classes_at_cut(cut_edge[start_cut - 1], false, 0u, ignored);
+	}
+
+	bool first_is_ref = true;
+	for (uint64_t cut = cut_begin; cut < cut_end; ++cut) {
+		for (uint32_t const upto = cut_edge[cut]; edge < upto; ++edge) {
+			uint32_t const zeros = pbwt_step(paths_by_edge, words_per_edge, edge, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
+			cur ^= 1;
+			// the copy that is first in the order now uses the edge exactly when no copy does not (:454-462)
+			first_is_ref = first_is_ref && 0u != zeros;
+		}
+		uint32_t distinct = 0;
+		bool const fits = classes_at_cut(cut_edge[cut - 1], cut >= 2, cut >= 2 ? cut_edge[cut - 2] : 0u, distinct);
+		if (!fits) {                                                    // (workgroup-uniform) the pool is full: the host takes the chunk
+			if (t == 0) chunk_status[chunk] = 1u;
+			return;
+		}
+		if (t == 0) {
+			rec_pool_end[cut] = n_pool;
+			rec_distinct[cut] = distinct;
+			rec_first_class[cut] = order[cur][0];
+			rec_first_is_ref[cut] = first_is_ref ? 1u : 0u;
+		}
+		first_is_ref = true;
 	}
 	if (t == 0) chunk_status[chunk] = 0u;
 }

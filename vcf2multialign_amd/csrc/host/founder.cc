@@ -6,6 +6,8 @@
 #include <mutex>
 #include <exception>
 #include <thread>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
@@ -341,8 +343,20 @@ struct matcher {
 	class_to_founder_map founder_by_class;         // class representative of the previous block -> founder
 	std::vector<char> reserved;
 	std::vector<u32> loose_rhs;
+	std::vector<u32> reserved_set;                 // the entries of `reserved` that are 1
+	void reserve(u32 rep) { reserved[rep] = 1; reserved_set.push_back(rep); }
 
-	u32 &slot(std::size_t row, u32 founder) { return assigned[founder * rows + row]; }
+	// The assignment is produced row by row and every row touches all founders, so it is kept row-major here (one cache line or
+	// two per cut instead of one per founder, each rows * 4 bytes apart) and turned into the reference's column-major matrix
+	// (founder_sequence_greedy_output.cc:171) at the end: finish().
+	std::vector<u32> by_row = std::vector<u32>(rows * founders, kPloidyMax);
+	u32 &slot(std::size_t row, u32 founder) { return by_row[row * founders + founder]; }
+	void finish()
+	{
+		for (std::size_t row(0); row < rows; ++row)
+			for (u32 f(0); f < founders; ++f) assigned[f * rows + row] = by_row[row * founders + f];
+		std::vector<u32>().swap(by_row);
+	}
 
 	// second cut: seed row 0 (:248-302)
 	void seed(std::vector<joined_class> const &joined, u32 lhs_distinct)
@@ -361,7 +375,7 @@ struct matcher {
 				if (free_founders) { --free_founders; give(*c); }
 			} else if (reserved_left) {
 				--reserved_left;
-				reserved[c->lhs_rep] = 1;
+				reserve(c->lhs_rep);
 				give(*c);
 			}
 		}
@@ -372,7 +386,10 @@ struct matcher {
 	// every cut from the second on: continue the founders into the block on the right (:304-442)
 	void extend(std::size_t row, std::vector<joined_class> const &joined, u32 rhs_distinct)
 	{
-		std::fill(reserved.begin(), reserved.end(), 0);
+		// (only what the previous cut set: clearing all of `reserved` -- one byte per chromosome copy -- at each of several hundred
+		// thousand cuts was most of the assignment's time)
+		for (u32 const rep : reserved_set) reserved[rep] = 0;
+		reserved_set.clear();
 		loose_rhs.clear();
 		u32 free_founders(founders);
 		u32 reserved_left(std::min(free_founders, rhs_distinct));
@@ -408,7 +425,7 @@ struct matcher {
 					}
 				} else if (reserved_left) {
 					--reserved_left;
-					if (follow(*c)) reserved[c->rhs_rep] = 1;
+					if (follow(*c)) reserve(c->rhs_rep);
 					else loose_rhs.push_back(c->rhs_rep);
 				}
 			}
@@ -421,7 +438,7 @@ struct matcher {
 		for (u32 const rhs_rep : loose_rhs) {
 			if (!reserved[rhs_rep]) {
 				place_anywhere(rhs_rep);
-				reserved[rhs_rep] = 1;
+				reserve(rhs_rep);
 			}
 		}
 		// step 5 (:418-428): founders still without a continuation
@@ -505,6 +522,7 @@ bool find_matchings_sequential(
 		}
 	}
 
+	m.finish();
 	if (1 == cuts_seen) {                                                     // a single block (:468-507)
 		u32 rep(kPloidyMax);
 		joined.clear();
@@ -757,10 +775,195 @@ bool find_matchings_chunked(
 			std::vector<joined_class>().swap(chunk.pool);
 			std::vector<cut_record>().swap(chunk.records);
 		});
+	m.finish();
 	return true;
 }
 
 } // namespace
+
+
+namespace {
+
+// V2M_FOUNDER_TIMING=1: where the walked searches spend their time, on stderr.
+struct phase_timer {
+	bool const on{nullptr != std::getenv("V2M_FOUNDER_TIMING")};
+	std::chrono::steady_clock::time_point last{std::chrono::steady_clock::now()};
+	void mark(char const *what)
+	{
+		if (!on) return;
+		auto const now(std::chrono::steady_clock::now());
+		std::fprintf(stderr, "[founder] %-40s %7.3f s\n", what, std::chrono::duration<double>(now - last).count());
+		last = now;
+	}
+};
+
+// pBWT states after the given numbers of edges, built from scratch on `threads` threads (pbwt_state_at).
+void build_states(variant_graph const &graph, std::vector<u32> const &edges, unsigned threads, std::unique_ptr<u32[]> &order, std::unique_ptr<u32[]> &divergence)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	order.reset(new u32[edges.size() * copies]);
+	divergence.reset(new u32[edges.size() * copies]);
+	std::atomic<std::size_t> next(0);
+	std::exception_ptr error;
+	std::mutex error_mutex;
+	auto const work([&] {
+		try {
+			for (std::size_t c; (c = next.fetch_add(1)) < edges.size();) {
+				edge_pbwt pbwt(copies, nullptr);
+				pbwt_state_at(graph, edges[c], pbwt);
+				std::copy(pbwt.order.begin(), pbwt.order.end(), order.get() + c * copies);
+				std::copy(pbwt.divergence.begin(), pbwt.divergence.end(), divergence.get() + c * copies);
+			}
+		} catch (...) {
+			std::lock_guard<std::mutex> const lock(error_mutex);
+			if (!error) error = std::current_exception();
+		}
+	});
+	std::vector<std::thread> pool;
+	for (unsigned t(1); t < std::max(1u, threads); ++t) pool.emplace_back(work);
+	work();
+	for (auto &t : pool) t.join();
+	if (error) std::rethrow_exception(error);
+}
+
+
+// find_matchings_chunked() with the chunk walks done by `walker`: it leaves, per cut, the joined classes in pBWT order; they
+// are sorted here (the reference's std::sort on the reference's input order, founder_sequence_greedy_output.cc:256) on the
+// threads, and the assignment consumes them in cut order.
+bool find_matchings_walked(
+	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
+	std::vector<u32> &assigned, unsigned threads, founder_walker &walker)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	std::size_t const n_cuts(cut_positions.size());
+	std::size_t const rows(n_cuts - 1);
+	u64 const n_edges(graph.edge_count());
+	check_edge_range(graph);
+	assigned.assign(rows * founder_count, kPloidyMax);
+	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}};
+
+	phase_timer timer;
+	std::vector<u32> cut_edge(n_cuts);
+	for (std::size_t j(0); j < n_cuts; ++j) cut_edge[j] = u32(graph.alt_edge_count_csum[cut_positions[j]]);
+
+	// start states: the cut search's if it has just run on this graph, else one every 8192 edges
+	if (walker.state_edge.empty() || walker.state_copies != copies || 0 != walker.state_edge.front()) {
+		walker.state_edge.clear();
+		for (u64 e(0); e < std::max<u64>(1, n_edges); e += 8192) walker.state_edge.push_back(u32(e));
+		build_states(graph, walker.state_edge, threads, walker.state_order, walker.state_divergence);
+		walker.state_copies = copies;
+	}
+	timer.mark("matching: start states");
+	std::size_t const n_chunks(walker.state_edge.size());
+	// chunk k: from the first cut at or past its state (the walker steps on to it), the cuts after that one up to and including
+	// the first cut at or past the next state
+	std::vector<u64> chunk_first_cut(n_chunks + 1);
+	for (std::size_t k(0); k < n_chunks; ++k) {
+		std::size_t const start_cut(std::size_t(std::lower_bound(cut_edge.begin(), cut_edge.end(), walker.state_edge[k]) - cut_edge.begin()));
+		chunk_first_cut[k] = std::min<u64>(start_cut + 1, n_cuts);
+	}
+	chunk_first_cut[n_chunks] = n_cuts;
+	for (std::size_t k(n_chunks); k-- > 0;) chunk_first_cut[k] = std::min(chunk_first_cut[k], chunk_first_cut[k + 1]);
+
+	u64 max_chunk_cuts(0);
+	for (std::size_t k(0); k < n_chunks; ++k) max_chunk_cuts = std::max<u64>(max_chunk_cuts, chunk_first_cut[k + 1] - chunk_first_cut[k]);
+	u64 pool_capacity(4096 + 128 * max_chunk_cuts);
+	if (char const *const e = std::getenv("V2M_FOUNDER_POOL_CAPACITY")) if (*e) pool_capacity = std::max<u64>(1, std::strtoull(e, nullptr, 10));   // test knob
+	std::unique_ptr<u32[]> pool_lhs(new u32[n_chunks * pool_capacity]), pool_rhs(new u32[n_chunks * pool_capacity]), pool_size(new u32[n_chunks * pool_capacity]);
+	std::vector<u64> rec_pool_end(n_cuts, 0);
+	std::vector<u32> rec_distinct(n_cuts, 0), rec_first_class(n_cuts, 0), rec_first_is_ref(n_cuts, 0), status(n_chunks, 1);
+	walker.records(copies, cut_edge, chunk_first_cut, walker.state_edge, walker.state_order.get(), walker.state_divergence.get(),
+		pool_capacity, pool_lhs.get(), pool_rhs.get(), pool_size.get(), rec_pool_end.data(), rec_distinct.data(), rec_first_class.data(), rec_first_is_ref.data(), status.data());
+	timer.mark("matching: chunk walks (walker)");
+	if (walker.on_last_walk) walker.on_last_walk();
+
+	// chunks left undone: the host's own chunk scan; the others: joined classes gathered and sorted per cut, on the threads
+	std::vector<cut_chunk> chunks(n_chunks);
+	walker.chunks_walked = walker.chunks_left = 0;
+	for (std::size_t k(0); k < n_chunks; ++k) {
+		chunks[k].first_cut = chunk_first_cut[k];
+		chunks[k].end_cut = chunk_first_cut[k + 1];
+		if (chunks[k].first_cut < chunks[k].end_cut) ++(0 == status[k] ? walker.chunks_walked : walker.chunks_left);
+	}
+	{
+		std::atomic<std::size_t> next(0);
+		std::exception_ptr error;
+		std::mutex error_mutex;
+		auto const work([&] {
+			try {
+				for (std::size_t k; (k = next.fetch_add(1)) < n_chunks;) {
+					cut_chunk &chunk(chunks[k]);
+					if (chunk.first_cut >= chunk.end_cut) continue;
+					if (0 != status[k]) { scan_cut_chunk(graph, cut_positions, chunk); continue; }
+					u32 const *const lhs(pool_lhs.get() + k * pool_capacity), *const rhs(pool_rhs.get() + k * pool_capacity), *const size(pool_size.get() + k * pool_capacity);
+					chunk.pool.resize(rec_pool_end[chunk.end_cut - 1]);
+					for (std::size_t i(0); i < chunk.pool.size(); ++i) chunk.pool[i] = {lhs[i], rhs[i], size[i]};
+					u64 begin(0);
+					for (std::size_t cut(chunk.first_cut); cut < chunk.end_cut; ++cut) {
+						u64 const end(rec_pool_end[cut]);
+						std::sort(chunk.pool.begin() + std::ptrdiff_t(begin), chunk.pool.begin() + std::ptrdiff_t(end));   // :256
+						chunk.records.push_back({std::size_t(begin), std::size_t(end), rec_distinct[cut], rec_first_class[cut], 0 != rec_first_is_ref[cut]});
+						begin = end;
+					}
+				}
+			} catch (...) {
+				std::lock_guard<std::mutex> const lock(error_mutex);
+				if (!error) error = std::current_exception();
+			}
+		});
+		std::vector<std::thread> pool;
+		for (unsigned t(1); t < std::max(1u, threads); ++t) pool.emplace_back(work);
+		work();
+		for (auto &t : pool) t.join();
+		if (error) std::rethrow_exception(error);
+	}
+
+	timer.mark("matching: gather + sort per cut");
+	// the assignment, in cut order (founder_sequence_greedy_output.cc:254-457)
+	u32 lhs_distinct(0), rhs_distinct(0), lhs_first_class(0), rhs_first_class(0);
+	bool lhs_first_is_ref(true);
+	std::vector<joined_class> joined;
+	std::size_t cuts_seen(0);
+	for (auto &chunk : chunks) {
+		for (auto const &rec : chunk.records) {
+			lhs_distinct = rhs_distinct;
+			lhs_first_class = rhs_first_class;
+			rhs_distinct = rec.rhs_distinct;
+			rhs_first_class = rec.rhs_first_class;
+			if (cuts_seen) {
+				joined.assign(chunk.pool.begin() + std::ptrdiff_t(rec.joined_begin), chunk.pool.begin() + std::ptrdiff_t(rec.joined_end));
+				if (!keep_ref_edges && lhs_first_is_ref && rec.rhs_first_is_ref)      // :258-264
+					std::erase_if(joined, [&](joined_class const &jc) { return jc.lhs_rep == lhs_first_class && jc.rhs_rep == rhs_first_class; });
+				if (1 == cuts_seen) m.seed(joined, lhs_distinct);
+				m.extend(cuts_seen, joined, rhs_distinct);
+			}
+			++cuts_seen;
+			lhs_first_is_ref = rec.rhs_first_is_ref;
+		}
+		std::vector<joined_class>().swap(chunk.pool);
+		std::vector<cut_record>().swap(chunk.records);
+	}
+	m.finish();
+	timer.mark("matching: greedy assignment");
+	return true;
+}
+
+} // namespace
+
+
+bool find_matchings(
+	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
+	std::vector<u32> &assigned, unsigned threads, founder_walker *walker)
+{
+	u32 const copies(graph.total_chromosome_copies());
+	if (cut_positions.size() < 2 || 0 == copies) return false;               // :163-167
+	if (0 == threads) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+	auto const &transposed(graph.paths_by_chrom_copy_and_edge);
+	bool const have_transposed(transposed.cols >= copies && transposed.rows >= graph.edge_count() && !transposed.words.empty());
+	if (!walker || cut_positions.size() <= 2 || copies > walker->max_copies() || 0 == graph.edge_count() || !have_transposed)
+		return find_matchings(graph, cut_positions, founder_count, keep_ref_edges, assigned, threads);
+	return find_matchings_walked(graph, cut_positions, founder_count, keep_ref_edges, assigned, threads, *walker);
+}
 
 
 bool find_matchings(
@@ -913,7 +1116,7 @@ namespace {
 
 // find_cut_positions_chunked() with the chunk walks done by `walker`: candidates and chunks as there, every chunk's start
 // state built on the host threads first, one call for all the walks, then the score updates in candidate order.
-u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads, cut_trial_walker &walker)
+u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads, founder_walker &walker)
 {
 	out.clear();
 	u32 const copies(graph.total_chromosome_copies());
@@ -952,6 +1155,7 @@ u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std:
 	chunk_first.push_back(n_cand);
 	std::size_t const n_chunks(chunk_first.size() - 1);
 
+	phase_timer timer;
 	std::vector<u32> cand_edge(n_cand);
 	std::vector<u64> cand_aligned(n_cand);
 	for (std::size_t c(0); c < n_cand; ++c) { cand_edge[c] = u32(cuts[c].edge); cand_aligned[c] = graph.aligned_positions[cuts[c].node]; }
@@ -983,6 +1187,7 @@ u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std:
 		if (error) std::rethrow_exception(error);
 	}
 
+	timer.mark("cut search: start states");
 	// the walks
 	u64 max_chunk_candidates(0);
 	for (std::size_t c(0); c < n_chunks; ++c) max_chunk_candidates = std::max<u64>(max_chunk_candidates, chunk_first[c + 1] - chunk_first[c]);
@@ -992,6 +1197,13 @@ u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std:
 	std::vector<u64> trial_end(n_cand, 0);
 	std::vector<u32> status(n_chunks, 1);
 	walker.walk(copies, min_distance, cand_edge, cand_aligned, chunk_first, start_order.get(), start_div.get(), capacity, trial_pred.get(), trial_class.get(), trial_end.data(), status.data());
+	timer.mark("cut search: chunk walks (walker)");
+	// (the states serve the matching that follows as well: any state at or before a chunk's first cut will do there)
+	walker.state_edge.resize(n_chunks);
+	for (std::size_t c(0); c < n_chunks; ++c) walker.state_edge[c] = cand_edge[chunk_first[c]];
+	walker.state_order = std::move(start_order);
+	walker.state_divergence = std::move(start_div);
+	walker.state_copies = copies;
 
 	// the score updates, in candidate order (find_cut_positions.cc:55-63); chunks the walker left undone are walked here
 	std::vector<u32> first_candidate_from_edge;
@@ -1020,13 +1232,14 @@ u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std:
 		for (std::size_t j(chunk.first); j < chunk.end; ++j)
 			for (std::size_t const t_end(chunk.trial_end[j - chunk.first]); t < t_end; ++t) cuts[j].improve(chunk.trials[t].class_count, cuts[chunk.trials[t].pred]);
 	}
+	timer.mark("cut search: score updates");
 	return collect_cut_positions(cuts, graph, out);
 }
 
 } // namespace
 
 
-u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads, cut_trial_walker *walker)
+u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads, founder_walker *walker)
 {
 	u32 const copies(graph.total_chromosome_copies());
 	if (0 == threads) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));

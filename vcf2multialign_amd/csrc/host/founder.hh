@@ -11,6 +11,8 @@
 // (un-transposed) matrix.
 #pragma once
 
+#include <functional>
+#include <memory>
 #include <vector>
 
 #include "variant_graph.hh"
@@ -25,23 +27,37 @@ constexpr u32 kCutPositionScoreMax = UINT32_MAX;   // find_cut_positions.hh:17
 // threads: as for find_matchings below.
 u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &cut_positions, unsigned threads = 1);
 
-// Something that walks chunks of the cut search elsewhere (the GPU: gpu_path.cc:gpu_cut_trial_walker over v2m_pbwt_cut_trials):
-// given every chunk's start state it produces, per chunk, the (earlier candidate, class count) pairs the reference's loop
-// would try at each candidate (find_cut_positions.cc:134-165), or marks the chunk as left undone.
-struct cut_trial_walker {
-	virtual ~cut_trial_walker() {}
+// Something that walks chunks of the two searches elsewhere (the GPU: gpu_path.cc:gpu_founder_walker over v2m_pbwt_cut_trials and
+// v2m_pbwt_cut_records): given every chunk's start state it produces, per chunk, what the reference's loops collect at each
+// candidate (find_cut_positions.cc:134-165) / at each cut (founder_sequence_greedy_output.cc:215-251), or marks the chunk as
+// left undone.  The start states the cut search built are kept for the matching that usually follows it.
+struct founder_walker {
+	virtual ~founder_walker() {}
 	virtual u64 max_copies() const = 0;
 	// cand_edge / cand_aligned: all candidates; chunk_first: n_chunks + 1 candidate indices; start_*: [n_chunks][n_copies];
 	// trial_pred / trial_class: n_chunks x capacity; trial_end: per candidate, within its chunk; status: per chunk, 0 = done
 	virtual void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
 		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
 		u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status) = 0;
+	// cut_edge: edges before every cut node; chunk_first_cut: n_chunks + 1 cut indices; start_edge: per chunk, the edges the given
+	// state has seen; pool_*: n_chunks x pool_capacity joined classes; rec_*: per cut
+	virtual void records(u64 n_copies, std::vector<u32> const &cut_edge, std::vector<u64> const &chunk_first_cut, std::vector<u32> const &start_edge,
+		u32 const *start_order, u32 const *start_divergence, u64 pool_capacity, u32 *pool_lhs, u32 *pool_rhs, u32 *pool_size,
+		u64 *rec_pool_end, u32 *rec_distinct, u32 *rec_first_class, u32 *rec_first_is_ref, u32 *status) = 0;
 	// what the last search did: chunks walked by the walker / walked here after all
 	u64 chunks_walked{}, chunks_left{};
+	// called once the matching has made its last call to the walker (the rest -- sorting, the greedy assignment -- is host work):
+	// the caller may use the device for something else from then on
+	std::function<void()> on_last_walk;
+	// pBWT states (order, biased divergence; [state][copy]) after state_edge[k] edges, left behind by the cut search
+	std::vector<u32> state_edge;
+	std::unique_ptr<u32[]> state_order, state_divergence;
+	u64 state_copies{};
 };
+typedef founder_walker cut_trial_walker;
 // The same search with the chunk walks handed to `walker` (the start states are still built here, on `threads` threads, and
 // the score updates stay sequential); chunks the walker leaves undone, and graphs it cannot take, are walked here.
-u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &cut_positions, unsigned threads, cut_trial_walker *walker);
+u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &cut_positions, unsigned threads, founder_walker *walker);
 
 // Greedy assignment of path equivalence classes to founders.  assigned_samples receives the
 // (cut_positions.size() - 1) x founder_count matrix, column-major, one column per founder; slots that stay
@@ -52,6 +68,10 @@ u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector
 bool find_matchings(
 	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
 	std::vector<u32> &assigned_samples, unsigned threads = 1);
+// ... with the chunk walks handed to `walker` (the greedy assignment stays sequential, here).
+bool find_matchings(
+	variant_graph const &graph, std::vector<u64> const &cut_positions, u32 founder_count, bool keep_ref_edges,
+	std::vector<u32> &assigned_samples, unsigned threads, founder_walker *walker);
 
 // --output-cut-positions / --input-cut-positions (founder_sequence_greedy_output.cc:118-136).  The reference writes the
 // struct {min_distance, cut_positions, score} (output.hh:89-97,133-139) through cereal's PortableBinaryOutputArchive;

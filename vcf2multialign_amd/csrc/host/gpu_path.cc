@@ -59,12 +59,21 @@ void upload_path_blocks(gpu_context &gpu, variant_graph const &g, copy_interleav
 }
 
 
-void gpu_cut_trial_walker::walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
+void gpu_founder_walker::walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
 	std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
 	u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status)
 {
 	m_gpu.check(v2m_pbwt_cut_trials(m_gpu.get(), n_copies, min_distance, cand_edge.size(), cand_edge.data(), cand_aligned.data(),
 		chunk_first.size() - 1, chunk_first.data(), start_order, start_divergence, capacity, trial_pred, trial_class, trial_end, status));
+}
+
+
+void gpu_founder_walker::records(u64 n_copies, std::vector<u32> const &cut_edge, std::vector<u64> const &chunk_first_cut, std::vector<u32> const &start_edge,
+	u32 const *start_order, u32 const *start_divergence, u64 pool_capacity, u32 *pool_lhs, u32 *pool_rhs, u32 *pool_size,
+	u64 *rec_pool_end, u32 *rec_distinct, u32 *rec_first_class, u32 *rec_first_is_ref, u32 *status)
+{
+	m_gpu.check(v2m_pbwt_cut_records(m_gpu.get(), n_copies, cut_edge.size(), cut_edge.data(), chunk_first_cut.size() - 1, chunk_first_cut.data(), start_edge.data(),
+		start_order, start_divergence, pool_capacity, pool_lhs, pool_rhs, pool_size, rec_pool_end, rec_distinct, rec_first_class, rec_first_is_ref, status));
 }
 
 

@@ -69,17 +69,21 @@ struct copy_interleave {
 };
 void upload_path_blocks(gpu_context &gpu, variant_graph const &graph, copy_interleave deal, u32 rank);
 
-// The chunk walks of the founder cut search on the GPU (v2m_pbwt_cut_trials).  The context must hold the uploaded graph with
-// its path matrix (upload_graph(..., true)).
-class gpu_cut_trial_walker final : public cut_trial_walker {
+// The chunk walks of the founder searches on the GPU (v2m_pbwt_cut_trials, v2m_pbwt_cut_records).  The context must hold the
+// uploaded graph with its path matrix (upload_graph(..., true)).
+class gpu_founder_walker final : public founder_walker {
 public:
-	explicit gpu_cut_trial_walker(gpu_context &gpu) : m_gpu(gpu) {}
+	explicit gpu_founder_walker(gpu_context &gpu) : m_gpu(gpu) {}
 	u64 max_copies() const override { return 8192; }
 	void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
 		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
 		u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status) override;
+	void records(u64 n_copies, std::vector<u32> const &cut_edge, std::vector<u64> const &chunk_first_cut, std::vector<u32> const &start_edge,
+		u32 const *start_order, u32 const *start_divergence, u64 pool_capacity, u32 *pool_lhs, u32 *pool_rhs, u32 *pool_size,
+		u64 *rec_pool_end, u32 *rec_distinct, u32 *rec_first_class, u32 *rec_first_is_ref, u32 *status) override;
 private:
 	gpu_context &m_gpu;
 };
+typedef gpu_founder_walker gpu_cut_trial_walker;
 
 } // namespace v2m::host

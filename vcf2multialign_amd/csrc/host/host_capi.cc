@@ -191,6 +191,39 @@ uint64_t v2mh_find_cut_positions_gpu(void *h, void *ctx, uint64_t min_distance, 
 	}
 }
 
+// find_cut_positions + find_matchings with the chunk walks of both on the GPU context `ctx`.  chunks: {cut search: walked on the
+// GPU, left to the host; matching: walked, left}.  with_search = 0: the cut positions are given in cuts_out[0 .. n_cuts_in).
+uint64_t v2mh_find_founders_gpu(void *h, void *ctx, uint64_t min_distance, uint32_t founder_count, int keep_ref_edges, unsigned threads,
+	int with_search, uint64_t n_cuts_in, uint64_t *cuts_out, uint32_t *assigned_out, uint64_t assigned_capacity, uint32_t *score_out, uint64_t *chunks, char *err, size_t errlen)
+{
+	try {
+		vh::gpu_context gpu(static_cast<v2m_ctx *>(ctx), vh::gpu_context::borrowed{});
+		vh::gpu_founder_walker walker(gpu);
+		auto const &g(HG(h).graph);
+		std::vector<vh::u64> cuts;
+		vh::u32 score(0);
+		if (with_search) {
+			score = vh::find_cut_positions(g, min_distance, cuts, threads, &walker);
+			if (chunks) { chunks[0] = walker.chunks_walked; chunks[1] = walker.chunks_left; }
+			if (score_out) *score_out = score;
+			if (vh::kCutPositionScoreMax == score) return 0;
+		} else {
+			cuts.assign(cuts_out, cuts_out + n_cuts_in);
+		}
+		std::vector<vh::u32> assigned;
+		walker.chunks_walked = walker.chunks_left = 0;
+		if (!vh::find_matchings(g, cuts, founder_count, 0 != keep_ref_edges, assigned, threads, &walker)) return 0;
+		if (chunks) { chunks[2] = walker.chunks_walked; chunks[3] = walker.chunks_left; }
+		if (assigned.size() > assigned_capacity) return 0;
+		std::copy(cuts.begin(), cuts.end(), cuts_out);
+		std::copy(assigned.begin(), assigned.end(), assigned_out);
+		return cuts.size();
+	} catch (std::exception const &e) {
+		if (err && errlen) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+		return 0;
+	}
+}
+
 uint64_t v2mh_find_founders(void *h, uint64_t min_distance, uint32_t founder_count, int keep_ref_edges,
 	uint64_t *cuts_out, uint32_t *assigned_out, uint64_t assigned_capacity, uint32_t *score_out)
 {

@@ -362,11 +362,15 @@ int main(int argc, char **argv)
 		vh::copy_interleave const deal{8, vh::u32(all_gpus.size())};
 		std::vector<vh::copy_shard> shards;
 		std::future<void> founder_graph_uploaded;
-		if (opt.founder_mode)   // the host-transposed matrix (the search needs it on the host anyway), uploaded while the search runs
+		if (opt.founder_mode) {
+			// The first context gets the graph with its (transposed) path matrix now: the cut search walks its chunks there
+			// (v2m_pbwt_cut_trials).  The other contexts' uploads and the output path's buffers are set up while the search runs.
+			vh::upload_graph(gpu, ref_seq, graph, true);
 			founder_graph_uploaded = std::async(std::launch::async, [&] {
-				for (auto *g : all_gpus) vh::upload_graph(*g, ref_seq, graph, true);
-				for (auto *g : all_gpus) vh::warm_up_sink(*g, opt.unaligned);       // ... and the output path's buffers set up meanwhile
+				for (std::size_t k(1); k < all_gpus.size(); ++k) vh::upload_graph(*all_gpus[k], ref_seq, graph, true);
+				for (std::size_t k(1); k < all_gpus.size(); ++k) vh::warm_up_sink(*all_gpus[k], opt.unaligned);
 			});
+		}
 		if (!opt.founder_mode) {
 			// every context's graph and matrix share go up on that context's own thread (one PCIe link each)
 			std::vector<std::exception_ptr> upload_errors(all_gpus.size());
@@ -417,6 +421,7 @@ int main(int argc, char **argv)
 			for (std::size_t k(1); k < all_gpus.size(); ++k) output.add_gpu(*all_gpus[k]);
 			std::vector<vh::u64> cuts;
 			vh::u32 score(0);
+			vh::gpu_founder_walker walker(gpu);   // the chunk walks of both searches run on the first context (v2m_pbwt_cut_trials / _records)
 			vh::u64 cut_min_distance(vh::u64(opt.minimum_distance));
 			if (opt.input_cut_positions) {                  // main.cc:499-500
 				auto loaded(vh::read_cut_positions(opt.input_cut_positions));
@@ -425,7 +430,8 @@ int main(int argc, char **argv)
 				cut_min_distance = loaded.min_distance;
 			} else {
 				std::cerr << "Optimising cut positions...\n";
-				score = vh::find_cut_positions(graph, vh::u64(opt.minimum_distance), cuts, 0);
+				score = vh::find_cut_positions(graph, vh::u64(opt.minimum_distance), cuts, 0, &walker);
+				if (opt.verbose) std::cerr << "Cut search: " << walker.chunks_walked << " chunks walked on the GPU, " << walker.chunks_left << " on the host.\n";
 				if (vh::kCutPositionScoreMax == score) { std::cerr << "ERROR: Unable to optimise cut positions.\n"; return EXIT_FAILURE; }
 				if (opt.verbose) {
 					std::cout << "Cut positions:";
@@ -438,7 +444,11 @@ int main(int argc, char **argv)
 				vh::write_cut_positions({cuts, cut_min_distance, score}, opt.output_cut_positions);
 			std::cerr << "Finding matchings in the variant graph...\n";
 			std::vector<vh::u32> assigned;
-			if (!vh::find_matchings(graph, cuts, vh::u32(opt.founder_sequences), opt.keep_ref_edges, assigned, 0)) { std::cerr << "ERROR: Unable to find matchings.\n"; return EXIT_FAILURE; }
+			// the first context is idle once the matching's chunk walks are back: its output buffers (a gigabyte of pinned memory,
+			// 0.15 s) are set up on another thread while the greedy assignment runs here
+			std::future<void> first_sink_warm;
+			walker.on_last_walk = [&] { first_sink_warm = std::async(std::launch::async, [&] { vh::warm_up_sink(gpu, opt.unaligned); }); };
+			if (!vh::find_matchings(graph, cuts, vh::u32(opt.founder_sequences), opt.keep_ref_edges, assigned, 0, &walker)) { std::cerr << "ERROR: Unable to find matchings.\n"; return EXIT_FAILURE; }
 			if (opt.verbose) {                              // main.cc:534-545
 				std::cout << "Matchings:\n";
 				std::size_t const rows(cuts.size() - 1);
@@ -451,6 +461,7 @@ int main(int argc, char **argv)
 			output.set_cut_positions(std::move(cuts));
 			output.set_assigned_samples(std::move(assigned), vh::u32(opt.founder_sequences));
 			founder_graph_uploaded.get();
+			if (first_sink_warm.valid()) first_sink_warm.get(); else vh::warm_up_sink(gpu, opt.unaligned);
 			do_output(output);
 		}
 	} catch (vh::gpu_error const &e) {

@@ -1274,6 +1274,75 @@ int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 }
 
 
+int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const uint32_t *cut_edge,
+	uint64_t n_chunks, const uint64_t *chunk_first_cut, const uint32_t *start_edge, const uint32_t *start_order, const uint32_t *start_divergence,
+	uint64_t pool_capacity, uint32_t *pool_lhs, uint32_t *pool_rhs, uint32_t *pool_size,
+	uint64_t *rec_pool_end, uint32_t *rec_distinct, uint32_t *rec_first_class, uint32_t *rec_first_is_ref, uint32_t *chunk_status)
+{
+	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
+	if (!ctx->has_graph || !ctx->d_paths) return fail(ctx, V2M_ERR_STATE, "the founder search needs an uploaded graph with its path matrix");
+	if (0 == n_chunks) return V2M_OK;
+	if (!cut_edge || !chunk_first_cut || !start_edge || !start_order || !start_divergence || !pool_lhs || !pool_rhs || !pool_size
+		|| !rec_pool_end || !rec_distinct || !rec_first_class || !rec_first_is_ref || !chunk_status)
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL array");
+	if (0 == n_copies || n_copies > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk holds at most %d chromosome copies (got %llu)", v2m::kPbwtMaxCopies, (unsigned long long) n_copies);
+	if (n_copies > ctx->path_cols) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the bound path matrix has %llu copies, %llu asked for", (unsigned long long) ctx->path_cols, (unsigned long long) n_copies);
+	if (chunk_first_cut[0] < 1 || chunk_first_cut[n_chunks] > n_cuts) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds outside the cut list");
+	for (u64 k(0); k < n_chunks; ++k) {
+		if (chunk_first_cut[k] > chunk_first_cut[k + 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds must not decrease");
+		if (chunk_first_cut[k] < chunk_first_cut[k + 1] && start_edge[k] > cut_edge[chunk_first_cut[k] - 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk %llu: the start state lies past the cut before its first one", (unsigned long long) k);
+	}
+	for (u64 j(1); j < n_cuts; ++j) if (cut_edge[j] < cut_edge[j - 1] || cut_edge[j] > ctx->n_edges) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut edges must ascend and stay inside the graph");
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+
+	u64 const rows(ctx->path_rows), cols(ctx->path_cols);
+	dev_buf d_by_edge, d_cut_edge, d_chunk_first, d_start_edge, d_order, d_div, d_lhs, d_rhs, d_size, d_end, d_distinct, d_first, d_ref, d_status;
+	V2M_HIP_TRY(ctx, d_by_edge.ensure(rows * (cols / 64) * sizeof(u64)));
+	if (int const rc = launch_transpose(ctx, ctx->d_paths, rows, cols, d_by_edge.as<u64>(), ctx->path_pitch, 0)) return rc;
+	auto const up([&](dev_buf &dst, void const *src, size_t bytes) -> int {
+		V2M_HIP_TRY(ctx, dst.ensure(std::max<size_t>(bytes, 16)));
+		if (bytes) V2M_HIP_TRY(ctx, hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+		return V2M_OK;
+	});
+	if (int const rc = up(d_cut_edge, cut_edge, n_cuts * sizeof(u32))) return rc;
+	if (int const rc = up(d_chunk_first, chunk_first_cut, (n_chunks + 1) * sizeof(u64))) return rc;
+	if (int const rc = up(d_start_edge, start_edge, n_chunks * sizeof(u32))) return rc;
+	if (int const rc = up(d_order, start_order, n_chunks * n_copies * sizeof(u32))) return rc;
+	if (int const rc = up(d_div, start_divergence, n_chunks * n_copies * sizeof(u32))) return rc;
+	size_t const pool_bytes(std::max<u64>(16, n_chunks * pool_capacity * sizeof(u32)));
+	V2M_HIP_TRY(ctx, d_lhs.ensure(pool_bytes));
+	V2M_HIP_TRY(ctx, d_rhs.ensure(pool_bytes));
+	V2M_HIP_TRY(ctx, d_size.ensure(pool_bytes));
+	V2M_HIP_TRY(ctx, d_end.ensure(n_cuts * sizeof(u64)));
+	V2M_HIP_TRY(ctx, d_distinct.ensure(n_cuts * sizeof(u32)));
+	V2M_HIP_TRY(ctx, d_first.ensure(n_cuts * sizeof(u32)));
+	V2M_HIP_TRY(ctx, d_ref.ensure(n_cuts * sizeof(u32)));
+	V2M_HIP_TRY(ctx, d_status.ensure(n_chunks * sizeof(u32)));
+	V2M_HIP_TRY(ctx, hipMemsetAsync(d_status.p, 0xFF, n_chunks * sizeof(u32), ctx->stream));
+	hipLaunchKernelGGL(v2m::pbwt_cut_records_kernel, dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
+		d_by_edge.as<u64>(), u32(cols / 64), u32(n_copies), d_cut_edge.as<u32>(), d_chunk_first.as<u64>(), d_start_edge.as<u32>(), d_order.as<u32>(), d_div.as<u32>(),
+		pool_capacity, d_lhs.as<u32>(), d_rhs.as<u32>(), d_size.as<u32>(), d_end.as<u64>(), d_distinct.as<u32>(), d_first.as<u32>(), d_ref.as<u32>(), d_status.as<u32>());
+	V2M_HIP_TRY(ctx, hipGetLastError());
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_pool_end, d_end.p, n_cuts * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_distinct, d_distinct.p, n_cuts * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_first_class, d_first.p, n_cuts * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+	V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_first_is_ref, d_ref.p, n_cuts * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	for (u64 k(0); k < n_chunks; ++k) {
+		if (0 != chunk_status[k]) { chunk_status[k] = 1; continue; }
+		if (chunk_first_cut[k] == chunk_first_cut[k + 1]) continue;
+		u64 const n(rec_pool_end[chunk_first_cut[k + 1] - 1]);
+		if (n > pool_capacity) { chunk_status[k] = 1; continue; }
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(pool_lhs + k * pool_capacity, d_lhs.as<u32>() + k * pool_capacity, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(pool_rhs + k * pool_capacity, d_rhs.as<u32>() + k * pool_capacity, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(pool_size + k * pool_capacity, d_size.as<u32>() + k * pool_capacity, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+	}
+	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return V2M_OK;
+}
+
+
 // ---- rows -----------------------------------------------------------------------------------
 
 int v2m_splice_rows_device(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, void *d_out, uint64_t row_pitch, uint64_t *row_lengths_out)

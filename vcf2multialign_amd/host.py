@@ -189,6 +189,33 @@ class HostGraph:
 			return None
 		return cuts[:k].tolist(), score.value
 
+	def find_founders_gpu(self, ctx, founder_count, min_distance=0, keep_ref_edges=False, threads=0, cut_positions=None):
+		"""find_cut_positions + find_matchings with the chunk walks of both on the GPU (v2m_pbwt_cut_trials, v2m_pbwt_cut_records);
+		cut_positions: skip the search and match over these.  Returns (cut_positions, assigned_samples column-major, score) or None;
+		self.gpu_chunks = (search: on the GPU, on the host; matching: on the GPU, on the host)."""
+		L = _load()
+		L.v2mh_find_founders_gpu.restype = C.c_uint64
+		L.v2mh_find_founders_gpu.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint, C.c_int, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64,
+			C.POINTER(C.c_uint32), C.c_void_p, C.c_char_p, C.c_size_t]
+		n = len(self.reference_positions)
+		cuts = np.zeros(n, dtype=np.uint64)
+		n_in = 0
+		if cut_positions is not None:
+			n_in = len(cut_positions)
+			cuts[:n_in] = cut_positions
+		assigned = np.zeros(max(1, n * founder_count), dtype=np.uint32)
+		score = C.c_uint32()
+		chunks = (C.c_uint64 * 4)()
+		err = C.create_string_buffer(512)
+		k = L.v2mh_find_founders_gpu(self._h, ctx._h, min_distance, founder_count, int(keep_ref_edges), threads, int(cut_positions is None), n_in,
+			cuts.ctypes.data, assigned.ctypes.data, assigned.size, C.byref(score), chunks, err, len(err))
+		if err.value:
+			raise RuntimeError(err.value.decode())
+		self.gpu_chunks = tuple(int(x) for x in chunks)
+		if k == 0:
+			return None
+		return cuts[:k].tolist(), assigned[:(k - 1) * founder_count].tolist(), score.value
+
 	def find_founders(self, founder_count, min_distance=0, keep_ref_edges=False, threads=1):
 		"""find_cut_positions + find_matchings (host algorithms).  Returns (cut_positions, assigned_samples column-major, score)
 		or None when there is no solution.  threads > 1 (0 = automatic) spreads the matching's pBWT over threads."""
