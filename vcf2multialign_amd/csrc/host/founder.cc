@@ -1140,9 +1140,12 @@ u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std:
 	std::size_t const n_cand(cuts.size());
 	if (n_cand <= 1) return collect_cut_positions(cuts, graph, out);
 
-	// chunks of candidates with about the same number of edges each: one workgroup walks one chunk, so there are at least a
-	// few hundred of them when the graph is large enough (a start state costs the host tens of ms: not many more than that)
-	std::size_t const wanted(std::min<std::size_t>(std::max<std::size_t>(std::size_t(threads) * 8, std::size_t(n_edges / 8192) + 1), n_cand - 1));
+	// chunks of candidates with about the same number of edges each: one workgroup walks one chunk, so the walker says how many
+	// it wants (a start state costs the host well under a millisecond of one thread at 5000 copies), but never fewer than a few
+	// hundred edges each
+	std::size_t const by_size(std::max<std::size_t>(std::size_t(threads) * 8, std::size_t(n_edges / 8192) + 1));
+	std::size_t const by_walker(std::min<std::size_t>(walker.preferred_chunks(), std::size_t(n_edges / 512) + 1));
+	std::size_t const wanted(std::min<std::size_t>(std::max(by_size, by_walker), n_cand - 1));
 	std::vector<u64> chunk_first;
 	for (std::size_t j(1), k(1); j <= wanted && k < n_cand; ++j) {
 		u64 const edge_goal(n_edges * j / wanted);

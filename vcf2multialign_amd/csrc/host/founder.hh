@@ -34,6 +34,8 @@ u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector
 struct founder_walker {
 	virtual ~founder_walker() {}
 	virtual u64 max_copies() const = 0;
+	// how many chunks it likes to walk at once (one workgroup each on the GPU: a couple per compute unit); 0 = no preference
+	virtual std::size_t preferred_chunks() const { return 0; }
 	// cand_edge / cand_aligned: all candidates; chunk_first: n_chunks + 1 candidate indices; start_*: [n_chunks][n_copies];
 	// trial_pred / trial_class: n_chunks x capacity; trial_end: per candidate, within its chunk; status: per chunk, 0 = done
 	virtual void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,

@@ -75,6 +75,7 @@ class gpu_founder_walker final : public founder_walker {
 public:
 	explicit gpu_founder_walker(gpu_context &gpu) : m_gpu(gpu) {}
 	u64 max_copies() const override { return 8192; }
+	std::size_t preferred_chunks() const override { return 256; }   // one workgroup per chunk, one workgroup per CU at a time (145 KB of LDS): one round over 256 CUs
 	void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
 		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
 		u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status) override;
