@@ -2,9 +2,11 @@
 // founder follows between consecutive cuts.
 //
 // Both walk a positional BWT with divergence counts over the ALT edges, every step depending on the previous
-// one, which is why they stay on the host -- but the state after any number of
-// edges can also be built from scratch from the transposed path matrix, so the walk is cut into chunks that run on
-// several threads (founder.cc: pbwt_state_at).  They restate the reference's find_initial_cut_positions_lambda_min (libvcf2multialign/find_cut_positions.cc:93-211),
+// one -- but the state after any number of edges can also be built from scratch from the transposed path matrix, so the walk is
+// cut into chunks (founder.cc: pbwt_state_at) that run on several host threads or, with a founder_walker (round 3), as one GPU
+// workgroup each (csrc/founder_kernels.hpp behind v2m_pbwt_cut_trials / v2m_pbwt_cut_records); the score updates and the
+// greedy assignment, which are strictly sequential, stay here.  They restate the reference's
+// find_initial_cut_positions_lambda_min (libvcf2multialign/find_cut_positions.cc:93-211),
 // pbwt_context (include/vcf2multialign/pbwt.hh:21-145) and founder_sequence_greedy_output::find_matchings
 // (libvcf2multialign/founder_sequence_greedy_output.cc:154-512); the rows they select are then spliced on the
 // GPU (output.hh: founder_sequence_greedy_output).  They read paths_by_edge_and_chrom_copy, the builder's own
