@@ -28,6 +28,15 @@ constexpr int kPbwtPerThread = kPbwtMaxCopies / kPbwtThreads;
 constexpr int kPbwtHashSlots = 4096;                  // distinct candidate bins per candidate node: far fewer in practice
 constexpr int kPbwtMaxBins = 1024;                    // more distinct bins than this at one candidate: the chunk is left to the host
 
+// __syncthreads() with the LDS wait spelled out: on loop back edges hipcc (ROCm 7.2) has emitted the barrier without the
+// s_waitcnt lgkmcnt(0) that __syncthreads() implies (kernels.hpp, ring transpose; tests/test_kernel_isa.py checks every
+// barrier of every kernel), and these kernels are all loops around barriers.
+__device__ __forceinline__ void pbwt_block_sync()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+	__syncthreads();
+}
+
 // "p -> is_const ? value : max(p, value)": what a run of copies does to a running maximum that is reset after every copy of
 // its own class.
 struct max_chain {
@@ -74,7 +83,7 @@ __device__ __forceinline__ uint32_t pbwt_step(
 	int cur, uint32_t my_begin, uint32_t my_end, int t, int lane, int wave)
 {
 	for (uint32_t w = t; w < words_per_edge; w += kPbwtThreads) column[w] = paths_by_edge[(uint64_t) edge * words_per_edge + w];
-	__syncthreads();
+	pbwt_block_sync();
 	unsigned short const *const ord = order[cur];
 	uint32_t const *const dv = divergence[cur];
 	// what this thread's run of copies does to the zero count and to the two running maxima
@@ -98,7 +107,7 @@ __device__ __forceinline__ uint32_t pbwt_step(
 		if (lane >= delta) incl = scan_combine(up, incl);
 	}
 	if (lane == 63) wave_items[wave] = incl;
-	__syncthreads();
+	pbwt_block_sync();
 	pbwt_scan_item before{0u, max_chain{0u, 0u}, max_chain{0u, 0u}};      // identity: no copies
 	uint32_t zeros_total = 0;
 	for (int w = 0; w < kPbwtWaves; ++w) {
@@ -120,7 +129,7 @@ __device__ __forceinline__ uint32_t pbwt_step(
 		if (!((flags >> (i - my_begin)) & 1u)) { out_ord[zero_at] = (unsigned short) copy; out_dv[zero_at] = p; ++zero_at; p = 1u; }
 		else { out_ord[one_at] = (unsigned short) copy; out_dv[one_at] = q; ++one_at; q = 1u; }
 	}
-	__syncthreads();
+	pbwt_block_sync();
 	return zeros_total;
 }
 
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 	}
 	for (uint32_t i = t; i < (uint32_t) kPbwtHashSlots; i += kPbwtThreads) { hash_key[i] = 0; hash_count[i] = 0; }
 	if (t == 0) { n_bins_s = 0; failed_s = 0; }
-	__syncthreads();
+	pbwt_block_sync();
 
 	int cur = 0;
 	uint64_t n_trials = 0;                                 // (kept by every thread: all of them see the same counts)
@@ -184,7 +193,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 #pragma unroll
 		for (int delta = 32; delta >= 1; delta >>= 1) { uint32_t const o = __shfl_xor(my_max, delta, 64); my_max = o > my_max ? o : my_max; }
 		if (lane == 0) reduce_max[wave] = my_max;
-		__syncthreads();
+		pbwt_block_sync();
 		uint32_t d_max = 0;
 		for (int w = 0; w < kPbwtWaves; ++w) d_max = reduce_max[w] > d_max ? reduce_max[w] : d_max;
 		uint32_t my_cnt = 0;
@@ -217,7 +226,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 #pragma unroll
 		for (int delta = 32; delta >= 1; delta >>= 1) my_cnt += __shfl_xor(my_cnt, delta, 64);
 		if (lane == 0) reduce_cnt[wave] = my_cnt;
-		__syncthreads();
+		pbwt_block_sync();
 		uint32_t count_max = 0;
 		for (int w = 0; w < kPbwtWaves; ++w) count_max += reduce_cnt[w];
 		uint32_t const n_bins = n_bins_s;
@@ -233,7 +242,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 			cnt = hash_count[slot];
 			for (uint32_t j = 0; j < n_bins; ++j) rank += (hash_key[bin_slot[j]] - 1u) > key;
 		}
-		__syncthreads();
+		pbwt_block_sync();
 		if ((uint32_t) t < n_bins) {
 			sorted_key[rank] = key;
 			sorted_count[rank] = cnt;
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 			hash_count[slot] = 0;
 		}
 		if (t == 0) n_bins_s = 0;
-		__syncthreads();
+		pbwt_block_sync();
 		// the trials: bin r is tried with class_count = copies in the bins before it (larger values) + the largest value's copies,
 		// unless it is the clipped bin, the candidate itself, or too close (find_cut_positions.cc:139-160)
 		uint32_t class_before = count_max, emit = 0;
@@ -252,7 +261,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 			emit = (k != next + 1u && k != next && min_distance <= cand_aligned[next] - cand_aligned[k]) ? 1u : 0u;
 			sorted_emit[t] = emit;
 		}
-		__syncthreads();
+		pbwt_block_sync();
 		uint32_t emitted = 0;                                           // how many bins emit (every thread computes it: small)
 		uint32_t my_slot = 0;
 		for (uint32_t j = 0; j < n_bins; ++j) { if (j == (uint32_t) t) my_slot = emitted; emitted += sorted_emit[j]; }
@@ -271,7 +280,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 			++n_trials;
 		}
 		if (t == 0) trial_end[cand] = n_trials;
-		__syncthreads();                                                // sorted_* are rewritten by the next candidate
+		pbwt_block_sync();                                                // sorted_* are rewritten by the next candidate
 	}
 	if (t == 0) chunk_status[chunk] = 0u;
 }
@@ -339,7 +348,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 		copy_class[0][i] = (unsigned short) kPbwtNoClass;
 		copy_class[1][i] = (unsigned short) kPbwtNoClass;
 	}
-	__syncthreads();
+	pbwt_block_sync();
 
 	int cur = 0, rhs = 0;                                  // copy_class[rhs]: the classes the last cut left behind
 	uint32_t edge = start_edge[chunk];
@@ -370,7 +379,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 			if (lane >= delta) incl = class_combine(up, incl);
 		}
 		if (lane == 63) class_items[wave] = incl;
-		__syncthreads();
+		pbwt_block_sync();
 		class_scan_item before{-1, 0u, 0u}, total{-1, 0u, 0u};
 		for (int w = 0; w < kPbwtWaves; ++w) {
 			class_scan_item const wi = class_items[w];
@@ -399,14 +408,14 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 			}
 			rhs_class[copy] = (unsigned short) rep;
 		}
-		__syncthreads();
+		pbwt_block_sync();
 		if (with_span && fits) {
 			for (uint32_t j = t; j < total.span_starts; j += kPbwtThreads)
 				my_size[n_pool + j] = (j + 1 < total.span_starts ? (uint32_t) span_start_index[j + 1] : n_copies) - (uint32_t) span_start_index[j];
 			n_pool += total.span_starts;
 		}
 		rhs ^= 1;
-		__syncthreads();                                                // class_items / span_start_index are rewritten by the next call
+		pbwt_block_sync();                                                // class_items / span_start_index are rewritten by the next call
 		return fits;
 	};
 
