@@ -78,6 +78,43 @@ def test_random_inputs_against_the_literal_restatement(HostGraph, tmp_path, seed
 			assert hg.find_founders(founders, min_distance, keep_ref_edges=keep, threads=threads) == exp, (founders, min_distance, keep, threads)
 
 
+@pytest.mark.parametrize("seed,ref_len,n_variants,n_samples,kw", [
+	(11, 5000, 400, 9, dict(multi_allelic=0.3)),
+	(12, 30000, 2500, 33, dict(multi_allelic=0.1, mix=(0.7, 0.15, 0.15))),
+	(13, 120000, 12000, 150, dict(mix=(0.8, 0.1, 0.1))),              # several chunks of thousands of edges, a few hundred copies
+], ids=lambda v: str(v) if isinstance(v, int) else None)
+def test_walked_searches_with_the_hosts_own_walker(HostGraph, tmp_path, monkeypatch, seed, ref_len, n_variants, n_samples, kw):
+	"""find_cut_positions / find_matchings with their chunk walks handed to a founder_walker -- what the GPU path runs around its two
+	kernels (tests/test_gpu_founders.py) -- with the walker that walks on the host, edge by edge from the states it is given:
+	chunk bounds, the cut search's states reused by the matching, chunks handed back when their output does not fit, a walker that
+	refuses the copy count.  Same answers as the sequential loops."""
+	import numpy as np
+	import oracle
+	import synth
+	rng = np.random.default_rng(2000 + seed)
+	ref = synth.random_reference(rng, ref_len)
+	recs = synth.random_records(rng, ref, n_variants, n_samples, **kw)
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, n_samples)
+	og = oracle.build_variant_graph(fa, vcf, "1")
+	hg = HostGraph(fa, vcf, "1")
+	hg.set_transposed_paths(og.paths_by_chrom_copy_and_edge, og.path_rows, og.path_cols)
+	for founders, min_distance, keep in ((2, 0, False), (3, 10, True), (25, 50, False), (4, 1000, True)):
+		want = hg.find_founders(founders, min_distance, keep_ref_edges=keep, threads=1)
+		for threads in (1, 3):
+			assert hg.find_founders_walked_on_host(founders, min_distance, keep_ref_edges=keep, threads=threads) == want, (founders, min_distance, keep, threads)
+			if want is not None and len(want[0]) > 2:
+				assert hg.gpu_chunks[0] >= 1 and hg.gpu_chunks[1] == 0 and hg.gpu_chunks[2] >= 1 and hg.gpu_chunks[3] == 0, hg.gpu_chunks
+	want = hg.find_founders(5, 20, threads=1)
+	monkeypatch.setenv("V2M_FOUNDER_TRIAL_CAPACITY", "50")                    # the walker's output does not fit: the chunks come back
+	monkeypatch.setenv("V2M_FOUNDER_POOL_CAPACITY", "40")
+	assert hg.find_founders_walked_on_host(5, 20, threads=2) == want
+	assert hg.gpu_chunks[1] >= 1 and hg.gpu_chunks[3] >= 1, hg.gpu_chunks
+	monkeypatch.delenv("V2M_FOUNDER_TRIAL_CAPACITY")
+	monkeypatch.delenv("V2M_FOUNDER_POOL_CAPACITY")
+	assert hg.find_founders_walked_on_host(5, 20, threads=2, max_copies=4) == want   # a walker that cannot hold the copies: the plain search
+	assert hg.gpu_chunks == (0, 0, 0, 0)
+
+
 def test_cut_position_file_round_trip(HostGraph, tmp_path):
 	"""--output-cut-positions / --input-cut-positions: {min_distance, cut_positions, score} in cereal's portable-binary
 	layout (output.hh:133-139); the reference holds no such file, so only the layout stated in founder.hh is checked."""

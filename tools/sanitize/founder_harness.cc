@@ -1,5 +1,6 @@
 // Sanitizer harness for the host's founder search (csrc/host/founder.cc): a random graph with one ALT edge per
-// second node, both path matrices filled; the sequential search against the chunked one on 2, 4 and 8 threads.
+// second node, both path matrices filled; the sequential search against the chunked one on 2, 4 and 8 threads and against the
+// walked one (chunks handed to a founder_walker: here the host's own).
 // Built and run by tools/sanitize_host.sh with -fsanitize=address,undefined and -fsanitize=thread.
 #include "founder.hh"
 
@@ -53,6 +54,17 @@ int main(int argc, char **argv)
 		find_matchings(g, cuts_mt, 25, false, assigned_mt, threads);
 		bool const same(score_mt == score && cuts_mt == cuts && assigned_mt == assigned);
 		std::printf("  %u threads: %s\n", threads, same ? "same" : "DIFFERENT");
+		if (!same) return 1;
+	}
+	// the walked searches (what the GPU path runs around its kernels) with the host's own walker, several threads building the states
+	for (unsigned threads : {1u, 4u}) {
+		auto walker(make_host_founder_walker(g));
+		std::vector<u64> cuts_w;
+		std::vector<u32> assigned_w;
+		u32 const score_w(find_cut_positions(g, 50, cuts_w, threads, walker.get()));
+		find_matchings(g, cuts_w, 25, false, assigned_w, threads, walker.get());
+		bool const same(score_w == score && cuts_w == cuts && assigned_w == assigned);
+		std::printf("  walked, %u threads: %s (%llu chunks)\n", threads, same ? "same" : "DIFFERENT", (unsigned long long) walker->chunks_walked);
 		if (!same) return 1;
 	}
 	return 0;

@@ -1242,6 +1242,124 @@ u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std:
 } // namespace
 
 
+namespace {
+
+class host_founder_walker final : public founder_walker {
+public:
+	host_founder_walker(variant_graph const &graph, u64 max_copies) : m_graph(graph), m_max_copies(max_copies) {}
+	u64 max_copies() const override { return m_max_copies; }
+
+	void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
+		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
+		u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status) override
+	{
+		u64 const n_edges(m_graph.edge_count()), words_per_column(m_graph.paths_by_edge_and_chrom_copy.words_per_column());
+		std::vector<u32> first_candidate_from_edge(n_edges + 1);
+		for (u64 e(0), c(0); e <= n_edges; ++e) { while (c < cand_edge.size() && cand_edge[c] < e) ++c; first_candidate_from_edge[e] = u32(c); }
+		for (std::size_t k(0); k + 1 < chunk_first.size(); ++k) {
+			status[k] = 0;
+			if (chunk_first[k] == chunk_first[k + 1]) continue;
+			divergence_counts counts(n_edges + 2);
+			edge_pbwt pbwt(u32(n_copies), nullptr);
+			std::copy(start_order + k * n_copies, start_order + (k + 1) * n_copies, pbwt.order.begin());
+			std::copy(start_divergence + k * n_copies, start_divergence + (k + 1) * n_copies, pbwt.divergence.begin());
+			for (u32 const d : pbwt.divergence) counts.add(d, 1);
+			pbwt.follow(&counts);
+			u64 edge(cand_edge[chunk_first[k]]), n_trials(0);
+			u32 *const pred_out(trial_pred + k * capacity), *const class_out(trial_class + k * capacity);
+			auto const emit([&](u32 pred, u32 class_count) { if (n_trials < capacity) { pred_out[n_trials] = pred; class_out[n_trials] = class_count; } ++n_trials; });
+			for (u64 next(chunk_first[k]); next < chunk_first[k + 1]; ++next) {
+				for (; edge < cand_edge[next]; ++edge) pbwt.advance(edge_column(m_graph, edge), words_per_column, edge);   // find_cut_positions.cc:170-176
+				u64 right_bound(next + 1);                                                                           // :134-165
+				u32 value(counts.largest());
+				u32 class_count(counts[value]);
+				for (value = counts.below(value); kNoValue != value; value = counts.below(value)) {
+					u64 const v(unbiased(value));
+					u64 const pred(v <= n_edges ? std::min<u64>(first_candidate_from_edge[v], right_bound) : right_bound);
+					if (pred != right_bound) {
+						right_bound = pred;
+						if (pred != next && min_distance <= cand_aligned[next] - cand_aligned[pred]) emit(u32(pred), class_count);
+					}
+					class_count += counts[value];
+				}
+				if (0 != right_bound && right_bound - 1 != next) emit(u32(right_bound - 1), class_count);
+				trial_end[next] = n_trials;
+			}
+			if (n_trials > capacity) status[k] = 1;
+		}
+	}
+
+	void records(u64 n_copies, std::vector<u32> const &cut_edge, std::vector<u64> const &chunk_first_cut, std::vector<u32> const &start_edge,
+		u32 const *start_order, u32 const *start_divergence, u64 pool_capacity, u32 *pool_lhs, u32 *pool_rhs, u32 *pool_size,
+		u64 *rec_pool_end, u32 *rec_distinct, u32 *rec_first_class, u32 *rec_first_is_ref, u32 *status) override
+	{
+		auto const &paths(m_graph.paths_by_edge_and_chrom_copy);
+		u64 const words_per_column(paths.words_per_column());
+		u32 const copies = u32(n_copies);
+		for (std::size_t k(0); k + 1 < chunk_first_cut.size(); ++k) {
+			status[k] = 0;
+			u64 const cut_begin(chunk_first_cut[k]), cut_end(chunk_first_cut[k + 1]);
+			if (cut_begin >= cut_end) continue;
+			edge_pbwt pbwt(copies, nullptr);
+			std::copy(start_order + k * n_copies, start_order + (k + 1) * n_copies, pbwt.order.begin());
+			std::copy(start_divergence + k * n_copies, start_divergence + (k + 1) * n_copies, pbwt.divergence.begin());
+			u64 edge(start_edge[k]), n_pool(0);
+			u64 const start_cut(cut_begin - 1);
+			for (; edge < cut_edge[start_cut]; ++edge) pbwt.advance(edge_column(m_graph, edge), words_per_column, edge);
+			std::vector<u32> lhs_class(copies, kPloidyMax), rhs_class(copies, kPloidyMax);
+			if (start_cut >= 1) {                                                 // the classes the previous cut left behind
+				u32 rep(kPloidyMax);
+				for (u32 i(0); i < copies; ++i) {
+					if (cut_edge[start_cut - 1] < unbiased(pbwt.divergence[i])) rep = pbwt.order[i];
+					rhs_class[pbwt.order[i]] = rep;
+				}
+			}
+			bool first_is_ref(true);
+			u32 *const lhs_out(pool_lhs + k * pool_capacity), *const rhs_out(pool_rhs + k * pool_capacity), *const size_out(pool_size + k * pool_capacity);
+			for (u64 cut(cut_begin); cut < cut_end; ++cut) {
+				for (; edge < cut_edge[cut]; ++edge) {                               // founder_sequence_greedy_output.cc:454-462
+					pbwt.advance(edge_column(m_graph, edge), words_per_column, edge);
+					first_is_ref = first_is_ref && !paths.test(pbwt.order.front(), edge);
+				}
+				lhs_class.swap(rhs_class);                                           // :215-251
+				u32 rep(kPloidyMax), distinct(0);
+				for (u32 i(0); i < copies; ++i) {
+					u32 const copy(pbwt.order[i]);
+					u64 const d(unbiased(pbwt.divergence[i]));
+					if (cut_edge[cut - 1] < d) { rep = copy; ++distinct; }
+					rhs_class[copy] = rep;
+					if (cut >= 2) {
+						if (cut_edge[cut - 2] < d) {
+							if (n_pool < pool_capacity) { lhs_out[n_pool] = lhs_class[copy]; rhs_out[n_pool] = rep; size_out[n_pool] = 0; }
+							++n_pool;
+						}
+						if (n_pool && n_pool <= pool_capacity) ++size_out[n_pool - 1];
+					}
+				}
+				rec_pool_end[cut] = n_pool;
+				rec_distinct[cut] = distinct;
+				rec_first_class[cut] = pbwt.order.front();
+				rec_first_is_ref[cut] = first_is_ref ? 1 : 0;
+				first_is_ref = true;
+			}
+			if (n_pool > pool_capacity) status[k] = 1;
+		}
+	}
+
+private:
+	variant_graph const &m_graph;
+	u64 m_max_copies;
+};
+
+} // namespace
+
+
+std::unique_ptr<founder_walker> make_host_founder_walker(variant_graph const &graph, u64 max_copies)
+{
+	return std::unique_ptr<founder_walker>(new host_founder_walker(graph, max_copies));
+}
+
+
 u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &out, unsigned threads, founder_walker *walker)
 {
 	u32 const copies(graph.total_chromosome_copies());

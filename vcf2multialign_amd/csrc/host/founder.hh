@@ -59,6 +59,12 @@ struct founder_walker {
 	u64 state_copies{};
 };
 typedef founder_walker cut_trial_walker;
+
+// A founder_walker that walks its chunks right here, edge by edge from the states it is given, on one thread: the walked
+// searches' plumbing (chunk bounds, state reuse, capacities, chunks handed back) without a GPU -- for the CPU test suite and
+// the sanitizer harness (tools/sanitize_host.sh).  It is also the plainest statement of what the GPU kernels compute.
+// max_copies: pretend to hold no more copies than this.
+std::unique_ptr<founder_walker> make_host_founder_walker(variant_graph const &graph, u64 max_copies = UINT64_MAX);
 // The same search with the chunk walks handed to `walker` (the start states are still built here, on `threads` threads, and
 // the score updates stay sequential); chunks the walker leaves undone, and graphs it cannot take, are walked here.
 u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector<u64> &cut_positions, unsigned threads, founder_walker *walker);

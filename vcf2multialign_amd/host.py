@@ -216,6 +216,23 @@ class HostGraph:
 			return None
 		return cuts[:k].tolist(), assigned[:(k - 1) * founder_count].tolist(), score.value
 
+	def find_founders_walked_on_host(self, founder_count, min_distance=0, keep_ref_edges=False, threads=2, max_copies=2 ** 63):
+		"""The walked searches (chunks handed to a founder_walker) with the host's own edge-by-edge walker: what the GPU path runs around
+		its kernels, testable without a GPU.  self.gpu_chunks = chunks (search: walked, handed back; matching: walked, handed back)."""
+		L = _load()
+		L.v2mh_find_founders_walked_on_host.restype = C.c_uint64
+		L.v2mh_find_founders_walked_on_host.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_void_p]
+		n = len(self.reference_positions)
+		cuts = np.zeros(n, dtype=np.uint64)
+		assigned = np.zeros(max(1, n * founder_count), dtype=np.uint32)
+		score = C.c_uint32()
+		chunks = (C.c_uint64 * 4)()
+		k = L.v2mh_find_founders_walked_on_host(self._h, min_distance, founder_count, int(keep_ref_edges), threads, max_copies, cuts.ctypes.data, assigned.ctypes.data, assigned.size, C.byref(score), chunks)
+		self.gpu_chunks = tuple(int(x) for x in chunks)
+		if k == 0:
+			return None
+		return cuts[:k].tolist(), assigned[:(k - 1) * founder_count].tolist(), score.value
+
 	def find_founders(self, founder_count, min_distance=0, keep_ref_edges=False, threads=1):
 		"""find_cut_positions + find_matchings (host algorithms).  Returns (cut_positions, assigned_samples column-major, score)
 		or None when there is no solution.  threads > 1 (0 = automatic) spreads the matching's pBWT over threads."""
