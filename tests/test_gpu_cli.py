@@ -326,6 +326,16 @@ def test_graphviz(tmp_path):
 	assert "\u2026" in exp and " (28)" in exp and " (30)" in exp
 
 
+def test_an_unusable_device_ends_the_run(tmp_path):
+	"""--device=99: the context cannot be created.  The run ends with the GPU path's error and writes nothing.  (The driver looks at
+	the context's fate right after the reference has been read -- by then it is known whenever the FASTA took longer than HIP's
+	start-up, 0.2 s -- and again at its first use; with a 64-byte FASTA only the second check can be relied on.)"""
+	fa, vcf = os.path.join(FIX, "test-2.fa"), os.path.join(FIX, "test-2.vcf")
+	r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(tmp_path / "x.a2m"), "--device=99"])
+	assert r.returncode != 0 and b"ERROR (GPU path" in r.stderr
+	assert not (tmp_path / "x.a2m").exists()
+
+
 def test_unsupported_and_bad_arguments():
 	assert run(["--founder-sequences=0", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0
 	assert run(["-H", "--founder-sequences=2", "-r", "x", "-a", "y", "-c", "1"]).returncode != 0

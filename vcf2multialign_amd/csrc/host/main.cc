@@ -20,6 +20,7 @@
 #include <tuple>
 #include <vector>
 
+#include <chrono>
 #include <csignal>
 
 #include "founder.hh"
@@ -292,9 +293,11 @@ int main(int argc, char **argv)
 			return EXIT_FAILURE;
 		}
 		std::cerr << " Done. Reference length is " << ref_seq.size() << ".\n";
-		// (the contexts are up by now -- 0.2 s, overlapped with the FASTA read: a missing or unusable GPU, or a bad --device, ends
-		// the run here, before the variants are parsed, not minutes later)
-		(void) first_gpu();
+		// A missing or unusable GPU, or a bad --device, should end the run here, before the variants are parsed, not minutes later.
+		// HIP's start-up takes 0.2 s whether it ends in a context or in an error, so after a reference of any size (100 Mb: 0.07 s
+		// + 30 ms of grace here; a genome: seconds) the outcome is usually in; when it is not, waiting for it would only take the
+		// overlap with the graph's loading away (0.1 s at config 3), and the first use reports the failure all the same.
+		if (std::future_status::ready == contexts_coming.wait_for(std::chrono::milliseconds(30))) (void) first_gpu();
 
 		vh::variant_graph graph;
 		if (opt.input_graph) {                                  // main.cc:392-401
