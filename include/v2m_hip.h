@@ -246,7 +246,7 @@ uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx);
  *                                       divergence values BIASED by one (0 = the reference's DIVERGENCE_MAX, pbwt.hh:25-42)
  * Outputs (host): for chunk k up to trial_capacity pairs at trial_pred / trial_class_count + k * trial_capacity -- (earlier
  * candidate, class count) in the order the reference's loop tries them --, trial_end[c] = the pairs of c's chunk up to and
- * including candidate c, and chunk_status[k] = 0, or 1 when the chunk was left undone (more than 1024 distinct earlier
+ * including candidate c (written for the candidates of this call's chunks only), and chunk_status[k] = 0, or 1 when the chunk was left undone (more than 1024 distinct earlier
  * candidates at one node, or trial_capacity exceeded): the caller walks that chunk itself.  Synchronous. */
 int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	uint64_t n_candidates, const uint32_t *cand_edge, const uint64_t *cand_aligned_pos,

@@ -1259,7 +1259,9 @@ int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 		d_chunk_first.as<u64>(), d_order.as<u32>(), d_div.as<u32>(), trial_capacity, d_pred.as<u32>(), d_class.as<u32>(), d_end.as<u64>(), d_status.as<u32>());
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-	V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_end, d_end.p, n_candidates * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+	// (only the candidates of this call's chunks: a caller may be consuming an earlier call's part of the same array meanwhile)
+	u64 const cand_lo(chunk_first[0]), cand_hi(chunk_first[n_chunks]);
+	if (cand_hi > cand_lo) V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_end + cand_lo, d_end.as<u64>() + cand_lo, (cand_hi - cand_lo) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
 	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	// only what the chunks produced comes back
 	for (u64 k(0); k < n_chunks; ++k) {
@@ -1324,10 +1326,13 @@ int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const
 		pool_capacity, d_lhs.as<u32>(), d_rhs.as<u32>(), d_size.as<u32>(), d_end.as<u64>(), d_distinct.as<u32>(), d_first.as<u32>(), d_ref.as<u32>(), d_status.as<u32>());
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-	V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_pool_end, d_end.p, n_cuts * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-	V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_distinct, d_distinct.p, n_cuts * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-	V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_first_class, d_first.p, n_cuts * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-	V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_first_is_ref, d_ref.p, n_cuts * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+	u64 const cut_lo(chunk_first_cut[0]), cut_hi(chunk_first_cut[n_chunks]);   // only the cuts of this call's chunks
+	if (cut_hi > cut_lo) {
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_pool_end + cut_lo, d_end.as<u64>() + cut_lo, (cut_hi - cut_lo) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_distinct + cut_lo, d_distinct.as<u32>() + cut_lo, (cut_hi - cut_lo) * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_first_class + cut_lo, d_first.as<u32>() + cut_lo, (cut_hi - cut_lo) * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+		V2M_HIP_TRY(ctx, hipMemcpyAsync(rec_first_is_ref + cut_lo, d_ref.as<u32>() + cut_lo, (cut_hi - cut_lo) * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+	}
 	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	for (u64 k(0); k < n_chunks; ++k) {
 		if (0 != chunk_status[k]) { chunk_status[k] = 1; continue; }
