@@ -72,7 +72,7 @@ def test_transpose_fixed(ctx, case):   # tests/transpose_matrix.cc:188-251
 
 # every kernel of the product build, with the dispatch-order switches (the other shapes and flavours exist in the tuning build
 # only: tests/test_gpu_tuning_build.py)
-TRANSPOSE_KERNELS = ["8x8", "stream16", "8x8/rr", "stream16/pf", "ring:8,8,8,8,64", "ring:8,8,8,8,128", "ring:8,8,8,8,24/sf", "ring:8,8,8,8,8/rr"]
+TRANSPOSE_KERNELS = ["8x8", "stream16", "8x8/rr", "stream16/pf", "lines8", "lines8:1", "lines8:3/sf", "lines8:8/rr"]
 
 
 @pytest.mark.parametrize("kernel", TRANSPOSE_KERNELS)
@@ -89,7 +89,7 @@ def test_transpose_random(ctx, monkeypatch, kernel, h, w):  # tests/transpose_ma
 
 
 @pytest.mark.parametrize("kernel", TRANSPOSE_KERNELS)
-@pytest.mark.parametrize("h,w", [(1, 1), (3, 17), (17, 3), (9, 33), (16, 16), (1, 79)])
+@pytest.mark.parametrize("h,w", [(1, 1), (3, 17), (17, 3), (9, 33), (16, 16), (1, 79), (79, 1), (13, 257)])
 def test_transpose_writes_only_the_destination(ctx, monkeypatch, kernel, h, w):
 	"""Device-resident transpose with guard words around the destination: panels that stick out over the matrix edge
 	must not write there."""
@@ -578,7 +578,7 @@ def test_path_slices_reproduce_every_row(ctx, v2m, tmp_path, world):
 	assert [got[r] for r in range(n_copies + 1)] == expected
 
 
-@pytest.mark.parametrize("kernel", ["", "8x8", "stream16", "ring:8,8,8,8,64", "ring:8,8,8,8,128/sf"])
+@pytest.mark.parametrize("kernel", ["", "8x8", "stream16", "lines8", "lines8:2/sf"])
 def test_bind_path_matrix_device(ctx, v2m, tmp_path, monkeypatch, kernel):
 	"""v2m_bind_path_matrix_device: a device-resident transpose input becomes the context's own (line-aligned) path matrix;
 	every transpose kernel with a destination pitch that differs from the word count."""

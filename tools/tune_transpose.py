@@ -17,7 +17,7 @@ import torch  # noqa: E402
 import vcf2multialign_amd as v2m  # noqa: E402
 from vcf2multialign_amd import _native as N  # noqa: E402
 
-QUICK = ["8x8", "stream16", "ring:8,8,8,4,64", "ring:8,8,8,8,64", "ring:8,8,8,8,64,nt", "ring:8,8,8,8,128", "ring:8,8,8,8,128,nt", "ring:8,8,8,16,128", "ring:8,4,8,8,64", "ring:8,4,8,8,128,nt", "ring:16,16,8,8,64", "ring:16,16,8,8,128,nt"]
+QUICK = ["8x8", "stream16", "stream16:old", "lines8", "lines8:4", "lines8:8", "lines8:16", "lines8:32", "lines8:0,4", "lines8:0,16", "ring:8,8,8,4,64", "ring:8,8,8,8,64", "ring:8,8,8,8,64,nt", "ring:8,8,8,8,128", "ring:8,8,8,8,128,nt", "ring:8,8,8,16,128", "ring:8,4,8,8,64", "ring:8,4,8,8,128,nt", "ring:16,16,8,8,64", "ring:16,16,8,8,128,nt"]
 FULL = QUICK + ["8x8/rr", "stream16/rr", "4x16", "16x4", "ring:16,8,8,4,64", "ring:16,8,8,4,64,slow", "ring:16,8,4,4,64", "ring:16,8,16,4,64", "ring:8,4,8,4,64"]
 
 args = sys.argv[1:]

@@ -122,6 +122,68 @@ __device__ __forceinline__ u64 wave_transpose_64x64_fast(u64 x, int lane)
 	return x;
 }
 
+// The butterfly again, written for the instruction count (round 3: the transposes issue ~100 VALU instructions per 512-byte
+// tile with the form above, which is most of what a wave does).  Per 64-bit word:
+//   distance 32: one v_permlane32_swap of the two dwords (as above);
+//   distance 16: the dwords are re-packed into (low halves, high halves) with two v_perm_b32, after which the exchange IS one
+//                v_permlane16_swap of the two registers (odd 16-lane rows of the first <-> even rows of the second), and two
+//                v_perm_b32 pack them back;
+//   distance 8:  whole bytes move: one DPP row rotate per dword, one v_perm_b32 with a per-lane selector;
+//   distance 4, 2, 1: with m = the lane's keep mask (low or ~low) the bits taken from the partner are (y & m) rotated by D
+//                one way or the other (nothing crosses the dword's ends: low has its top D bits clear), so a dword costs
+//                a DPP move + v_and, one v_alignbit_b32 with a per-lane amount and one v_and_or_b32.
+// The per-lane constants (selector, masks, rotate amounts) depend on the lane only: a kernel computes them once.
+struct lean_butterfly {
+	u32 sel8;              // v_perm_b32 selector of the distance-8 stage
+	u32 m4, m2, m1;        // keep masks
+	u32 r4, r2, r1;        // rotate-right amounts
+	__device__ __forceinline__ explicit lean_butterfly(int lane)
+		: sel8((lane & 8) ? 0x03070105u : 0x06020400u),
+		  m4((lane & 4) ? 0xF0F0F0F0u : 0x0F0F0F0Fu), m2((lane & 2) ? 0xCCCCCCCCu : 0x33333333u), m1((lane & 1) ? 0xAAAAAAAAu : 0x55555555u),
+		  r4((lane & 4) ? 4u : 28u), r2((lane & 2) ? 2u : 30u), r1((lane & 1) ? 1u : 31u)
+	{
+	}
+
+	template <int kDist> __device__ __forceinline__ static u32 partner(u32 v)
+	{
+		if constexpr (kDist == 1) return (u32) __builtin_amdgcn_mov_dpp((int) v, 0xB1, 0xF, 0xF, false);
+		else if constexpr (kDist == 2) return (u32) __builtin_amdgcn_mov_dpp((int) v, 0x4E, 0xF, 0xF, false);
+		else if constexpr (kDist == 4) return (u32) __builtin_amdgcn_mov_dpp(__builtin_amdgcn_mov_dpp((int) v, 0x141, 0xF, 0xF, false), 0x1B, 0xF, 0xF, false);
+		else { static_assert(kDist == 8, "DPP reaches the lanes of a 16-lane row"); return (u32) __builtin_amdgcn_mov_dpp((int) v, 0x128, 0xF, 0xF, false); }
+	}
+
+	template <int kDist> __device__ __forceinline__ static u32 bit_stage(u32 x, u32 m, u32 r)
+	{
+		u32 const take = partner<kDist>(x) & m;
+		return (x & m) | __builtin_amdgcn_alignbit(take, take, r);
+	}
+
+	__device__ __forceinline__ u64 operator()(u64 x) const
+	{
+		u32 lo, hi;
+		{
+			auto const r = __builtin_amdgcn_permlane32_swap((u32) x, (u32) (x >> 32), false, false);
+			lo = r[0]; hi = r[1];
+		}
+		{
+			u32 const e = __builtin_amdgcn_perm(hi, lo, 0x05040100u);     // the low halves of (lo, hi)
+			u32 const o = __builtin_amdgcn_perm(hi, lo, 0x07060302u);     // the high halves
+			auto const r = __builtin_amdgcn_permlane16_swap(e, o, false, false);   // e's odd rows <-> o's even rows
+			lo = __builtin_amdgcn_perm(r[1], r[0], 0x05040100u);
+			hi = __builtin_amdgcn_perm(r[1], r[0], 0x07060302u);
+		}
+		lo = __builtin_amdgcn_perm(partner<8>(lo), lo, sel8);
+		hi = __builtin_amdgcn_perm(partner<8>(hi), hi, sel8);
+		lo = bit_stage<4>(lo, m4, r4); hi = bit_stage<4>(hi, m4, r4);
+		lo = bit_stage<2>(lo, m2, r2); hi = bit_stage<2>(hi, m2, r2);
+		lo = bit_stage<1>(lo, m1, r1); hi = bit_stage<1>(hi, m1, r1);
+		// (without this the compiler sinks the last stage's two halves to the word's use, a write-out a whole block later, and
+		// keeps four registers per word alive instead of two)
+		asm volatile("" : "+v"(lo), "+v"(hi));
+		return ((u64) hi << 32) | lo;
+	}
+};
+
 // Workgroups are handed to the 8 XCDs round-robin (block b runs on XCD b % 8) and every XCD has its own L2.  Panels that
 // are neighbours in the matrix share 128-B lines on the side whose run is shorter than a line or not line-aligned, so the
 // work items (numbered so that neighbours are consecutive) are cut into 8 contiguous chunks, one per XCD: a shared line
@@ -172,6 +234,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 
 	// each wave owns kR / 4 row-words; pull their tiles into registers
 	constexpr int kA = kR / 4;
+	lean_butterfly const butterfly(lane);
 	u64 x[kA][kC];
 #pragma unroll
 	for (int a = 0; a < kA; ++a)
@@ -210,7 +273,7 @@ __global__ __launch_bounds__(kTrThreads) void transpose_bits_kernel(
 // takes the kernel from 52 KB of LDS -- 3 workgroups per CU -- to 35 KB -- 4).
 // kTsR x kTsC: row-words x column groups of a workgroup's block (16 x 16: a 128-B line on both sides; 8 x 32: 64-B source runs,
 // 256-B destination runs, for a dense destination whose columns start at arbitrary 8-byte offsets).
-template <int kTsDepth, int kSlabCols, int kWaves = 4, int kTsR = 16, int kTsC = 16>
+template <int kTsDepth, int kSlabCols, int kWaves = 4, int kTsR = 16, int kTsC = 16, bool kLean = true>
 __global__ __launch_bounds__(64 * kWaves) void transpose_bits_stream_kernel(
 	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,
 	u32 n_row_panels, u32 n_col_panels, u32 items_per_xcd, u32 rows_fastest)
@@ -257,6 +320,7 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_stream_kernel(
 	};
 
 	u64 y[kA][kTsC];
+	lean_butterfly const butterfly(lane);
 #pragma unroll
 	for (int cg = 0; cg < kTsDepth; ++cg) fetch(cg, stage[cg]);
 	stash(0, 0, stage[0]);
@@ -266,8 +330,9 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_stream_kernel(
 		if (cg + kTsDepth < kTsC) fetch(cg + kTsDepth, stage[cg % kTsDepth]);   // stage[cg % kTsDepth] was stashed for this group already
 #pragma unroll
 		for (int a = 0; a < kA; ++a)
-			y[a][cg] = wave_transpose_64x64_fast(in[cg & 1][lane][kA * wave + a], lane);
+			y[a][cg] = kLean ? butterfly(in[cg & 1][lane][kA * wave + a]) : wave_transpose_64x64_fast(in[cg & 1][lane][kA * wave + a], lane);
 		if (cg + 1 < kTsC) stash((cg + 1) & 1, cg + 1, stage[(cg + 1) % kTsDepth]);
+		if (kLean) __builtin_amdgcn_sched_barrier(0);              // (keeps the scheduler from interleaving the steps: 214 registers instead of 150)
 	}
 
 	// write-out, one row-word at a time through the wave's own slab (LDS operations of one wave execute in order)
@@ -441,6 +506,162 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 			compute(cg_lo + st, j & 1);
 			stash((j + 1) & 1, pf[(j + 1) % kD]);  // (after the last step: a stash nobody reads)
 		}
+	}
+}
+
+
+// Whole-line streaming transpose ("lines" kernel, round 3).
+//
+// What the dense form (destination columns at the reference's own padding, transpose_matrix.cc:53-54: a column starts at byte
+// 8 * r * DW) loses with the streaming kernel is that each of its 128-byte destination runs straddles two 128-B lines, so
+// every line is written in two masked pieces by two workgroups; the ring kernel above stores whole sectors but pays for its
+// per-step bookkeeping.  This kernel keeps the streaming kernel's structure -- transposed tiles accumulated in registers over
+// 16 column groups, written out through a wave-private LDS slab, 16 consecutive lanes per destination column -- and streams
+// on along a span of several 16-group blocks, carrying the previous block's words in registers: destination column r's lines
+// begin at its words s_r, s_r + 16, ... with s_r = (-r * dst_pitch) mod 16, so after block b the wave holds the whole line
+// [16 (b - 1) + s_r, 16 b + s_r) of every one of its columns -- the previous block's words from s_r on, the current block's
+// words before s_r.  Both blocks' words go into the slab side by side (32 words per column, no per-lane select anywhere) and
+// the column's line is read back from word s_r of them: every store is a whole, aligned 128-byte line.  Only the first and
+// last line of a span are written in two pieces (by the neighbouring spans' workgroups), and with a line-aligned pitch
+// (the library's own path matrix) s_r is 0 and the kernel degenerates into the streaming kernel.
+// A workgroup owns 8 source row-words (64-byte source runs; the panels that share the source lines are neighbours in item
+// order and on one XCD).  kWaves = 4 (two tiles per wave and step) or 8 (one).
+template <int kWaves, int kDepth, int kTsR = 8, int kSlabRows = 32>
+__global__ __launch_bounds__(64 * kWaves) void transpose_bits_lines_kernel(
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,
+	u32 n_panels, u32 n_spans, u32 span_blocks, u32 items_per_xcd, u32 panel_fastest)
+{
+	constexpr int kThreads = 64 * kWaves, kA = kTsR / kWaves, kPer = (64 * kTsR) / kThreads;
+	static_assert(kTsR % kWaves == 0 && 16 % kDepth == 0 && (64 * kTsR) % kThreads == 0 && (32 == kSlabRows || 16 == kSlabRows), "geometry");
+	__shared__ u64 in[2][64][kTsR + 1];
+	__shared__ u64 slab[kWaves][kSlabRows][33];  // [wave][destination column of the part of the tile][previous block's 16 words, this block's 16 words]
+
+	u64 item64;
+	if (!xcd_chunked_item(blockIdx.x, (u64) n_panels * n_spans, items_per_xcd, item64)) return;   // whole workgroup
+	u32 const item = (u32) item64;                                 // (a grid has fewer than 2^31 workgroups)
+	u32 const panel = panel_fastest ? item % n_panels : item / n_spans;
+	u32 const span = panel_fastest ? item / n_panels : item % n_spans;
+
+	int const t = threadIdx.x, lane = t & 63;
+	int const wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	u64 const rw0 = (u64) panel * kTsR;
+	u32 const n_blocks = ((u32) DW + 15) / 16;                     // (the host checks that DW fits comfortably)
+	u32 const b_lo = span * span_blocks, b_hi = (b_lo + span_blocks < n_blocks) ? b_lo + span_blocks : n_blocks;
+	u32 const span_lo = 16 * b_lo, span_hi = (16 * b_hi < (u32) DW) ? 16 * b_hi : (u32) DW;   // this workgroup's words of every destination column
+
+	// source: as in the streaming kernel, every load unconditional from an address clamped into the matrix (what lies outside is
+	// never stored: destination columns past SW * 64 and words past span_hi are masked at the store)
+	u32 src_off[kPer];                                             // byte offset inside a column group (the host checks 512 * src_pitch < 2^32)
+#pragma unroll
+	for (int k = 0; k < kPer; ++k) {
+		int const idx = t + kThreads * k;
+		u64 const w = rw0 + idx % kTsR;
+		src_off[k] = (u32) (((u64) (idx / kTsR) * src_pitch + (w < SW ? w : SW - 1)) * 8);
+	}
+	u32 const cg_max = (u32) DW - 1;
+	auto const fetch = [&](u64 (&st)[kPer], u32 cg) {
+		char const *const base = reinterpret_cast<char const *>(src + (u64) (cg < cg_max ? cg : cg_max) * 64 * src_pitch);   // uniform
+#pragma unroll
+		for (int k = 0; k < kPer; ++k) st[k] = *reinterpret_cast<u64 const *>(base + src_off[k]);
+	};
+	auto const stash = [&](int buf, u64 const (&st)[kPer]) {
+#pragma unroll
+		for (int k = 0; k < kPer; ++k) {
+			int const idx = t + kThreads * k;
+			in[buf][idx / kTsR][idx % kTsR] = st[k];
+		}
+	};
+
+	// destination: lane -> (column of the part of the tile, word of its line) for the stores of a part.  Column 4 k + lane / 16
+	// of the part (16 or 32 * part + that of the tile, and 16 * pitch = 0 mod 16) has s = (s_lane - 4 k * pitch) mod 16: four
+	// values, k and k + 4 share one.  The stores take a uniform base (SGPRs) and a 32-bit byte offset per lane (the host checks
+	// that 4 * dst_pitch + DW words stay below 2^29).
+	u32 const lane_col = (u32) lane >> 4, lane_word = (u32) lane & 15;
+	u32 const pitch_lo = (u32) dst_pitch & 15;
+	u32 s_word[4];                                                 // s + the lane's word of the line
+#pragma unroll
+	for (int k = 0; k < 4; ++k) s_word[k] = ((0u - (lane_col + 4 * k) * pitch_lo) & 15) + lane_word;
+	u32 const lane_col_off = lane_col * (u32) dst_pitch;
+
+	u64 y_prev[kA][16], y_cur[kA][16];
+#pragma unroll
+	for (int a = 0; a < kA; ++a)
+#pragma unroll
+		for (int c = 0; c < 16; ++c) y_prev[a][c] = 0;
+
+	// Odd spans stream BACKWARDS.  The line a span shares with its neighbour is written in two pieces, one by either workgroup;
+	// when both stream forwards one piece is written at the end of a workgroup's life and the other at the start of the next
+	// one's, a whole workgroup's run apart: the line has left the L2 in between and the memory sees two partial writes (measured:
+	// this cost as much as a sixth of the kernel's time).  With the directions alternating, neighbours reach their common
+	// boundary at the same end of their lives, and they start together (neighbouring items, same XCD).
+	bool const reverse = 0 != (span & 1);
+
+	// the lines that begin in block e: its words from s_r on (the slab's first 16 words), the next block's words before s_r (the
+	// next 16).  Forwards e is the block before the one just computed, backwards the one just computed.
+	u32 const slab_cur = reverse ? 0u : 16u, slab_prev = 16u - slab_cur;
+	auto const emit = [&](u32 e) {
+#pragma unroll
+		for (int a = 0; a < kA; ++a) {
+			u64 const rw = rw0 + (u64) (kA * wave + a);            // wave-uniform
+			bool const rw_ok = rw < SW;
+#pragma unroll
+			for (int part = 0; part < 64 / kSlabRows; ++part) {
+				if (lane / kSlabRows == part) {
+#pragma unroll
+					for (int c = 0; c < 16; ++c) {
+						slab[wave][lane % kSlabRows][slab_prev + c] = y_prev[a][c];
+						slab[wave][lane % kSlabRows][slab_cur + c] = y_cur[a][c];
+					}
+				}
+				__builtin_amdgcn_wave_barrier();                   // (LDS operations of one wave execute in order)
+				u64 v[kSlabRows / 4];
+#pragma unroll
+				for (int k = 0; k < kSlabRows / 4; ++k) v[k] = slab[wave][lane_col + 4 * k][s_word[k & 3]];
+#pragma unroll
+				for (int k = 0; k < kSlabRows / 4; ++k) {
+					u32 const c_rel = 16 * e + s_word[k & 3];      // (e = -1 wraps into a huge value or back into the first words: [span_lo, span_hi) decides)
+					char *const base = reinterpret_cast<char *>(dst + (rw * 64 + kSlabRows * part + 4 * k) * dst_pitch);   // uniform
+					if (rw_ok && c_rel >= span_lo && c_rel < span_hi)
+						*reinterpret_cast<u64 *>(base + (lane_col_off + c_rel) * 8u) = v[k];
+				}
+				__builtin_amdgcn_wave_barrier();
+			}
+		}
+	};
+
+	// step st of the span: block st / 16 from its first (forwards) or last (backwards) block, group st % 16 of the block
+	u32 const n_span_blocks = b_hi - b_lo;
+	auto const group_of = [&](u32 st) -> u32 {
+		u32 const i = st >> 4;
+		if (i >= n_span_blocks) return cg_max;                     // (prefetches past the span's end: any group will do)
+		return 16 * (reverse ? b_hi - 1 - i : b_lo + i) + (st & 15);
+	};
+
+	lean_butterfly const butterfly(lane);
+	u64 stage[kDepth][kPer];
+#pragma unroll
+	for (int j = 0; j < kDepth; ++j) fetch(stage[j], group_of(j));
+	stash(0, stage[0]);
+	// one round more than the span has blocks: the last one computes nothing (y_cur = y_prev = the span's last block) and emits
+	// that block's words from s_r on (forwards) / before s_r (backwards: the line begins in the block before the span)
+	for (u32 i = 0; i <= n_span_blocks; ++i) {
+		if (i < n_span_blocks) {
+#pragma unroll
+			for (int c = 0; c < 16; ++c) {
+				asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // (see the ring kernel: the wait __syncthreads() implies can get lost on a loop's back edge)
+				__syncthreads();                                   // in[c & 1] is complete; everyone is done with in[(c + 1) & 1]
+				fetch(stage[c % kDepth], group_of(16 * i + c + kDepth));   // stage[c % kDepth] was stashed for this step already
+#pragma unroll
+				for (int a = 0; a < kA; ++a) y_cur[a][c] = butterfly(in[c & 1][lane][kA * wave + a]);
+				stash((c + 1) & 1, stage[(c + 1) % kDepth]);
+				__builtin_amdgcn_sched_barrier(0);                 // (keeps the scheduler from interleaving the steps, which costs it 100 registers and an occupancy step)
+			}
+		}
+		emit(reverse ? b_hi - 1 - i : b_lo + i - 1);
+#pragma unroll
+		for (int a = 0; a < kA; ++a)
+#pragma unroll
+			for (int c = 0; c < 16; ++c) y_prev[a][c] = y_cur[a][c];
 	}
 }
 

@@ -241,7 +241,7 @@ int launch_transpose_shape(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 S
 	return V2M_OK;
 }
 
-template <int kDepth, int kSlabCols, int kWaves = 4, int kTsR = 16, int kTsC = 16>
+template <int kDepth, int kSlabCols, int kWaves = 4, int kTsR = 16, int kTsC = 16, bool kLean = true>
 int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, bool xcd, int order)
 {
 	u64 const P((SW + kTsR - 1) / kTsR), Q((DW + kTsC - 1) / kTsC);
@@ -249,7 +249,7 @@ int launch_transpose_stream(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 
 	if (P > 0xFFFFFFFFull || Q > 0xFFFFFFFFull || !make_xcd_grid(P * Q, xcd, g)) return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL((v2m::transpose_bits_stream_kernel<kDepth, kSlabCols, kWaves, kTsR, kTsC>), dim3(g.blocks), dim3(64 * kWaves), 0, ctx->stream, d_src, d_dst, SW, DW, SP, DP, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
+		hipLaunchKernelGGL((v2m::transpose_bits_stream_kernel<kDepth, kSlabCols, kWaves, kTsR, kTsC, kLean>), dim3(g.blocks), dim3(64 * kWaves), 0, ctx->stream, d_src, d_dst, SW, DW, SP, DP, u32(P), u32(Q), g.items_per_xcd, rows_fastest_for(order, P, Q));
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
@@ -275,7 +275,36 @@ int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP
 	return V2M_OK;
 }
 
-// Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "ring:R,W,S,D[,K[,slow|nt]]" (slow = ds_bpermute
+// The whole-line streaming kernel: kTsR row-words per workgroup on kWaves waves, spans of `span_blocks` blocks of 16 column groups.
+// span_blocks = 0: chosen here.  Long spans leave fewer lines written in two pieces, short ones more workgroups to balance: a
+// whole destination column per workgroup where columns are short and there are plenty of panels (the inverse direction of a
+// path matrix: 5 blocks at config 3, 20 at config 5), otherwise the longest of 32 / 16 / 8 / 4 blocks that still leaves
+// 4096 workgroups (measured: config 3 forward 4 or 8, config 5 forward 16-32).
+template <int kWaves, int kDepth, int kTsR = 8, int kSlabRows = 32>
+int launch_transpose_lines(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, u64 span_blocks, bool xcd, int order)
+{
+	u64 const P((SW + kTsR - 1) / kTsR), NB((DW + 15) / 16);
+	if (0 == span_blocks) {
+		if (NB <= 32 && P >= 1024) span_blocks = NB;
+		else {
+			span_blocks = 32;
+			while (span_blocks > 4 && P * ((NB + span_blocks - 1) / span_blocks) < 4096) span_blocks /= 2;
+		}
+	}
+	u64 const NS((NB + span_blocks - 1) / span_blocks);
+	xcd_grid g;
+	if (P > 0xFFFFFFFFull || NS > 0xFFFFFFFFull || span_blocks > 0xFFFFull || SP >= (u64(1) << 23) || 4 * DP + DW >= (u64(1) << 29) || !make_xcd_grid(P * NS, xcd, g))
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
+	{
+		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
+		hipLaunchKernelGGL((v2m::transpose_bits_lines_kernel<kWaves, kDepth, kTsR, kSlabRows>), dim3(g.blocks), dim3(64 * kWaves), 0, ctx->stream,
+			d_src, d_dst, SW, DW, SP, DP, u32(P), u32(NS), u32(span_blocks), g.items_per_xcd, 1 == order ? 1u : 2 == order ? 0u : 1u);
+	}
+	V2M_HIP_TRY(ctx, hipGetLastError());
+	return V2M_OK;
+}
+
+// Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "lines8[:K]" (spans of K blocks), "ring:R,W,S,D[,K[,slow|nt]]" (tuning build; slow = ds_bpermute
 // butterfly, nt = nontemporal loads and stores); trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks, "/pf" / "/sf" make the row
 // panels / the column panels (spans) run fastest in item order instead of the shorter dimension.
 #ifdef V2M_TUNING_BUILD
@@ -302,8 +331,8 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		char tail[16] = "";
 		int const got(std::sscanf(shape.c_str() + 5, "%d,%d,%d,%d,%d,%15s", &R, &W, &S, &D, &K, tail));
 		if (got < 4) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
-		bool const fast(0 != std::strcmp(tail, "slow")), nt(0 == std::strcmp(tail, "nt"));
-		// The product build holds the kernels the library picks among (kTransposeCandidates): 8x8, stream16 and ring:8,8,8,8.  The other
+		[[maybe_unused]] bool const fast(0 != std::strcmp(tail, "slow")), nt(0 == std::strcmp(tail, "nt"));
+		// The product build holds the kernels the library picks among (kTransposeCandidates): 8x8, stream16 and lines8.  The other
 		// shapes and flavours measured on the way there (tools/tune_transpose.py) are compiled with -DV2M_TUNING_BUILD
 		// only (vcf2multialign_amd/libv2m_hip_tuning.so, loaded with V2M_HIP_LIBRARY by the tuning tool and the variant tests).
 #define V2M_RING_FLAVOUR(r, w, s, d, f, n) launch_transpose_ring<r, w, s, d, f, n>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order)
@@ -314,14 +343,27 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		V2M_RING(16, 8, 8, 4) V2M_RING(16, 16, 8, 8) V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4)
 		V2M_RING(8, 4, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 8, 4) V2M_RING(8, 8, 8, 8) V2M_RING(8, 8, 8, 16)
 #undef V2M_RING
-#else
-		if (R == 8 && W == 8 && S == 8 && D == 8 && fast && !nt) return V2M_RING_FLAVOUR(8, 8, 8, 8, true, false);
 #endif
 #undef V2M_RING_FLAVOUR
-		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (the product build has 8x8, stream16 and ring:8,8,8,8; the rest needs -DV2M_TUNING_BUILD)");
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (the product build has 8x8, stream16 and lines8; the rest needs -DV2M_TUNING_BUILD)");
 	}
 	if (shape == "stream16") return launch_transpose_stream<4, 64>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+	if (0 == shape.compare(0, 6, "lines8")) {
+		// "lines8[:K]": spans of K blocks (0 / absent = chosen per shape); the tuning build also has "lines8:K,V" with V = another geometry
+		int K(0), V(8);
+		if (shape.size() > 6 && (':' != shape[6] || std::sscanf(shape.c_str() + 7, "%d,%d", &K, &V) < 1 || K < 0)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
+		if (8 == V) return launch_transpose_lines<8, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
 #ifdef V2M_TUNING_BUILD
+		if (4 == V) return launch_transpose_lines<4, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);                // 4 waves, two tiles each
+		if (88 == V) return launch_transpose_lines<8, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);               // 8 steps of prefetch
+		if (816 == V) return launch_transpose_lines<8, 4, 8, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);       // 16-column slab
+		if (16 == V) return launch_transpose_lines<16, 4, 16, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);      // 16 row-words on 16 waves
+		if (168 == V) return launch_transpose_lines<16, 8, 16, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
+#endif
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (needs -DV2M_TUNING_BUILD)");
+	}
+#ifdef V2M_TUNING_BUILD
+	if (shape == "stream16:old") return launch_transpose_stream<4, 64, 4, 16, 16, false>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "stream16:2,64") return launch_transpose_stream<2, 64>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "stream16:4,32") return launch_transpose_stream<4, 32>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 	if (shape == "stream16:2,32") return launch_transpose_stream<2, 32>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
@@ -351,7 +393,7 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 // Several kernels implement the transpose; which is fastest depends on the matrix shape, so matrices of at least 32 MiB
 // are timed once per shape and context with each candidate (the result is the same either way) and the fastest is
 // remembered.  V2M_TRANSPOSE_PANEL forces one; V2M_TRANSPOSE_CANDIDATES (comma-free list separated by ';') replaces the list.
-char const *const kTransposeCandidates[] = {"8x8", "stream16", "ring:8,8,8,8,64", "ring:8,8,8,8,128"};
+char const *const kTransposeCandidates[] = {"8x8", "stream16", "lines8"};
 
 // src_pitch / dst_pitch: words from one column to the next (0 = dense: n_rows / 64 and n_cols / 64).
 int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst, u64 src_pitch = 0, u64 dst_pitch = 0)
