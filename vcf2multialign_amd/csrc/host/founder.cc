@@ -465,7 +465,7 @@ bool find_matchings_sequential(
 
 	std::size_t const rows(cut_positions.size() - 1);
 	assigned.assign(rows * founder_count, kPloidyMax);                         // :171-172
-	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}};
+	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}, {}};
 
 	auto const &paths(graph.paths_by_edge_and_chrom_copy);
 	u64 const words_per_column(paths.words_per_column());
@@ -729,7 +729,7 @@ bool find_matchings_chunked(
 	std::size_t const n_cuts(cut_positions.size());
 	std::size_t const rows(n_cuts - 1);
 	assigned.assign(rows * founder_count, kPloidyMax);
-	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}};
+	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}, {}};
 
 	// chunks of consecutive cuts with about the same number of edges each, several per thread
 	u64 const n_edges(graph.edge_count());
@@ -841,7 +841,7 @@ bool find_matchings_walked(
 	u64 const n_edges(graph.edge_count());
 	check_edge_range(graph);
 	assigned.assign(rows * founder_count, kPloidyMax);
-	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}};
+	matcher m{founder_count, rows, assigned, {}, std::vector<char>(copies, 0), {}, {}};
 
 	phase_timer timer;
 	std::vector<u32> cut_edge(n_cuts);

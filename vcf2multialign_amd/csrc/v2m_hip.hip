@@ -421,19 +421,26 @@ int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64
 		scoped_events ev;
 		V2M_HIP_TRY(ctx, ev.create(names.size() + 1));
 		scoped_profiling_off const quiet(ctx);   // the calibration launches are not the caller's
+		std::vector<char> usable(names.size(), 1);   // a candidate may decline a shape (its index arithmetic is 32-bit): it is left out, not an error
 		for (int rep(0); rep < 2; ++rep) {        // the second round's times count (the first touches the pages)
 			V2M_HIP_TRY(ctx, hipEventRecord(ev[0], ctx->stream));
 			for (std::size_t k(0); k < names.size(); ++k) {
-				if (int const rc = launch_transpose_named(ctx, names[k], d_src, SW, DW, SP, DP, d_dst)) return rc;
+				if (usable[k]) {
+					int const rc(launch_transpose_named(ctx, names[k], d_src, SW, DW, SP, DP, d_dst));
+					if (V2M_ERR_UNSUPPORTED == rc) usable[k] = 0;
+					else if (rc) return rc;
+				}
 				V2M_HIP_TRY(ctx, hipEventRecord(ev[k + 1], ctx->stream));
 			}
 			V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 			for (std::size_t k(0); k < names.size(); ++k) {
 				float ms(0);
 				V2M_HIP_TRY(ctx, hipEventElapsedTime(&ms, ev[k], ev[k + 1]));
-				if (rep) best[k] = ms;
+				if (rep && usable[k]) best[k] = ms;
 			}
 		}
+		if (std::none_of(usable.begin(), usable.end(), [](char u) { return 0 != u; })) return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
+		if (std::any_of(usable.begin(), usable.end(), [](char u) { return 0 == u; })) ctx->err.clear();   // (the declining candidate's message)
 	}
 	std::size_t const pick(std::size_t(std::min_element(best.begin(), best.end()) - best.begin()));
 	ctx->transpose_choice.push_back({n_rows, n_cols, SP, DP, names[pick]});
