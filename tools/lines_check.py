@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Correctness of named transpose kernels on ragged shapes with guard words (tuning build), before they are timed.
 
-    python tools/lines_check.py name [name ...]"""
+    python tools/lines_check.py [--random N] name [name ...]"""
 import os
 import sys
 
@@ -16,6 +16,11 @@ import vcf2multialign_amd as v2m  # noqa: E402
 
 SHAPES = [(1, 1), (1, 2), (2, 1), (3, 5), (8, 8), (9, 7), (16, 17), (79, 33), (5, 130), (64, 64), (17, 15), (33, 31), (2, 200), (1, 79), (79, 1), (7, 300), (300, 7), (13, 257)]
 names = sys.argv[1:]
+if "--random" in names:          # --random N: N more shapes of up to 400 x 400 words (a soak run)
+	i = names.index("--random")
+	rng0 = np.random.default_rng(int(names[i + 1]))
+	SHAPES = SHAPES + [(int(rng0.integers(1, 400)), int(rng0.integers(1, 400))) for _ in range(int(names[i + 1]))]
+	del names[i:i + 2]
 bad = 0
 with v2m.Context(0) as ctx:
 	for name in names:

@@ -11,7 +11,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
-#include <future>
 #include <map>
 #include <memory>
 #include <numeric>
@@ -1197,74 +1196,46 @@ u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std:
 	for (std::size_t c(0); c < n_chunks; ++c) max_chunk_candidates = std::max<u64>(max_chunk_candidates, chunk_first[c + 1] - chunk_first[c]);
 	u64 capacity(std::max<u64>(4096, 192 * max_chunk_candidates));            // (about 100 pairs per candidate on 1KG-like input)
 	if (char const *const e = std::getenv("V2M_FOUNDER_TRIAL_CAPACITY")) if (*e) capacity = std::max<u64>(1, std::strtoull(e, nullptr, 10));   // test knob: forces chunks back to the host
-	// The walks go to the walker in batches of chunks, two host buffers in turn: batch b + 1 is being walked (on a helper
-	// thread: one call at a time) while batch b's pairs are consumed here, and the pairs of all chunks -- 800 MB at config 4 -- pass
-	// through a few dozen MB of memory that is touched once instead of being paged in and unmapped again.
-	std::size_t const batch_chunks(32);
-	std::size_t const n_batches((n_chunks + batch_chunks - 1) / batch_chunks);
-	struct batch_slot {
-		std::unique_ptr<u32[]> pred, cls;
-		std::vector<u32> status;
-		std::vector<u64> first;            // the batch's slice of chunk_first
-		std::future<void> walked;
-	};
-	batch_slot slots[2];
-	for (auto &slot : slots) { slot.pred.reset(new u32[batch_chunks * capacity]); slot.cls.reset(new u32[batch_chunks * capacity]); }
+	std::unique_ptr<u32[]> trial_pred(new u32[n_chunks * capacity]), trial_class(new u32[n_chunks * capacity]);
 	std::vector<u64> trial_end(n_cand, 0);
-	u32 const *const all_order(start_order.get()), *const all_div(start_div.get());
-	auto const launch([&](std::size_t b) {
-		batch_slot &slot(slots[b & 1]);
-		std::size_t const c0(b * batch_chunks), c1(std::min(n_chunks, c0 + batch_chunks));
-		slot.first.assign(chunk_first.begin() + std::ptrdiff_t(c0), chunk_first.begin() + std::ptrdiff_t(c1) + 1);
-		slot.status.assign(c1 - c0, 1);
-		slot.walked = std::async(std::launch::async, [&, c0, b] {
-			batch_slot &s(slots[b & 1]);
-			walker.walk(copies, min_distance, cand_edge, cand_aligned, s.first, all_order + c0 * copies, all_div + c0 * copies, capacity, s.pred.get(), s.cls.get(), trial_end.data(), s.status.data());
-		});
-	});
-
-	// the score updates, in candidate order (find_cut_positions.cc:55-63); chunks the walker left undone are walked here
-	std::vector<u32> first_candidate_from_edge;
-	walker.chunks_walked = walker.chunks_left = 0;
-	if (n_batches) launch(0);
-	for (std::size_t b(0); b < n_batches; ++b) {
-		batch_slot &slot(slots[b & 1]);
-		slot.walked.get();
-		if (b + 1 < n_batches) launch(b + 1);                                 // (the other buffer: batch b - 1 has been consumed)
-		std::size_t const c0(b * batch_chunks);
-		for (std::size_t k(0); k < slot.status.size(); ++k) {
-			std::size_t const c(c0 + k);
-			++(0 == slot.status[k] ? walker.chunks_walked : walker.chunks_left);
-			if (0 == slot.status[k]) {
-				u32 const *const pred(slot.pred.get() + k * capacity), *const cls(slot.cls.get() + k * capacity);
-				u64 t(0);
-				for (std::size_t j(chunk_first[c]); j < chunk_first[c + 1]; ++j) {
-					cut_candidate &current(cuts[j]);
-					for (u64 const t_end(trial_end[j]); t < t_end; ++t) current.improve(cls[t], cuts[pred[t]]);
-				}
-				continue;
-			}
-			if (first_candidate_from_edge.empty()) {
-				first_candidate_from_edge.resize(n_edges + 1);
-				std::size_t q(0);
-				for (u64 e(0); e <= n_edges; ++e) { while (q < cuts.size() && cuts[q].edge < e) ++q; first_candidate_from_edge[e] = u32(q); }
-			}
-			cut_search_chunk chunk;
-			chunk.first = chunk_first[c];
-			chunk.end = chunk_first[c + 1];
-			scan_cut_search_chunk(graph, min_distance, cuts, first_candidate_from_edge, chunk);
-			std::size_t t(0);
-			for (std::size_t j(chunk.first); j < chunk.end; ++j)
-				for (std::size_t const t_end(chunk.trial_end[j - chunk.first]); t < t_end; ++t) cuts[j].improve(chunk.trials[t].class_count, cuts[chunk.trials[t].pred]);
-		}
-	}
-	timer.mark("cut search: chunk walks + score updates");
+	std::vector<u32> status(n_chunks, 1);
+	walker.walk(copies, min_distance, cand_edge, cand_aligned, chunk_first, start_order.get(), start_div.get(), capacity, trial_pred.get(), trial_class.get(), trial_end.data(), status.data());
+	timer.mark("cut search: chunk walks (walker)");
 	// (the states serve the matching that follows as well: any state at or before a chunk's first cut will do there)
 	walker.state_edge.resize(n_chunks);
 	for (std::size_t c(0); c < n_chunks; ++c) walker.state_edge[c] = cand_edge[chunk_first[c]];
 	walker.state_order = std::move(start_order);
 	walker.state_divergence = std::move(start_div);
 	walker.state_copies = copies;
+
+	// the score updates, in candidate order (find_cut_positions.cc:55-63); chunks the walker left undone are walked here
+	std::vector<u32> first_candidate_from_edge;
+	walker.chunks_walked = walker.chunks_left = 0;
+	for (std::size_t c(0); c < n_chunks; ++c) {
+		++(0 == status[c] ? walker.chunks_walked : walker.chunks_left);
+		if (0 == status[c]) {
+			u32 const *const pred(trial_pred.get() + c * capacity), *const cls(trial_class.get() + c * capacity);
+			u64 t(0);
+			for (std::size_t j(chunk_first[c]); j < chunk_first[c + 1]; ++j) {
+				cut_candidate &current(cuts[j]);
+				for (u64 const t_end(trial_end[j]); t < t_end; ++t) current.improve(cls[t], cuts[pred[t]]);
+			}
+			continue;
+		}
+		if (first_candidate_from_edge.empty()) {
+			first_candidate_from_edge.resize(n_edges + 1);
+			std::size_t k(0);
+			for (u64 e(0); e <= n_edges; ++e) { while (k < cuts.size() && cuts[k].edge < e) ++k; first_candidate_from_edge[e] = u32(k); }
+		}
+		cut_search_chunk chunk;
+		chunk.first = chunk_first[c];
+		chunk.end = chunk_first[c + 1];
+		scan_cut_search_chunk(graph, min_distance, cuts, first_candidate_from_edge, chunk);
+		std::size_t t(0);
+		for (std::size_t j(chunk.first); j < chunk.end; ++j)
+			for (std::size_t const t_end(chunk.trial_end[j - chunk.first]); t < t_end; ++t) cuts[j].improve(chunk.trials[t].class_count, cuts[chunk.trials[t].pred]);
+	}
+	timer.mark("cut search: score updates");
 	return collect_cut_positions(cuts, graph, out);
 }
 
