@@ -72,11 +72,11 @@ def test_transpose_fixed(ctx, case):   # tests/transpose_matrix.cc:188-251
 
 # every kernel of the product build, with the dispatch-order switches (the other shapes and flavours exist in the tuning build
 # only: tests/test_gpu_tuning_build.py)
-TRANSPOSE_KERNELS = ["8x8", "stream16", "8x8/rr", "stream16/pf", "lines8", "lines8:1", "lines8:3/sf", "lines8:8/rr"]
+TRANSPOSE_KERNELS = ["8x8", "stream16", "8x8/rr", "stream16/pf", "lines8", "lines8:1", "lines8:3/sf", "lines8:8/rr", "lines8:400"]   # (the last: whole columns, merged column ends)
 
 
 @pytest.mark.parametrize("kernel", TRANSPOSE_KERNELS)
-@pytest.mark.parametrize("h,w", [(1, 1), (1, 2), (2, 1), (3, 5), (8, 8), (9, 7), (16, 17), (79, 33), (5, 130), (64, 64), (17, 15), (33, 31), (2, 200)])
+@pytest.mark.parametrize("h,w", [(1, 1), (1, 2), (2, 1), (3, 5), (8, 8), (9, 7), (16, 17), (79, 33), (5, 130), (64, 64), (17, 15), (33, 31), (2, 200), (3, 16), (130, 79), (4, 113)])
 def test_transpose_random(ctx, monkeypatch, kernel, h, w):  # tests/transpose_matrix.cc:254-279 (1/3 of the bits set), plus ragged panels
 	monkeypatch.setenv("V2M_TRANSPOSE_PANEL", kernel)   # both transpose kernels (the library picks per shape by measurement)
 	rng = np.random.default_rng(1000 * h + w)

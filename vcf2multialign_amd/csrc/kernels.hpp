@@ -526,7 +526,7 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 // (the library's own path matrix) s_r is 0 and the kernel degenerates into the streaming kernel.
 // A workgroup owns 8 source row-words (64-byte source runs; the panels that share the source lines are neighbours in item
 // order and on one XCD).  kWaves = 4 (two tiles per wave and step) or 8 (one).
-template <int kWaves, int kDepth, int kTsR = 8, int kSlabRows = 32>
+template <int kWaves, int kDepth, int kTsR = 8, int kSlabRows = 32, bool kMerge = false>
 __global__ __launch_bounds__(64 * kWaves) void transpose_bits_lines_kernel(
 	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,
 	u32 n_panels, u32 n_spans, u32 span_blocks, u32 items_per_xcd, u32 panel_fastest)
@@ -596,21 +596,43 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_lines_kernel(
 	// boundary at the same end of their lives, and they start together (neighbouring items, same XCD).
 	bool const reverse = 0 != (span & 1);
 
+	// kMerge (the host picks it when a workgroup takes whole destination columns of a DENSE destination, dst_pitch == DW >= 16):
+	// column r's last line and column r + 1's first are then one line of memory, and its two pieces would be written a whole
+	// run apart by the same wave.  Instead every line is written once, by the column it BEGINS in: the wave keeps its first
+	// block's words (y_first) to the end, and in the last two rounds column r + 1's first words go into column r's slab row
+	// behind its last words -- lane l + 1 writes them there.  Only a tile's first column writes its head on its own (the
+	// column before it belongs to another wave) and a tile's last column its tail.
+	u64 y_first[kMerge ? kA : 1][16];
+	u32 const n_blocks_all = n_blocks;
+
 	// the lines that begin in block e: its words from s_r on (the slab's first 16 words), the next block's words before s_r (the
 	// next 16).  Forwards e is the block before the one just computed, backwards the one just computed.
 	u32 const slab_cur = reverse ? 0u : 16u, slab_prev = 16u - slab_cur;
 	auto const emit = [&](u32 e) {
+		bool const head_round = kMerge && e + 1 == 0;              // uniform
+		bool const overlay = kMerge && e + 2 >= n_blocks_all;      // uniform: one of the last two rounds (or the head round of a one-block column)
+		u32 const overlay_at = (u32) DW - 16 * e;                  // slab position of the next column's word 0
 #pragma unroll
 		for (int a = 0; a < kA; ++a) {
 			u64 const rw = rw0 + (u64) (kA * wave + a);            // wave-uniform
 			bool const rw_ok = rw < SW;
 #pragma unroll
 			for (int part = 0; part < 64 / kSlabRows; ++part) {
+				if (head_round && part > 0) continue;
 				if (lane / kSlabRows == part) {
 #pragma unroll
 					for (int c = 0; c < 16; ++c) {
 						slab[wave][lane % kSlabRows][slab_prev + c] = y_prev[a][c];
 						slab[wave][lane % kSlabRows][slab_cur + c] = y_cur[a][c];
+					}
+				}
+				if (kMerge) {
+					if (overlay && lane >= 1 && (lane - 1) / kSlabRows == part) {
+#pragma unroll
+						for (int c = 0; c < 16; ++c) {
+							u32 const at = overlay_at + c;         // (position 32 is the row's pad word: what does not fit is not needed)
+							slab[wave][(lane - 1) % kSlabRows][at < 32 ? at : 32] = y_first[kMerge ? a : 0][c];
+						}
 					}
 				}
 				__builtin_amdgcn_wave_barrier();                   // (LDS operations of one wave execute in order)
@@ -621,7 +643,16 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_lines_kernel(
 				for (int k = 0; k < kSlabRows / 4; ++k) {
 					u32 const c_rel = 16 * e + s_word[k & 3];      // (e = -1 wraps into a huge value or back into the first words: [span_lo, span_hi) decides)
 					char *const base = reinterpret_cast<char *>(dst + (rw * 64 + kSlabRows * part + 4 * k) * dst_pitch);   // uniform
-					if (rw_ok && c_rel >= span_lo && c_rel < span_hi)
+					bool ok;
+					if (kMerge) {
+						u32 const begins = c_rel - lane_word;      // the line's first word, column-relative (huge: it begins in the column before)
+						bool const first_col = 0 == part && 0 == k && 0 == lane_col;
+						bool const last_col = 64 / kSlabRows - 1 == part && kSlabRows / 4 - 1 == k && 3 == lane_col;
+						bool const own = c_rel < (u32) DW;
+						ok = own ? (begins < (u32) DW || first_col) : (begins < (u32) DW && !last_col);
+					}
+					else ok = c_rel >= span_lo && c_rel < span_hi;
+					if (rw_ok && ok)
 						*reinterpret_cast<u64 *>(base + (lane_col_off + c_rel) * 8u) = v[k];
 				}
 				__builtin_amdgcn_wave_barrier();
@@ -656,6 +687,12 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_lines_kernel(
 				stash((c + 1) & 1, stage[(c + 1) % kDepth]);
 				__builtin_amdgcn_sched_barrier(0);                 // (keeps the scheduler from interleaving the steps, which costs it 100 registers and an occupancy step)
 			}
+		}
+		if (kMerge && 0 == i) {
+#pragma unroll
+			for (int a = 0; a < kA; ++a)
+#pragma unroll
+				for (int c = 0; c < 16; ++c) y_first[a][c] = y_cur[a][c];
 		}
 		emit(reverse ? b_hi - 1 - i : b_lo + i - 1);
 #pragma unroll

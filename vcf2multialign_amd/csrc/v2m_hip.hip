@@ -280,7 +280,7 @@ int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP
 // whole destination column per workgroup where columns are short and there are plenty of panels (the inverse direction of a
 // path matrix: 5 blocks at config 3, 20 at config 5), otherwise the longest of 32 / 16 / 8 / 4 blocks that still leaves
 // 4096 workgroups (measured: config 3 forward 4 or 8, config 5 forward 16-32).
-template <int kWaves, int kDepth, int kTsR = 8, int kSlabRows = 32>
+template <int kWaves, int kDepth, int kTsR = 8, int kSlabRows = 32, bool kMayMerge = false>
 int launch_transpose_lines(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, u64 span_blocks, bool xcd, int order)
 {
 	u64 const P((SW + kTsR - 1) / kTsR), NB((DW + 15) / 16);
@@ -297,8 +297,16 @@ int launch_transpose_lines(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 S
 		return fail(ctx, V2M_ERR_UNSUPPORTED, "matrix too large for one transpose launch");
 	{
 		timed_launch tl(ctx, V2M_KERNEL_TRANSPOSE);
-		hipLaunchKernelGGL((v2m::transpose_bits_lines_kernel<kWaves, kDepth, kTsR, kSlabRows>), dim3(g.blocks), dim3(64 * kWaves), 0, ctx->stream,
-			d_src, d_dst, SW, DW, SP, DP, u32(P), u32(NS), u32(span_blocks), g.items_per_xcd, 1 == order ? 1u : 2 == order ? 0u : 1u);
+		u32 const panel_fastest(1 == order ? 1u : 2 == order ? 0u : 1u);
+		// whole SHORT columns of a dense destination whose columns do not start on lines: every line written once, by the column it
+		// begins in.  (Short: the column ends are 2 of 6 lines at config 3's 79 words, where this is worth 9 %; at config 5's 313
+		// words they are 2 of 21 and the 34 registers the kernel needs for it cost more than they bring.)
+		if (kMayMerge && 1 == NS && NB <= 8 && DP == DW && DW >= 16 && 0 != DP % 16)
+			hipLaunchKernelGGL((v2m::transpose_bits_lines_kernel<kWaves, kDepth, kTsR, kSlabRows, kMayMerge>), dim3(g.blocks), dim3(64 * kWaves), 0, ctx->stream,
+				d_src, d_dst, SW, DW, SP, DP, u32(P), u32(NS), u32(span_blocks), g.items_per_xcd, panel_fastest);
+		else
+			hipLaunchKernelGGL((v2m::transpose_bits_lines_kernel<kWaves, kDepth, kTsR, kSlabRows, false>), dim3(g.blocks), dim3(64 * kWaves), 0, ctx->stream,
+				d_src, d_dst, SW, DW, SP, DP, u32(P), u32(NS), u32(span_blocks), g.items_per_xcd, panel_fastest);
 	}
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
@@ -352,13 +360,14 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		// "lines8[:K]": spans of K blocks (0 / absent = chosen per shape); the tuning build also has "lines8:K,V" with V = another geometry
 		int K(0), V(8);
 		if (shape.size() > 6 && (':' != shape[6] || std::sscanf(shape.c_str() + 7, "%d,%d", &K, &V) < 1 || K < 0)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
-		if (8 == V) return launch_transpose_lines<8, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
+		if (8 == V) return launch_transpose_lines<8, 4, 8, 32, true>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
 #ifdef V2M_TUNING_BUILD
 		if (4 == V) return launch_transpose_lines<4, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);                // 4 waves, two tiles each
 		if (88 == V) return launch_transpose_lines<8, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);               // 8 steps of prefetch
 		if (816 == V) return launch_transpose_lines<8, 4, 8, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);       // 16-column slab
 		if (16 == V) return launch_transpose_lines<16, 4, 16, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);      // 16 row-words on 16 waves
 		if (168 == V) return launch_transpose_lines<16, 8, 16, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
+		if (1 == V) return launch_transpose_lines<8, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);                // the product's geometry without the merged column ends
 #endif
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (needs -DV2M_TUNING_BUILD)");
 	}
