@@ -216,6 +216,18 @@ def test_ring_transpose_indexing_model():
 	assert b"cases ok" in r.stdout
 
 
+def test_lines_transpose_indexing_model():
+	"""tools/lines_transpose_model.py: the whole-line transpose kernel's carried block, slab layout, span directions, store guards
+	and merged column ends, replayed on the CPU: every destination word written exactly once with the right value, nothing
+	outside the matrix (the GPU suite then checks the real kernel)."""
+	import subprocess
+	import sys
+	ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lines_transpose_model.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+	assert r.returncode == 0, r.stderr.decode()[-2000:]
+	assert b"cases ok" in r.stdout and b"with merged column ends" in r.stdout
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
 	import subprocess
 	import sys
