@@ -45,7 +45,7 @@
 extern "C" {
 #endif
 
-#define V2M_ABI_VERSION 3
+#define V2M_ABI_VERSION 4
 
 enum {
 	V2M_OK = 0,
@@ -252,6 +252,19 @@ int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	uint64_t n_candidates, const uint32_t *cand_edge, const uint64_t *cand_aligned_pos,
 	uint64_t n_chunks, const uint64_t *chunk_first, const uint32_t *start_order, const uint32_t *start_divergence,
 	uint64_t trial_capacity, uint32_t *trial_pred, uint32_t *trial_class_count, uint64_t *trial_end, uint32_t *chunk_status);
+
+/* The same walks with the pairs handed over chunk by chunk instead of landing in arrays of the caller's: once all chunks are
+ * walked, runs of whole chunks come back through two pinned slots of the library's in turn, and `sink` is called once per chunk,
+ * in chunk order, on the calling thread -- (user, chunk index, status as above, the chunk's pairs, their number; the pointers are
+ * valid during the call only; 0 pairs for a chunk left undone or empty) -- while the next slice is crossing the link.  trial_end
+ * and chunk_status are complete before the first call.  The caller's score updates (find_cut_positions.cc:55-63) thus run under the
+ * copies, and no large pageable array is ever a copy target (config 4: 800 MB of pairs; touching, pinning and releasing such an
+ * array cost more than using it).  A sink that returns non-zero ends the call with V2M_ERR_SINK. */
+typedef int (*v2m_trials_sink)(void *user, uint64_t chunk, uint32_t status, const uint32_t *pred, const uint32_t *class_count, uint64_t n_pairs);
+int v2m_pbwt_cut_trials_streamed(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
+	uint64_t n_candidates, const uint32_t *cand_edge, const uint64_t *cand_aligned_pos,
+	uint64_t n_chunks, const uint64_t *chunk_first, const uint32_t *start_order, const uint32_t *start_divergence,
+	uint64_t trial_capacity, uint64_t *trial_end, uint32_t *chunk_status, v2m_trials_sink sink, void *sink_user);
 
 /* The same for founder_sequence_greedy_output::find_matchings (libvcf2multialign/founder_sequence_greedy_output.cc:154-512): the
  * pBWT steps between cut positions and, at every cut, what the reference's loop :215-251 collects -- the number of path classes

@@ -125,6 +125,26 @@ def test_chunks_the_gpu_leaves_undone_are_walked_on_the_host(v2m, HostGraph, tmp
 		assert hg.gpu_chunks[3] >= 1                                       # some chunks' joined classes did not fit: walked on the host
 
 
+def test_streamed_and_array_form_of_the_chunk_walks_agree(v2m, HostGraph, tmp_path, monkeypatch):
+	"""v2m_pbwt_cut_trials_streamed (pairs through pinned slots and a callback, what the searches use) and v2m_pbwt_cut_trials (pairs
+	into the caller's arrays): same cut positions, with several slices in flight and with chunks handed back to the host."""
+	rng = np.random.default_rng(91)
+	ref = synth.random_reference(rng, 120000)
+	recs = synth.random_records(rng, ref, 9000, 180, mix=(0.8, 0.1, 0.1))
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, 180)
+	og = oracle.build_variant_graph(fa, vcf, "1")
+	streamed, hg = _gpu_cuts(v2m, HostGraph, og, fa, vcf, 15)
+	assert hg.gpu_chunks_left == 0 and hg.gpu_chunks_walked > 1
+	monkeypatch.setenv("V2M_FOUNDER_ARRAYS", "1")
+	arrays, hg = _gpu_cuts(v2m, HostGraph, og, fa, vcf, 15)
+	assert hg.gpu_chunks_left == 0 and arrays == streamed
+	monkeypatch.setenv("V2M_FOUNDER_TRIAL_CAPACITY", "3000")                 # some chunks come back undone, in both forms
+	assert _gpu_cuts(v2m, HostGraph, og, fa, vcf, 15)[0] == streamed
+	monkeypatch.delenv("V2M_FOUNDER_ARRAYS")
+	got, hg = _gpu_cuts(v2m, HostGraph, og, fa, vcf, 15)
+	assert hg.gpu_chunks_left >= 1 and got == streamed
+
+
 def test_refuses_what_it_cannot_hold(v2m):
 	"""More chromosome copies than a workgroup's LDS holds, or no path matrix on the device: an error, not a silent fallback."""
 	from vcf2multialign_amd import _native as N

@@ -6,6 +6,7 @@
 #include <mutex>
 #include <exception>
 #include <thread>
+#include <sys/mman.h>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -797,6 +798,29 @@ struct phase_timer {
 	}
 };
 
+// The walkers' output areas: hundreds of MB that are written once (by a device-to-host copy) and read once.  As ordinary
+// pages, touching them for the first time and giving them back costs more than using them (config 4: 800 MB of pairs, 0.15 s to
+// release alone); mapped with 2-MB pages both costs all but vanish.
+class huge_u32_buffer {
+public:
+	explicit huge_u32_buffer(std::size_t count)
+	{
+		std::size_t const huge(std::size_t(2) << 20);
+		m_bytes = (std::max<std::size_t>(count, 1) * sizeof(u32) + huge - 1) / huge * huge;
+		void *const p(::mmap(nullptr, m_bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0));
+		if (MAP_FAILED == p) throw std::bad_alloc();
+		(void) ::madvise(p, m_bytes, MADV_HUGEPAGE);             // (advice: without transparent huge pages it is an ordinary mapping)
+		m_p = static_cast<u32 *>(p);
+	}
+	~huge_u32_buffer() { if (m_p) ::munmap(m_p, m_bytes); }
+	huge_u32_buffer(huge_u32_buffer const &) = delete;
+	huge_u32_buffer &operator=(huge_u32_buffer const &) = delete;
+	u32 *get() const { return m_p; }
+private:
+	u32 *m_p{};
+	std::size_t m_bytes{};
+};
+
 // pBWT states after the given numbers of edges, built from scratch on `threads` threads (pbwt_state_at).
 void build_states(variant_graph const &graph, std::vector<u32> const &edges, unsigned threads, std::unique_ptr<u32[]> &order, std::unique_ptr<u32[]> &divergence)
 {
@@ -869,7 +893,7 @@ bool find_matchings_walked(
 	for (std::size_t k(0); k < n_chunks; ++k) max_chunk_cuts = std::max<u64>(max_chunk_cuts, chunk_first_cut[k + 1] - chunk_first_cut[k]);
 	u64 pool_capacity(4096 + 128 * max_chunk_cuts);
 	if (char const *const e = std::getenv("V2M_FOUNDER_POOL_CAPACITY")) if (*e) pool_capacity = std::max<u64>(1, std::strtoull(e, nullptr, 10));   // test knob
-	std::unique_ptr<u32[]> pool_lhs(new u32[n_chunks * pool_capacity]), pool_rhs(new u32[n_chunks * pool_capacity]), pool_size(new u32[n_chunks * pool_capacity]);
+	huge_u32_buffer const pool_lhs(n_chunks * pool_capacity), pool_rhs(n_chunks * pool_capacity), pool_size(n_chunks * pool_capacity);
 	std::vector<u64> rec_pool_end(n_cuts, 0);
 	std::vector<u32> rec_distinct(n_cuts, 0), rec_first_class(n_cuts, 0), rec_first_is_ref(n_cuts, 0), status(n_chunks, 1);
 	walker.records(copies, cut_edge, chunk_first_cut, walker.state_edge, walker.state_order.get(), walker.state_divergence.get(),
@@ -1196,50 +1220,64 @@ u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std:
 	for (std::size_t c(0); c < n_chunks; ++c) max_chunk_candidates = std::max<u64>(max_chunk_candidates, chunk_first[c + 1] - chunk_first[c]);
 	u64 capacity(std::max<u64>(4096, 192 * max_chunk_candidates));            // (about 100 pairs per candidate on 1KG-like input)
 	if (char const *const e = std::getenv("V2M_FOUNDER_TRIAL_CAPACITY")) if (*e) capacity = std::max<u64>(1, std::strtoull(e, nullptr, 10));   // test knob: forces chunks back to the host
-	std::unique_ptr<u32[]> trial_pred(new u32[n_chunks * capacity]), trial_class(new u32[n_chunks * capacity]);
 	std::vector<u64> trial_end(n_cand, 0);
 	std::vector<u32> status(n_chunks, 1);
-	walker.walk(copies, min_distance, cand_edge, cand_aligned, chunk_first, start_order.get(), start_div.get(), capacity, trial_pred.get(), trial_class.get(), trial_end.data(), status.data());
-	timer.mark("cut search: chunk walks (walker)");
+
+	// The walker hands every chunk's pairs over in chunk order (the GPU walker: while the next chunks' pairs are still on their way
+	// back); here the score updates, in candidate order (find_cut_positions.cc:55-63).  Chunks the walker left undone are walked here.
+	std::vector<u32> first_candidate_from_edge;
+	walker.chunks_walked = walker.chunks_left = 0;
+	walker.walk_streamed(copies, min_distance, cand_edge, cand_aligned, chunk_first, start_order.get(), start_div.get(), capacity, trial_end.data(), status.data(),
+		[&](std::size_t c, u32 chunk_status, u32 const *pred, u32 const *cls, u64 n_pairs) {
+			++(0 == chunk_status ? walker.chunks_walked : walker.chunks_left);
+			if (0 == chunk_status) {
+				u64 t(0);
+				for (std::size_t j(chunk_first[c]); j < chunk_first[c + 1]; ++j) {
+					cut_candidate &current(cuts[j]);
+					u64 const t_end(trial_end[j]);
+					if (t_end > n_pairs) throw std::runtime_error("founder search: a walked chunk's pair counts exceed what it handed over");
+					for (; t < t_end; ++t) current.improve(cls[t], cuts[pred[t]]);
+				}
+				return;
+			}
+			if (first_candidate_from_edge.empty()) {
+				first_candidate_from_edge.resize(n_edges + 1);
+				std::size_t k(0);
+				for (u64 e(0); e <= n_edges; ++e) { while (k < cuts.size() && cuts[k].edge < e) ++k; first_candidate_from_edge[e] = u32(k); }
+			}
+			cut_search_chunk chunk;
+			chunk.first = chunk_first[c];
+			chunk.end = chunk_first[c + 1];
+			scan_cut_search_chunk(graph, min_distance, cuts, first_candidate_from_edge, chunk);
+			std::size_t t(0);
+			for (std::size_t j(chunk.first); j < chunk.end; ++j)
+				for (std::size_t const t_end(chunk.trial_end[j - chunk.first]); t < t_end; ++t) cuts[j].improve(chunk.trials[t].class_count, cuts[chunk.trials[t].pred]);
+		});
+	timer.mark("cut search: chunk walks + score updates");
 	// (the states serve the matching that follows as well: any state at or before a chunk's first cut will do there)
 	walker.state_edge.resize(n_chunks);
 	for (std::size_t c(0); c < n_chunks; ++c) walker.state_edge[c] = cand_edge[chunk_first[c]];
 	walker.state_order = std::move(start_order);
 	walker.state_divergence = std::move(start_div);
 	walker.state_copies = copies;
-
-	// the score updates, in candidate order (find_cut_positions.cc:55-63); chunks the walker left undone are walked here
-	std::vector<u32> first_candidate_from_edge;
-	walker.chunks_walked = walker.chunks_left = 0;
-	for (std::size_t c(0); c < n_chunks; ++c) {
-		++(0 == status[c] ? walker.chunks_walked : walker.chunks_left);
-		if (0 == status[c]) {
-			u32 const *const pred(trial_pred.get() + c * capacity), *const cls(trial_class.get() + c * capacity);
-			u64 t(0);
-			for (std::size_t j(chunk_first[c]); j < chunk_first[c + 1]; ++j) {
-				cut_candidate &current(cuts[j]);
-				for (u64 const t_end(trial_end[j]); t < t_end; ++t) current.improve(cls[t], cuts[pred[t]]);
-			}
-			continue;
-		}
-		if (first_candidate_from_edge.empty()) {
-			first_candidate_from_edge.resize(n_edges + 1);
-			std::size_t k(0);
-			for (u64 e(0); e <= n_edges; ++e) { while (k < cuts.size() && cuts[k].edge < e) ++k; first_candidate_from_edge[e] = u32(k); }
-		}
-		cut_search_chunk chunk;
-		chunk.first = chunk_first[c];
-		chunk.end = chunk_first[c + 1];
-		scan_cut_search_chunk(graph, min_distance, cuts, first_candidate_from_edge, chunk);
-		std::size_t t(0);
-		for (std::size_t j(chunk.first); j < chunk.end; ++j)
-			for (std::size_t const t_end(chunk.trial_end[j - chunk.first]); t < t_end; ++t) cuts[j].improve(chunk.trials[t].class_count, cuts[chunk.trials[t].pred]);
-	}
-	timer.mark("cut search: score updates");
 	return collect_cut_positions(cuts, graph, out);
 }
 
 } // namespace
+
+
+void founder_walker::walk_streamed(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
+	std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
+	u64 capacity, u64 *trial_end, u32 *status, chunk_taker const &take)
+{
+	std::size_t const n_chunks(chunk_first.size() - 1);
+	huge_u32_buffer const trial_pred(n_chunks * capacity), trial_class(n_chunks * capacity);
+	walk(n_copies, min_distance, cand_edge, cand_aligned, chunk_first, start_order, start_divergence, capacity, trial_pred.get(), trial_class.get(), trial_end, status);
+	for (std::size_t c(0); c < n_chunks; ++c) {
+		u64 const n((0 == status[c] && chunk_first[c] < chunk_first[c + 1]) ? trial_end[chunk_first[c + 1] - 1] : 0);
+		take(c, status[c], trial_pred.get() + c * capacity, trial_class.get() + c * capacity, n);
+	}
+}
 
 
 namespace {

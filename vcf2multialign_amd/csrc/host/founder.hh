@@ -43,6 +43,13 @@ struct founder_walker {
 	virtual void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
 		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
 		u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status) = 0;
+	// The same walks with every chunk's pairs handed to `take` (chunk, status, preds, class counts, number of pairs) in chunk order
+	// instead of landing in arrays of the caller's; trial_end and status are complete before the first call.  Here: walk() into
+	// arrays of its own, then the calls.  The GPU walker streams the pairs back while `take` works (v2m_pbwt_cut_trials_streamed).
+	typedef std::function<void(std::size_t, u32, u32 const *, u32 const *, u64)> chunk_taker;
+	virtual void walk_streamed(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
+		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
+		u64 capacity, u64 *trial_end, u32 *status, chunk_taker const &take);
 	// cut_edge: edges before every cut node; chunk_first_cut: n_chunks + 1 cut indices; start_edge: per chunk, the edges the given
 	// state has seen; pool_*: n_chunks x pool_capacity joined classes; rec_*: per cut
 	virtual void records(u64 n_copies, std::vector<u32> const &cut_edge, std::vector<u64> const &chunk_first_cut, std::vector<u32> const &start_edge,

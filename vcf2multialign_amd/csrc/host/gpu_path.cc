@@ -1,5 +1,8 @@
 #include "gpu_path.hh"
 
+#include <cstdlib>
+#include <exception>
+
 #include <algorithm>
 
 namespace v2m::host {
@@ -65,6 +68,29 @@ void gpu_founder_walker::walk(u64 n_copies, u64 min_distance, std::vector<u32> c
 {
 	m_gpu.check(v2m_pbwt_cut_trials(m_gpu.get(), n_copies, min_distance, cand_edge.size(), cand_edge.data(), cand_aligned.data(),
 		chunk_first.size() - 1, chunk_first.data(), start_order, start_divergence, capacity, trial_pred, trial_class, trial_end, status));
+}
+
+
+void gpu_founder_walker::walk_streamed(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
+	std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
+	u64 capacity, u64 *trial_end, u32 *status, chunk_taker const &take)
+{
+	if (char const *const e = std::getenv("V2M_FOUNDER_ARRAYS")) if (*e && '0' != *e) {   // test knob: the array form of the call (v2m_pbwt_cut_trials), then the hand-over
+		founder_walker::walk_streamed(n_copies, min_distance, cand_edge, cand_aligned, chunk_first, start_order, start_divergence, capacity, trial_end, status, take);
+		return;
+	}
+	// the library calls back through C: what `take` throws is parked and thrown again once the call has returned
+	struct relay { chunk_taker const &take; std::exception_ptr error; } state{take, nullptr};
+	int const rc(v2m_pbwt_cut_trials_streamed(m_gpu.get(), n_copies, min_distance, cand_edge.size(), cand_edge.data(), cand_aligned.data(),
+		chunk_first.size() - 1, chunk_first.data(), start_order, start_divergence, capacity, trial_end, status,
+		[](void *user, uint64_t chunk, uint32_t chunk_status, uint32_t const *pred, uint32_t const *class_count, uint64_t n_pairs) -> int {
+			relay &r(*static_cast<relay *>(user));
+			try { r.take(std::size_t(chunk), chunk_status, pred, class_count, n_pairs); }
+			catch (...) { r.error = std::current_exception(); return 1; }
+			return 0;
+		}, &state));
+	if (state.error) std::rethrow_exception(state.error);
+	m_gpu.check(rc);
 }
 
 

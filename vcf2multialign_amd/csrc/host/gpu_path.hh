@@ -79,6 +79,9 @@ public:
 	void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
 		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
 		u64 capacity, u32 *trial_pred, u32 *trial_class, u64 *trial_end, u32 *status) override;
+	void walk_streamed(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
+		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,
+		u64 capacity, u64 *trial_end, u32 *status, chunk_taker const &take) override;   // v2m_pbwt_cut_trials_streamed
 	void records(u64 n_copies, std::vector<u32> const &cut_edge, std::vector<u64> const &chunk_first_cut, std::vector<u32> const &start_edge,
 		u32 const *start_order, u32 const *start_divergence, u64 pool_capacity, u32 *pool_lhs, u32 *pool_rhs, u32 *pool_size,
 		u64 *rec_pool_end, u32 *rec_distinct, u32 *rec_first_class, u32 *rec_first_is_ref, u32 *status) override;

@@ -62,6 +62,7 @@ struct pinned_buf {
 		if (hipSuccess == st) bytes = n; else p = nullptr;
 		return st;
 	}
+	template <typename T> T *as() const { return static_cast<T *>(p); }
 };
 
 struct event_pair { hipEvent_t begin{}, end{}; };
@@ -118,6 +119,7 @@ struct v2m_ctx {
 	dev_buf d_eff, d_row_bits, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial, d_tile_counts, d_row_lengths;
 	dev_buf ring[2];
 	pinned_buf host_ring[2];
+	pinned_buf trials_stage[2];   // v2m_pbwt_cut_trials_streamed: the pairs' way back to the host
 	hipEvent_t ev_compute[2]{}, ev_copy[2]{};
 };
 
@@ -1270,15 +1272,20 @@ uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx) { return (ctx && ctx->has_
 
 // ---- founder search: chunk walks ------------------------------------------------------------------
 
-int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
+namespace {
+
+// v2m_pbwt_cut_trials (the pairs land in the caller's arrays) and v2m_pbwt_cut_trials_streamed (they pass through two pinned
+// slots and a callback takes them chunk by chunk while the next slice is on its way).
+int pbwt_cut_trials_impl(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	uint64_t n_candidates, const uint32_t *cand_edge, const uint64_t *cand_aligned_pos,
 	uint64_t n_chunks, const uint64_t *chunk_first, const uint32_t *start_order, const uint32_t *start_divergence,
-	uint64_t trial_capacity, uint32_t *trial_pred, uint32_t *trial_class_count, uint64_t *trial_end, uint32_t *chunk_status)
+	uint64_t trial_capacity, uint32_t *trial_pred, uint32_t *trial_class_count, uint64_t *trial_end, uint32_t *chunk_status,
+	v2m_trials_sink sink, void *sink_user)
 {
 	if (!ctx) return V2M_ERR_INVALID_ARGUMENT;
 	if (!ctx->has_graph || !ctx->d_paths) return fail(ctx, V2M_ERR_STATE, "the founder search needs an uploaded graph with its path matrix");
 	if (0 == n_chunks) return V2M_OK;
-	if (!cand_edge || !cand_aligned_pos || !chunk_first || !start_order || !start_divergence || !trial_pred || !trial_class_count || !trial_end || !chunk_status)
+	if (!cand_edge || !cand_aligned_pos || !chunk_first || !start_order || !start_divergence || (!sink && (!trial_pred || !trial_class_count)) || !trial_end || !chunk_status)
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL array");
 	if (0 == n_copies || n_copies > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk holds at most %d chromosome copies (got %llu)", v2m::kPbwtMaxCopies, (unsigned long long) n_copies);
 	if (n_copies > ctx->path_cols) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the bound path matrix has %llu copies, %llu asked for", (unsigned long long) ctx->path_cols, (unsigned long long) n_copies);
@@ -1322,15 +1329,88 @@ int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	if (cand_hi > cand_lo) V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_end + cand_lo, d_end.as<u64>() + cand_lo, (cand_hi - cand_lo) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
 	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	// only what the chunks produced comes back
+	std::vector<u64> produced(n_chunks, 0);
 	for (u64 k(0); k < n_chunks; ++k) {
 		if (0 != chunk_status[k] || chunk_first[k] == chunk_first[k + 1]) { if (0 != chunk_status[k]) chunk_status[k] = 1; continue; }
 		u64 const n(trial_end[chunk_first[k + 1] - 1]);
 		if (n > trial_capacity) { chunk_status[k] = 1; continue; }
-		V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_pred + k * trial_capacity, d_pred.as<u32>() + k * trial_capacity, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
-		V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_class_count + k * trial_capacity, d_class.as<u32>() + k * trial_capacity, n * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+		produced[k] = n;
 	}
-	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (!sink) {
+		for (u64 k(0); k < n_chunks; ++k) {
+			if (0 == produced[k]) continue;
+			V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_pred + k * trial_capacity, d_pred.as<u32>() + k * trial_capacity, produced[k] * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+			V2M_HIP_TRY(ctx, hipMemcpyAsync(trial_class_count + k * trial_capacity, d_class.as<u32>() + k * trial_capacity, produced[k] * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+		}
+		V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		return V2M_OK;
+	}
+
+	// Streamed: runs of whole chunks travel through two pinned slots in turn (pairs of a slice: preds first, class counts behind them); while
+	// the callback works through one slice the next one crosses the link.  Nothing of the caller's is ever the target of a copy:
+	// hundreds of MB of pageable memory as a copy target cost more to fault in, pin and release than the pairs take to use.
+	u64 const slot_pairs(std::max<u64>(trial_capacity, u64(4) << 20));
+	for (auto &slot : ctx->trials_stage) V2M_HIP_TRY(ctx, slot.ensure(2 * slot_pairs * sizeof(u32)));
+	scoped_events ev;
+	V2M_HIP_TRY(ctx, ev.create(2));
+	struct slice { u64 first, end; };
+	std::vector<slice> slices;
+	for (u64 k(0); k < n_chunks;) {
+		u64 end(k), pairs(0);
+		while (end < n_chunks && (end == k || pairs + produced[end] <= slot_pairs)) pairs += produced[end++];
+		slices.push_back({k, end});
+		k = end;
+	}
+	auto const issue([&](std::size_t i) -> int {
+		u32 *const pred(ctx->trials_stage[i & 1].as<u32>()), *const cls(pred + slot_pairs);
+		u64 at(0);
+		for (u64 k(slices[i].first); k < slices[i].end; ++k) {
+			if (0 == produced[k]) continue;
+			V2M_HIP_TRY(ctx, hipMemcpyAsync(pred + at, d_pred.as<u32>() + k * trial_capacity, produced[k] * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+			V2M_HIP_TRY(ctx, hipMemcpyAsync(cls + at, d_class.as<u32>() + k * trial_capacity, produced[k] * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
+			at += produced[k];
+		}
+		V2M_HIP_TRY(ctx, hipEventRecord(ev[i & 1], ctx->stream));
+		return V2M_OK;
+	});
+	if (int const rc = issue(0)) return rc;
+	for (std::size_t i(0); i < slices.size(); ++i) {
+		if (i + 1 < slices.size()) if (int const rc = issue(i + 1)) return rc;          // (the other slot: slice i - 1 has been handed over)
+		V2M_HIP_TRY(ctx, hipEventSynchronize(ev[i & 1]));
+		u32 const *const pred(ctx->trials_stage[i & 1].as<u32>()), *const cls(pred + slot_pairs);
+		u64 at(0);
+		for (u64 k(slices[i].first); k < slices[i].end; ++k) {
+			if (int const rc = sink(sink_user, k, chunk_status[k], pred + at, cls + at, produced[k])) {
+				(void) hipStreamSynchronize(ctx->stream);
+				return fail(ctx, V2M_ERR_SINK, "the trial sink returned %d at chunk %llu", rc, (unsigned long long) k);
+			}
+			at += produced[k];
+		}
+	}
 	return V2M_OK;
+}
+
+} // namespace
+
+
+int v2m_pbwt_cut_trials(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
+	uint64_t n_candidates, const uint32_t *cand_edge, const uint64_t *cand_aligned_pos,
+	uint64_t n_chunks, const uint64_t *chunk_first, const uint32_t *start_order, const uint32_t *start_divergence,
+	uint64_t trial_capacity, uint32_t *trial_pred, uint32_t *trial_class_count, uint64_t *trial_end, uint32_t *chunk_status)
+{
+	return pbwt_cut_trials_impl(ctx, n_copies, min_distance, n_candidates, cand_edge, cand_aligned_pos, n_chunks, chunk_first, start_order, start_divergence,
+		trial_capacity, trial_pred, trial_class_count, trial_end, chunk_status, nullptr, nullptr);
+}
+
+
+int v2m_pbwt_cut_trials_streamed(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
+	uint64_t n_candidates, const uint32_t *cand_edge, const uint64_t *cand_aligned_pos,
+	uint64_t n_chunks, const uint64_t *chunk_first, const uint32_t *start_order, const uint32_t *start_divergence,
+	uint64_t trial_capacity, uint64_t *trial_end, uint32_t *chunk_status, v2m_trials_sink sink, void *sink_user)
+{
+	if (ctx && !sink) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL sink");
+	return pbwt_cut_trials_impl(ctx, n_copies, min_distance, n_candidates, cand_edge, cand_aligned_pos, n_chunks, chunk_first, start_order, start_divergence,
+		trial_capacity, nullptr, nullptr, trial_end, chunk_status, sink, sink_user);
 }
 
 
