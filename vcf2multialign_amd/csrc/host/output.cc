@@ -1,10 +1,14 @@
 #include "output.hh"
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
 
 #include <fcntl.h>
 #include <sys/uio.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
+#include <atomic>
 #include <cerrno>
 #include <condition_variable>
 #include <cstring>
@@ -529,17 +533,34 @@ output::row_set founder_sequence_greedy_output::rows_for(char sep, char const *s
 	if (m_should_output_reference) {                                                // :519-531
 		rows.ids.push_back(prefixed("REF", sep) + suffix);
 		rows.copy_index.push_back(V2M_PLOIDY_MAX);
-		rows.cut_offsets.push_back(rows.cut_nodes.size());
+		rows.cut_offsets.push_back(0);
 	}
+	// the delegate's copy switch at each cut node (:106-114): one (node, copy) pair per cut and founder -- 17 M of them at config 4,
+	// written by a few threads (every founder's run of the two arrays is its own)
+	rows.cut_nodes.resize(std::size_t(m_founder_count) * col_rows);
+	rows.cut_copies.resize(std::size_t(m_founder_count) * col_rows);
 	for (u32 col(0); col < m_founder_count; ++col) {                                // :533-549
 		m_delegate->will_handle_founder_sequence(col);
 		rows.ids.push_back(prefixed(std::to_string(1 + col), sep) + suffix);        // :542
 		rows.copy_index.push_back(V2M_PLOIDY_MAX);
-		for (std::size_t k(0); k < col_rows; ++k) {                                 // the delegate's copy switch at each cut node (:106-114)
-			rows.cut_nodes.push_back(m_cut_positions[k]);
-			rows.cut_copies.push_back(m_assigned_samples[col * col_rows + k]);
-		}
-		rows.cut_offsets.push_back(rows.cut_nodes.size());
+		rows.cut_offsets.push_back(std::size_t(col + 1) * col_rows);                // (cut_offsets starts out as {0}: row r's cuts are [r], [r + 1])
+	}
+	{
+		std::atomic<u32> next(0);
+		auto const work([&] {
+			for (u32 col; (col = next.fetch_add(1)) < m_founder_count;) {
+				std::size_t const base(std::size_t(col) * col_rows);
+				for (std::size_t k(0); k < col_rows; ++k) {
+					rows.cut_nodes[base + k] = m_cut_positions[k];
+					rows.cut_copies[base + k] = m_assigned_samples[base + k];
+				}
+			}
+		});
+		std::vector<std::thread> pool;
+		unsigned const n_threads(std::size_t(m_founder_count) * col_rows >= (std::size_t(1) << 20) ? std::min<unsigned>(8, m_founder_count) : 1u);
+		for (unsigned t(1); t < n_threads; ++t) pool.emplace_back(work);
+		work();
+		for (auto &t : pool) t.join();
 	}
 	return rows;
 }
@@ -547,7 +568,12 @@ output::row_set founder_sequence_greedy_output::rows_for(char sep, char const *s
 
 void founder_sequence_greedy_output::output_a2m(variant_graph const &, std::ostream &stream)
 {
-	write_a2m(rows_for('\t', ""), stream);
+	bool const timing(nullptr != std::getenv("V2M_FOUNDER_TIMING"));
+	auto const t0(std::chrono::steady_clock::now());
+	row_set const rows(rows_for('\t', ""));
+	auto const t1(std::chrono::steady_clock::now());
+	write_a2m(rows, stream);
+	if (timing) std::fprintf(stderr, "[founder] output: row tables %.3f s, rows through the GPU %.3f s\n", std::chrono::duration<double>(t1 - t0).count(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count());
 }
 
 

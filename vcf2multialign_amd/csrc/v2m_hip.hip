@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -510,47 +512,75 @@ int prepare_rows(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begin, u64 row
 	out.n_rows = n_rows;
 	out.any_switching_row = false;
 
-	u32 n(0);
+	// segment offsets first (a row with cuts: one segment per cut, plus a leading REF one unless its first cut is node 0), then the
+	// rows are filled independently of each other: founder batches carry hundreds of thousands of cuts per row (config 4: 672 495 x 26
+	// rows, each cut checked against the graph), which a few threads do in a quarter of the time
 	out.seg_offsets[0] = 0;
 	for (u64 r(row_begin); r < row_end; ++r) {
 		u64 const c_begin(rows->cut_offsets ? rows->cut_offsets[r] : 0), c_end(rows->cut_offsets ? rows->cut_offsets[r + 1] : 0);
-		u32 const first(n);
+		u64 const n_seg(c_begin == c_end ? 1 : (c_end - c_begin) + (0 != rows->cut_nodes[c_begin] ? 1 : 0));
+		out.seg_offsets[r - row_begin + 1] = u32(out.seg_offsets[r - row_begin] + n_seg);
+		out.any_switching_row = out.any_switching_row || n_seg > 1;
+	}
+	out.n_segments = out.seg_offsets[n_rows];
+
+	// (error messages are composed where the error is found; the first failing row in row order is the one reported)
+	struct row_error { int code{V2M_OK}; std::string text; };
+	auto const fill_row([&](u64 r, row_error &err) {
+		auto const failed([&](int code, char const *fmt, unsigned long long a, unsigned long long b = 0) {
+			char buf[256];
+			std::snprintf(buf, sizeof(buf), fmt, a, b);
+			err.code = code;
+			err.text = buf;
+		});
+		u64 const c_begin(rows->cut_offsets ? rows->cut_offsets[r] : 0), c_end(rows->cut_offsets ? rows->cut_offsets[r + 1] : 0);
+		u32 n(out.seg_offsets[r - row_begin]);
 		if (c_begin == c_end) {
-			if (!rows->copy_index) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row %llu has no cuts and rows->copy_index is NULL", (unsigned long long) r);
+			if (!rows->copy_index) return failed(V2M_ERR_INVALID_ARGUMENT, "row %llu has no cuts and rows->copy_index is NULL", r);
 			u32 const copy(rows->copy_index[r]);
 			if (copy != V2M_PLOIDY_MAX && (!ctx->d_paths || copy >= ctx->path_cols))
-				return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row %llu: chromosome copy %u is outside the path matrix (%llu columns)", (unsigned long long) r, copy, (unsigned long long) ctx->path_cols);
+				return failed(V2M_ERR_INVALID_ARGUMENT, "row %llu: chromosome copy %llu is outside the path matrix", r, copy);
 			out.seg_edge_begin[n] = 0;
 			out.seg_copy[n] = copy;
-			++n;
-		} else {
-			u64 prev(0);
-			for (u64 k(c_begin); k < c_end; ++k) {
-				u64 const node(rows->cut_nodes[k]);
-				u32 const copy(rows->cut_copies[k]);
-				if (node >= ctx->n_nodes) return fail(ctx, V2M_ERR_PRECONDITION, "row %llu: cut node %llu does not exist", (unsigned long long) r, (unsigned long long) node);
-				if (k > c_begin && node <= prev) return fail(ctx, V2M_ERR_PRECONDITION, "row %llu: cut nodes must be strictly increasing", (unsigned long long) r);
-				if (copy != V2M_PLOIDY_MAX && (!ctx->d_paths || copy >= ctx->path_cols))
-					return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "row %llu: chromosome copy %u is outside the path matrix", (unsigned long long) r, copy);
-				u32 const first_edge(ctx->h_csum[node]);
-				// founder_sequence_greedy_output.cc:108 asserts the walk never jumps over a cut node
-				if (node > 0 && ctx->h_tgt_prefix_max[first_edge] > node)
-					return fail(ctx, V2M_ERR_PRECONDITION, "row %llu: cut node %llu lies inside the span of an ALT edge", (unsigned long long) r, (unsigned long long) node);
-				if (k == c_begin && node != 0) {   // copy index is PLOIDY_MAX until the first cut is visited
-					out.seg_edge_begin[n] = 0;
-					out.seg_copy[n] = V2M_PLOIDY_MAX;
-					++n;
-				}
-				out.seg_edge_begin[n] = first_edge;
-				out.seg_copy[n] = copy;
-				++n;
-				prev = node;
-			}
+			return;
 		}
-		out.any_switching_row = out.any_switching_row || n - first > 1;
-		out.seg_offsets[r - row_begin + 1] = n;
+		u64 prev(0);
+		for (u64 k(c_begin); k < c_end; ++k) {
+			u64 const node(rows->cut_nodes[k]);
+			u32 const copy(rows->cut_copies[k]);
+			if (node >= ctx->n_nodes) return failed(V2M_ERR_PRECONDITION, "row %llu: cut node %llu does not exist", r, node);
+			if (k > c_begin && node <= prev) return failed(V2M_ERR_PRECONDITION, "row %llu: cut nodes must be strictly increasing", r);
+			if (copy != V2M_PLOIDY_MAX && (!ctx->d_paths || copy >= ctx->path_cols))
+				return failed(V2M_ERR_INVALID_ARGUMENT, "row %llu: chromosome copy %llu is outside the path matrix", r, copy);
+			u32 const first_edge(ctx->h_csum[node]);
+			// founder_sequence_greedy_output.cc:108 asserts the walk never jumps over a cut node
+			if (node > 0 && ctx->h_tgt_prefix_max[first_edge] > node)
+				return failed(V2M_ERR_PRECONDITION, "row %llu: cut node %llu lies inside the span of an ALT edge", r, node);
+			if (k == c_begin && node != 0) {   // copy index is PLOIDY_MAX until the first cut is visited
+				out.seg_edge_begin[n] = 0;
+				out.seg_copy[n] = V2M_PLOIDY_MAX;
+				++n;
+			}
+			out.seg_edge_begin[n] = first_edge;
+			out.seg_copy[n] = copy;
+			++n;
+			prev = node;
+		}
+	});
+	std::vector<row_error> errors(n_rows);
+	unsigned const n_threads(out.n_segments >= (u64(1) << 20) ? unsigned(std::min<u64>(n_rows, 8)) : 1u);
+	if (n_threads <= 1) {
+		for (u64 r(row_begin); r < row_end; ++r) { fill_row(r, errors[r - row_begin]); if (V2M_OK != errors[r - row_begin].code) break; }
 	}
-	out.n_segments = n;
+	else {
+		std::atomic<u64> next(row_begin);
+		auto const work([&] { for (u64 r; (r = next.fetch_add(1)) < row_end;) fill_row(r, errors[r - row_begin]); });
+		std::vector<std::thread> pool;
+		for (unsigned t(1); t < n_threads; ++t) pool.emplace_back(work);
+		work();
+		for (auto &t : pool) t.join();
+	}
+	for (auto const &e : errors) if (V2M_OK != e.code) return fail(ctx, e.code, "%s", e.text.c_str());
 	return V2M_OK;
 }
 
@@ -1552,14 +1582,23 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 		return V2M_OK;
 	};
 
+	// V2M_SPLICE_TIMING=1: where the host's time of this call went (row tables + launches / waiting for copies + the sink), to stderr
+	bool const timing(nullptr != std::getenv("V2M_SPLICE_TIMING"));
+	double t_issue(0), t_drain(0);
+	auto const now([] { return std::chrono::steady_clock::now(); });
+	auto const since([&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); });
+	auto const t_call(now());
+
 	int rc(V2M_OK);
 	u64 launched(0);
 	for (u64 s(0); s < n_slices && V2M_OK == rc; ++s) {
 		int const b(int(s & 1));
 		u64 const r0(s * rows_per_slice), r1(std::min(rows->n_rows, r0 + rows_per_slice));
+		auto const t_slice(now());
 		rc = unaligned
 			? splice_unaligned_slice(ctx, rows, r0, r1, ctx->ring[b].as<char>(), pitch)
 			: splice_aligned_slice(ctx, rows, r0, r1, ctx->ring[b].as<char>(), pitch);
+		t_issue += since(t_slice);
 		if (V2M_OK != rc) break;
 		hipError_t st(hipSuccess);
 		if (unaligned)   // d_row_lengths is reused by the next slice: take the copy on the compute stream
@@ -1570,12 +1609,18 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 		if (hipSuccess == st) st = hipEventRecord(ctx->ev_copy[b], ctx->copy_stream);
 		if (hipSuccess != st) { rc = fail(ctx, V2M_ERR_HIP, "D2H pipeline: %s", hipGetErrorString(st)); break; }
 		launched = s + 1;
+		auto const t_d(now());
 		if (s >= 1) rc = drain(s - 1);
+		t_drain += since(t_d);
 	}
+	auto const t_d(now());
 	if (V2M_OK == rc && launched) rc = drain(launched - 1);
+	t_drain += since(t_d);
 	// leave both streams idle whatever happened
 	(void) hipStreamSynchronize(ctx->stream);
 	(void) hipStreamSynchronize(ctx->copy_stream);
+	if (timing) std::fprintf(stderr, "[v2m_splice_rows] %llu rows in %llu slices: %.3f s in all, %.3f s preparing and launching, %.3f s waiting for copies and in the sink\n",
+		(unsigned long long) rows->n_rows, (unsigned long long) n_slices, since(t_call), t_issue, t_drain);
 	return rc;
 }
 
