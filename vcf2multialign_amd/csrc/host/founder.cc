@@ -305,35 +305,78 @@ struct joined_class {                                                         //
 	bool operator<(joined_class const &o) const { return size < o.size; }
 };
 
-// The reference keeps "class representative -> founder" in a std::multimap (founder_sequence_greedy_output.cc:174); it
-// never holds more entries than there are founders and is rebuilt at every cut, so a sorted array does the same without
-// an allocation per entry: entries with equal keys stay in insertion order, find() returns the first of them (what
-// libstdc++'s and libc++'s multimap::find do), begin() is the smallest key.
+// The reference keeps "class representative -> founder" in a std::multimap (founder_sequence_greedy_output.cc:174).  It never
+// holds more entries than there are founders, every founder is in it at most once, it is refilled in founder order at every cut
+// (:431-436, and :248-302 for the first one), and it is only ever asked two things: find(key) -- which for a multimap is the
+// first inserted of the entries with that key, i.e. the LOWEST founder on that class -- and begin(), the smallest key (again its
+// lowest founder); what is erased is always the entry just found.  So the map is kept as what it is a view of: one key per
+// founder, plus, per class, the queue of the founders that sit on it in founder order.  find() is the queue's head, erase() pops
+// it, refilling is a pass over the founders -- where two dozen sorted insertions per cut, then scans of the keys, were most of
+// the assignment's time at several hundred thousand cuts (a cut makes ~40 lookups: the reference's loop :353-403 goes over the
+// joined classes again and again while founders are left, moving one founder per class and pass).
 class class_to_founder_map {
 public:
-	typedef std::pair<u32, u32> value_type;
-	typedef std::vector<value_type>::iterator iterator;
+	static constexpr u64 kGone = UINT64_MAX;       // (keys are 32-bit class representatives, kPloidyMax included)
+	static constexpr u32 kNone = UINT32_MAX;
 
-	iterator begin() { return m_entries.begin(); }
-	iterator end() { return m_entries.end(); }
-	bool empty() const { return m_entries.empty(); }
-	void clear() { m_entries.clear(); }
-	void erase(iterator it) { m_entries.erase(it); }
-
-	void insert(value_type const &v)
+	void reset(u32 founders, u32 classes)
 	{
-		m_entries.insert(std::upper_bound(m_entries.begin(), m_entries.end(), v.first, [](u32 key, value_type const &e) { return key < e.first; }), v);
+		m_key.assign(founders, kGone);
+		m_next.assign(founders, kNone);
+		m_head.assign(classes, kNone);
+		m_tail.assign(classes, kNone);
+		m_live = 0;
 	}
-	void emplace(u32 key, u32 founder) { insert({key, founder}); }
-
-	iterator find(u32 key)
+	bool empty() const { return 0 == m_live; }
+	void clear()
 	{
-		auto const it(std::lower_bound(m_entries.begin(), m_entries.end(), key, [](value_type const &e, u32 k) { return e.first < k; }));
-		return (it != m_entries.end() && it->first == key) ? it : m_entries.end();
+		for (u64 &k : m_key) { if (k < m_head.size()) m_head[k] = m_tail[k] = kNone; k = kGone; }
+		m_live = 0;
+	}
+	void emplace(u32 key, u32 founder)             // a founder that is not in the map; founders arrive in ascending order
+	{
+		m_key[founder] = key;
+		m_next[founder] = kNone;
+		++m_live;
+		if (key < m_head.size()) {
+			if (kNone == m_head[key]) m_head[key] = founder; else m_next[m_tail[key]] = founder;
+			m_tail[key] = founder;
+		}
+	}
+	void erase(u32 founder)                        // the founder find() or first() has just returned: the head of its class's queue
+	{
+		u64 const key(m_key[founder]);
+		if (key < m_head.size()) {
+			if (m_head[key] != founder) throw std::logic_error("founder matching: a founder left its class out of turn");
+			m_head[key] = m_next[founder];
+			if (kNone == m_head[key]) m_tail[key] = kNone;
+		}
+		m_key[founder] = kGone;
+		--m_live;
+	}
+
+	u32 find(u32 key) const                        // the lowest founder on class `key`, or kNone
+	{
+		if (key < m_head.size()) return m_head[key];
+		u32 const n(u32(m_key.size()));            // (kPloidyMax: founders without a class)
+		for (u32 f(0); f < n; ++f) if (m_key[f] == key) return f;
+		return kNone;
+	}
+
+	u32 first() const                              // the founder of begin(): smallest key, lowest founder; the map must not be empty
+	{
+		u32 const n(u32(m_key.size()));
+		u64 best(kGone);
+		u32 best_f(kNone);
+		for (u32 f(0); f < n; ++f) if (m_key[f] < best) { best = m_key[f]; best_f = f; }
+		return best_f;
 	}
 
 private:
-	std::vector<value_type> m_entries;
+	std::vector<u64> m_key;                        // per founder: the class it sits on, kGone once it has been continued / before it has one
+	std::vector<u32> m_next;                       // per founder: the next founder on the same class
+	std::vector<u32> m_head, m_tail;               // per class: its queue
+	u32 m_live{};
 };
 
 // The matching state that survives from one cut to the next.
@@ -362,6 +405,7 @@ struct matcher {
 	// second cut: seed row 0 (:248-302)
 	void seed(std::vector<joined_class> const &joined, u32 lhs_distinct)
 	{
+		founder_by_class.reset(founders, u32(reserved.size()));
 		u32 free_founders(founders);
 		u32 reserved_left(std::min(free_founders, lhs_distinct));
 		free_founders -= reserved_left;
@@ -397,18 +441,16 @@ struct matcher {
 		free_founders -= reserved_left;
 
 		auto const follow([&](joined_class const &c) -> bool {               // a founder currently on c.lhs_rep moves to c.rhs_rep
-			auto const it(founder_by_class.find(c.lhs_rep));
-			if (founder_by_class.end() == it) return false;
-			u32 const founder(it->second);
-			founder_by_class.erase(it);
+			u32 const founder(founder_by_class.find(c.lhs_rep));
+			if (class_to_founder_map::kNone == founder) return false;
+			founder_by_class.erase(founder);
 			slot(row, founder) = c.rhs_rep;
 			return true;
 		});
 		auto const place_anywhere([&](u32 rhs_rep) {
 			if (founder_by_class.empty()) return;
-			auto const it(founder_by_class.begin());
-			u32 const founder(it->second);
-			founder_by_class.erase(it);
+			u32 const founder(founder_by_class.first());
+			founder_by_class.erase(founder);
 			slot(row, founder) = rhs_rep;
 		});
 
@@ -447,7 +489,7 @@ struct matcher {
 			for (auto c(joined.rbegin()); c != joined.rend() && !founder_by_class.empty(); ++c) place_anywhere(c->rhs_rep);
 
 		founder_by_class.clear();                                             // :431-436
-		for (u32 f(0); f < founders; ++f) founder_by_class.insert({slot(row, f), f});
+		for (u32 f(0); f < founders; ++f) founder_by_class.emplace(slot(row, f), f);
 	}
 };
 
