@@ -951,66 +951,84 @@ bool find_matchings_walked(
 		chunks[k].end_cut = chunk_first_cut[k + 1];
 		if (chunks[k].first_cut < chunks[k].end_cut) ++(0 == status[k] ? walker.chunks_walked : walker.chunks_left);
 	}
+	// The threads take the chunks in order and leave each one ready (joined classes gathered, sorted per cut); this thread runs the
+	// assignment, in cut order (founder_sequence_greedy_output.cc:254-457), over every chunk as soon as it is ready: the sorting
+	// disappears behind the assignment.
 	{
 		std::atomic<std::size_t> next(0);
+		std::unique_ptr<std::atomic<unsigned char>[]> ready(new std::atomic<unsigned char>[n_chunks]);
+		for (std::size_t k(0); k < n_chunks; ++k) ready[k].store(0, std::memory_order_relaxed);
+		std::atomic<bool> failed(false);
 		std::exception_ptr error;
 		std::mutex error_mutex;
 		auto const work([&] {
 			try {
 				for (std::size_t k; (k = next.fetch_add(1)) < n_chunks;) {
 					cut_chunk &chunk(chunks[k]);
-					if (chunk.first_cut >= chunk.end_cut) continue;
-					if (0 != status[k]) { scan_cut_chunk(graph, cut_positions, chunk); continue; }
-					u32 const *const lhs(pool_lhs.get() + k * pool_capacity), *const rhs(pool_rhs.get() + k * pool_capacity), *const size(pool_size.get() + k * pool_capacity);
-					chunk.pool.resize(rec_pool_end[chunk.end_cut - 1]);
-					for (std::size_t i(0); i < chunk.pool.size(); ++i) chunk.pool[i] = {lhs[i], rhs[i], size[i]};
-					u64 begin(0);
-					for (std::size_t cut(chunk.first_cut); cut < chunk.end_cut; ++cut) {
-						u64 const end(rec_pool_end[cut]);
-						std::sort(chunk.pool.begin() + std::ptrdiff_t(begin), chunk.pool.begin() + std::ptrdiff_t(end));   // :256
-						chunk.records.push_back({std::size_t(begin), std::size_t(end), rec_distinct[cut], rec_first_class[cut], 0 != rec_first_is_ref[cut]});
-						begin = end;
+					if (chunk.first_cut < chunk.end_cut) {
+						if (0 != status[k]) scan_cut_chunk(graph, cut_positions, chunk);
+						else {
+							u32 const *const lhs(pool_lhs.get() + k * pool_capacity), *const rhs(pool_rhs.get() + k * pool_capacity), *const size(pool_size.get() + k * pool_capacity);
+							chunk.pool.resize(rec_pool_end[chunk.end_cut - 1]);
+							for (std::size_t i(0); i < chunk.pool.size(); ++i) chunk.pool[i] = {lhs[i], rhs[i], size[i]};
+							u64 begin(0);
+							for (std::size_t cut(chunk.first_cut); cut < chunk.end_cut; ++cut) {
+								u64 const end(rec_pool_end[cut]);
+								std::sort(chunk.pool.begin() + std::ptrdiff_t(begin), chunk.pool.begin() + std::ptrdiff_t(end));   // :256
+								chunk.records.push_back({std::size_t(begin), std::size_t(end), rec_distinct[cut], rec_first_class[cut], 0 != rec_first_is_ref[cut]});
+								begin = end;
+							}
+						}
 					}
+					ready[k].store(1, std::memory_order_release);
 				}
 			} catch (...) {
 				std::lock_guard<std::mutex> const lock(error_mutex);
 				if (!error) error = std::current_exception();
+				failed.store(true);
 			}
 		});
 		std::vector<std::thread> pool;
-		for (unsigned t(1); t < std::max(1u, threads); ++t) pool.emplace_back(work);
-		work();
+		for (unsigned t(0); t < std::max(1u, threads); ++t) pool.emplace_back(work);
+
+		u32 lhs_distinct(0), rhs_distinct(0), lhs_first_class(0), rhs_first_class(0);
+		bool lhs_first_is_ref(true);
+		std::vector<joined_class> joined;
+		std::size_t cuts_seen(0);
+		try {
+			for (std::size_t k(0); k < n_chunks && !failed.load(); ++k) {
+				while (!ready[k].load(std::memory_order_acquire)) { if (failed.load()) break; std::this_thread::yield(); }
+				if (failed.load()) break;
+				cut_chunk &chunk(chunks[k]);
+				for (auto const &rec : chunk.records) {
+					lhs_distinct = rhs_distinct;
+					lhs_first_class = rhs_first_class;
+					rhs_distinct = rec.rhs_distinct;
+					rhs_first_class = rec.rhs_first_class;
+					if (cuts_seen) {
+						joined.assign(chunk.pool.begin() + std::ptrdiff_t(rec.joined_begin), chunk.pool.begin() + std::ptrdiff_t(rec.joined_end));
+						if (!keep_ref_edges && lhs_first_is_ref && rec.rhs_first_is_ref)      // :258-264
+							std::erase_if(joined, [&](joined_class const &jc) { return jc.lhs_rep == lhs_first_class && jc.rhs_rep == rhs_first_class; });
+						if (1 == cuts_seen) m.seed(joined, lhs_distinct);
+						m.extend(cuts_seen, joined, rhs_distinct);
+					}
+					++cuts_seen;
+					lhs_first_is_ref = rec.rhs_first_is_ref;
+				}
+				std::vector<joined_class>().swap(chunk.pool);
+				std::vector<cut_record>().swap(chunk.records);
+			}
+		} catch (...) {
+			std::lock_guard<std::mutex> const lock(error_mutex);
+			if (!error) error = std::current_exception();
+			failed.store(true);
+		}
+		if (failed.load()) next.store(n_chunks);                                  // nobody starts another chunk
 		for (auto &t : pool) t.join();
 		if (error) std::rethrow_exception(error);
 	}
-
-	timer.mark("matching: gather + sort per cut");
-	// the assignment, in cut order (founder_sequence_greedy_output.cc:254-457)
-	u32 lhs_distinct(0), rhs_distinct(0), lhs_first_class(0), rhs_first_class(0);
-	bool lhs_first_is_ref(true);
-	std::vector<joined_class> joined;
-	std::size_t cuts_seen(0);
-	for (auto &chunk : chunks) {
-		for (auto const &rec : chunk.records) {
-			lhs_distinct = rhs_distinct;
-			lhs_first_class = rhs_first_class;
-			rhs_distinct = rec.rhs_distinct;
-			rhs_first_class = rec.rhs_first_class;
-			if (cuts_seen) {
-				joined.assign(chunk.pool.begin() + std::ptrdiff_t(rec.joined_begin), chunk.pool.begin() + std::ptrdiff_t(rec.joined_end));
-				if (!keep_ref_edges && lhs_first_is_ref && rec.rhs_first_is_ref)      // :258-264
-					std::erase_if(joined, [&](joined_class const &jc) { return jc.lhs_rep == lhs_first_class && jc.rhs_rep == rhs_first_class; });
-				if (1 == cuts_seen) m.seed(joined, lhs_distinct);
-				m.extend(cuts_seen, joined, rhs_distinct);
-			}
-			++cuts_seen;
-			lhs_first_is_ref = rec.rhs_first_is_ref;
-		}
-		std::vector<joined_class>().swap(chunk.pool);
-		std::vector<cut_record>().swap(chunk.records);
-	}
 	m.finish();
-	timer.mark("matching: greedy assignment");
+	timer.mark("matching: sort per cut + greedy assignment");
 	return true;
 }
 
