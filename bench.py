@@ -364,6 +364,7 @@ def main():
 			"inverse_ms": round(inv_ms, 4), "inverse_GBs": gbs(tr_bytes, inv_ms), "inverse_frac": round(tr_bytes / inv_ms / 1e6 / HBM_PEAK_GBS, 4), "involution_bit_exact": involution,
 			"note": "dense_forward / inverse: v2m_transpose_bits_device with a caller-visible destination (both sides at the reference's 64-bit padding); padded_1024: the same with both dimensions padded to 1024 bits",
 			"padded_1024": {"matrix_bits": [hp_p, ep_p], "forward_ms": round(fwd_p, 4), "forward_GBs": gbs(2 * hp_p * ep_p // 8, fwd_p), "inverse_ms": round(inv_p, 4), "inverse_GBs": gbs(2 * hp_p * ep_p // 8, inv_p)},
+			"kernels": "; ".join(note for note in ctx.info.split("; ") if note.startswith("transpose ")),   # which kernel the library measured fastest for each of these shapes
 		}
 		if not involution:
 			log("[bench] PARITY FAILURE: transpose(transpose(m)) != m")

@@ -332,7 +332,7 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_stream_kernel(
 		for (int a = 0; a < kA; ++a)
 			y[a][cg] = kLean ? butterfly(in[cg & 1][lane][kA * wave + a]) : wave_transpose_64x64_fast(in[cg & 1][lane][kA * wave + a], lane);
 		if (cg + 1 < kTsC) stash((cg + 1) & 1, cg + 1, stage[(cg + 1) % kTsDepth]);
-		if (kLean) __builtin_amdgcn_sched_barrier(0);              // (keeps the scheduler from interleaving the steps: 214 registers instead of 150)
+		if (kLean) __builtin_amdgcn_sched_barrier(0);              // (the steps stay apart in the schedule: merged, the compiler drains the whole load queue -- s_waitcnt vmcnt(0) -- nine times per block instead of once)
 	}
 
 	// write-out, one row-word at a time through the wave's own slab (LDS operations of one wave execute in order)
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_lines_kernel(
 #pragma unroll
 				for (int a = 0; a < kA; ++a) y_cur[a][c] = butterfly(in[c & 1][lane][kA * wave + a]);
 				stash((c + 1) & 1, stage[(c + 1) % kDepth]);
-				__builtin_amdgcn_sched_barrier(0);                 // (keeps the scheduler from interleaving the steps, which costs it 100 registers and an occupancy step)
+				__builtin_amdgcn_sched_barrier(0);                 // (as in the streaming kernel: the steps stay apart in the schedule)
 			}
 		}
 		if (kMerge && 0 == i) {
