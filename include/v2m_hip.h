@@ -23,6 +23,16 @@
  *                                 (chromosome_copy_index, and    libvcf2multialign/haplotype_output.cc:22-32
  *                                 the founder delegate's copy    libvcf2multialign/founder_sequence_greedy_output.cc:78-115
  *                                 switch at cut nodes)
+ *   v2m_upload_path_slice /       transpose_matrix() at its one  libvcf2multialign/variant_graph.cc:453
+ *   v2m_upload_path_blocks /      call site, for one GPU's       include/vcf2multialign/variant_graph.hh:62-63
+ *   v2m_bind_path_matrix_device   chromosome copies (or all)
+ *   v2m_pbwt_cut_trials[_streamed] the edge-by-edge part of      include/vcf2multialign/pbwt.hh:77-134
+ *   v2m_pbwt_cut_records          find_cut_positions() and       libvcf2multialign/find_cut_positions.cc:126-176
+ *                                 find_matchings() (optional)    libvcf2multialign/founder_sequence_greedy_output.cc:208-251
+ *
+ * V2M_ABI_VERSION: 1 = round 1 (transpose, graph, rows); 2 = + v2m_upload_path_slice, v2m_bind_path_matrix_device;
+ * 3 = + v2m_upload_path_blocks, v2m_pbwt_cut_trials, v2m_pbwt_cut_records; 4 = + v2m_pbwt_cut_trials_streamed.
+ * Entries are only ever added.
  *
  * Conventions
  *   - Plain C: pointers + sizes, no exceptions, no C++/torch types.  Every function that can
