@@ -30,9 +30,9 @@
  *   v2m_pbwt_cut_records          find_cut_positions() and       libvcf2multialign/find_cut_positions.cc:126-176
  *                                 find_matchings() (optional)    libvcf2multialign/founder_sequence_greedy_output.cc:208-251
  *
- * V2M_ABI_VERSION: 1 = round 1 (transpose, graph, rows); 2 = + v2m_upload_path_slice, v2m_bind_path_matrix_device;
- * 3 = + v2m_upload_path_blocks, v2m_pbwt_cut_trials, v2m_pbwt_cut_records; 4 = + v2m_pbwt_cut_trials_streamed.
- * Entries are only ever added.
+ * V2M_ABI_VERSION: 1 = round 1 (transpose, graph, rows); 2 = + v2m_upload_path_slice, v2m_alloc_output / v2m_free_output,
+ * v2m_profile_get_launches (v2m_bind_path_matrix_device followed without a step); 3 = + v2m_upload_path_blocks (and then
+ * v2m_pbwt_cut_trials, v2m_pbwt_cut_records); 4 = + v2m_pbwt_cut_trials_streamed.  Entries have only ever been added.
  *
  * Conventions
  *   - Plain C: pointers + sizes, no exceptions, no C++/torch types.  Every function that can
