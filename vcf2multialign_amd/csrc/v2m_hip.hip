@@ -283,7 +283,8 @@ int launch_transpose_ring(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP
 // span_blocks = 0: chosen here.  Long spans leave fewer lines written in two pieces, short ones more workgroups to balance: a
 // whole destination column per workgroup where columns are short and there are plenty of panels (the inverse direction of a
 // path matrix: 5 blocks at config 3, 20 at config 5), otherwise the longest of 32 / 16 / 8 / 4 blocks that still leaves
-// 4096 workgroups (measured: config 3 forward 4 or 8, config 5 forward 16-32).
+// 1024 workgroups = two rounds over the chip (measured, config 3 forward with its 10 panels: 8 or 10 blocks 0.295-0.306 ms,
+// 4-7 blocks 0.300-0.322, 12 and more 0.334-0.347; config 5 forward: 16-32).
 template <int kWaves, int kDepth, int kTsR = 8, int kSlabRows = 32, bool kMayMerge = false>
 int launch_transpose_lines(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, u64 span_blocks, bool xcd, int order)
 {
@@ -292,7 +293,7 @@ int launch_transpose_lines(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 S
 		if (NB <= 32 && P >= 1024) span_blocks = NB;
 		else {
 			span_blocks = 32;
-			while (span_blocks > 4 && P * ((NB + span_blocks - 1) / span_blocks) < 4096) span_blocks /= 2;
+			while (span_blocks > 4 && P * ((NB + span_blocks - 1) / span_blocks) < 1024) span_blocks /= 2;
 		}
 	}
 	u64 const NS((NB + span_blocks - 1) / span_blocks);
