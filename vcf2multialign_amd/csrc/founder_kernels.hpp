@@ -77,13 +77,26 @@ __device__ __forceinline__ pbwt_scan_item scan_shfl_up(pbwt_scan_item const &x, 
 // One step of Durbin's algorithm 2 for edge `edge` (pbwt.hh:77-134) by the whole workgroup: state order[cur] / divergence[cur]
 // -> order[cur ^ 1] / divergence[cur ^ 1].  Thread t owns the copies [my_begin, my_end) of the order.  Returns how many copies do
 // NOT use the edge (workgroup-uniform).  Contains three barriers; the caller flips `cur`.
+// The edge's bit column (words_per_edge <= 128 words, one per thread) travels in a register: `column_word` holds thread t's word of
+// THIS edge on entry -- fetched while the previous step ran, or by pbwt_fetch_column() before the first one -- and of the next
+// edge on return (steps always visit consecutive edges; `edge_limit` clamps the fetch after the last one).  Fetched at the top of
+// the step instead, every step stood still for one global-memory latency (config 4: 58.3 -> 56.9 ms and 28.3 -> 27.0 ms for the two
+// kernels -- most of a step is barriers and dependent LDS passes, not this).
+__device__ __forceinline__ uint64_t pbwt_fetch_column(uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge, uint32_t edge_limit, int t)
+{
+	if (0u == edge_limit) return 0;
+	uint32_t const e = edge < edge_limit ? edge : edge_limit - 1u;
+	return (uint32_t) t < words_per_edge ? paths_by_edge[(uint64_t) e * words_per_edge + (uint32_t) t] : 0;
+}
+
 __device__ __forceinline__ uint32_t pbwt_step(
-	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge,
+	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge, uint32_t edge_limit, uint64_t &column_word,
 	unsigned short (*order)[kPbwtMaxCopies], uint32_t (*divergence)[kPbwtMaxCopies], uint64_t *column, pbwt_scan_item *wave_items,
 	int cur, uint32_t my_begin, uint32_t my_end, int t, int lane, int wave)
 {
-	for (uint32_t w = t; w < words_per_edge; w += kPbwtThreads) column[w] = paths_by_edge[(uint64_t) edge * words_per_edge + w];
+	if ((uint32_t) t < words_per_edge) column[t] = column_word;
 	pbwt_block_sync();
+	column_word = pbwt_fetch_column(paths_by_edge, words_per_edge, edge + 1u, edge_limit, t);   // in flight while this step runs
 	unsigned short const *const ord = order[cur];
 	uint32_t const *const dv = divergence[cur];
 	// what this thread's run of copies does to the zero count and to the two running maxima
@@ -173,6 +186,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 	int cur = 0;
 	uint64_t n_trials = 0;                                 // (kept by every thread: all of them see the same counts)
 	uint32_t edge = cand_begin < cand_end ? cand_edge[cand_begin] : 0;
+	uint64_t column_word = pbwt_fetch_column(paths_by_edge, words_per_edge, edge, n_edges, t);
 	uint32_t *const my_pred = trial_pred + (uint64_t) chunk * trial_capacity;
 	uint32_t *const my_class = trial_class_count + (uint64_t) chunk * trial_capacity;
 
@@ -180,7 +194,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		// ---- the edges before this candidate's node (find_cut_positions.cc:170-176 over pbwt.hh:77-134) -----------------
 		uint32_t const upto = cand_edge[cand];
 		for (; edge < upto; ++edge) {
-			pbwt_step(paths_by_edge, words_per_edge, edge, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
+			pbwt_step(paths_by_edge, words_per_edge, edge, n_edges, column_word, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
 			cur ^= 1;
 		}
 
@@ -316,7 +330,7 @@ __device__ __forceinline__ class_scan_item class_shfl_up(class_scan_item const &
 __device__ __forceinline__ bool past_edge(uint32_t d, uint32_t threshold) { return 0u == d || d - 1u > threshold; }
 
 __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
-	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t n_copies,
+	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t n_copies, uint32_t n_edge_columns /* columns of paths_by_edge (>= every edge visited + 1 is not required: fetches are clamped) */,
 	uint32_t const *__restrict__ cut_edge,                // [n_cuts]: edges before each cut node
 	uint64_t const *__restrict__ chunk_first_cut,         // [n_chunks + 1]: chunk k handles the cuts [first[k], first[k + 1]); first[k] >= 1
 	uint32_t const *__restrict__ start_edge,              // [n_chunks]: the given state is the one after this many edges (<= cut_edge[first[k] - 1])
@@ -352,10 +366,11 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 
 	int cur = 0, rhs = 0;                                  // copy_class[rhs]: the classes the last cut left behind
 	uint32_t edge = start_edge[chunk];
+	uint64_t column_word = pbwt_fetch_column(paths_by_edge, words_per_edge, edge, n_edge_columns, t);
 	// up to the cut before the chunk's first one; the classes it left behind (founder.cc:scan_cut_chunk)
 	uint64_t const start_cut = cut_begin - 1;
 	for (uint32_t const upto = cut_edge[start_cut]; edge < upto; ++edge) {
-		pbwt_step(paths_by_edge, words_per_edge, edge, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
+		pbwt_step(paths_by_edge, words_per_edge, edge, n_edge_columns, column_word, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
 		cur ^= 1;
 	}
 
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	bool first_is_ref = true;
 	for (uint64_t cut = cut_begin; cut < cut_end; ++cut) {
 		for (uint32_t const upto = cut_edge[cut]; edge < upto; ++edge) {
-			uint32_t const zeros = pbwt_step(paths_by_edge, words_per_edge, edge, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
+			uint32_t const zeros = pbwt_step(paths_by_edge, words_per_edge, edge, n_edge_columns, column_word, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
 			cur ^= 1;
 			// the copy that is first in the order now uses the edge exactly when no copy does not (:454-462)
 			first_is_ref = first_is_ref && 0u != zeros;

@@ -1491,7 +1491,7 @@ int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const
 	V2M_HIP_TRY(ctx, d_status.ensure(n_chunks * sizeof(u32)));
 	V2M_HIP_TRY(ctx, hipMemsetAsync(d_status.p, 0xFF, n_chunks * sizeof(u32), ctx->stream));
 	hipLaunchKernelGGL(v2m::pbwt_cut_records_kernel, dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
-		d_by_edge.as<u64>(), u32(cols / 64), u32(n_copies), d_cut_edge.as<u32>(), d_chunk_first.as<u64>(), d_start_edge.as<u32>(), d_order.as<u32>(), d_div.as<u32>(),
+		d_by_edge.as<u64>(), u32(cols / 64), u32(n_copies), u32(rows), d_cut_edge.as<u32>(), d_chunk_first.as<u64>(), d_start_edge.as<u32>(), d_order.as<u32>(), d_div.as<u32>(),
 		pool_capacity, d_lhs.as<u32>(), d_rhs.as<u32>(), d_size.as<u32>(), d_end.as<u64>(), d_distinct.as<u32>(), d_first.as<u32>(), d_ref.as<u32>(), d_status.as<u32>());
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
