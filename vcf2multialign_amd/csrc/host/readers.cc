@@ -6,6 +6,13 @@
 #include <unistd.h>
 
 #include <condition_variable>
+#include <cstdlib>
+#include <cstdio>
+#include <chrono>
+#include <algorithm>
+#include <memory>
+#include <exception>
+#include <functional>
 #include <cstring>
 #include <fstream>
 #include <mutex>
@@ -92,7 +99,7 @@ struct field_cursor {
 
 // ---- record parsing (runs on worker threads) ------------------------------------------------------------------
 
-struct parsed_genotype { u32 row, alt_number, sample, copy; };
+struct parsed_genotype { u32 row, alt_number; };   // (which sample and copy a row is comes from the context when an overlap is reported: 8 bytes x 360 M genotypes at config 3)
 
 struct parsed_record {
 	u64 line_in_chunk;        // 1-based within the chunk
@@ -123,6 +130,10 @@ struct parse_context {
 };
 
 struct chunk_error { u64 line; char const *what; };
+
+// "0|0\t" and "0/0\t" as the four bytes a little-endian load sees
+constexpr std::uint32_t kRefRefPhased = 0x09307C30u, kRefRefUnphased = 0x09302F30u;
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "the column fast path compares little-endian words");
 
 // Parses the lines of text[begin, end) (whole lines) into `out`.
 void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &out)
@@ -174,7 +185,20 @@ void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &
 			// genotypes of the included copies (:379-425); allele 0 and '.' are not recorded (:393-397)
 			rec.geno_begin = out.genos.size();
 			std::size_t sample(0);
-			for (std::string_view field; fc.next(field); ++sample) {
+			for (std::string_view field; ; ++sample) {
+				// Most of a population-scale VCF is "0|0\t": both copies on the reference allele, nothing to record (:393-397).  Runs of
+				// such columns are skipped four bytes at a time instead of a memchr and three loops each (config 3: 2.5 G columns; GT must
+				// be the first FORMAT key and the sample at most diploid, so that the general path below would find nothing either).
+				if (0 == gt_index) {
+					while (!fc.done && fc.end - fc.p >= 4 && sample < ctx.n_samples && ctx.copy_begin[sample + 1] - ctx.copy_begin[sample] <= 2) {
+						std::uint32_t four;
+						std::memcpy(&four, fc.p, 4);
+						if (kRefRefPhased != four && kRefRefUnphased != four) break;
+						fc.p += 4;
+						++sample;
+					}
+				}
+				if (!fc.next(field)) break;
 				if (sample >= ctx.n_samples) throw chunk_error{out.n_lines, "more sample columns than in the header"};
 				std::string_view gt(field);
 				if (gt_index || std::string_view::npos != field.find(':')) {
@@ -200,7 +224,7 @@ void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &
 								for (char const c : tok) { if (c < '0' || '9' < c) throw chunk_error{out.n_lines, "bad GT allele"}; allele = 10 * allele + u32(c - '0'); }
 								if (allele) {
 									if (allele > rec.n_alts) throw chunk_error{out.n_lines, "GT allele exceeds the ALT count"};
-									out.genos.push_back({u32(row), allele, u32(sample), copy});
+									out.genos.push_back({u32(row), allele});
 								}
 							}
 						}
@@ -330,6 +354,13 @@ void build_variant_graph(
 		return;
 	}
 
+	// about one ALT edge per line of the size of the first record's (a hint for the path matrix's allocation, nothing more)
+	{
+		std::size_t const first_eol(text.find('\n', body_begin));
+		std::size_t const line_bytes(std::max<std::size_t>(16, (std::string_view::npos == first_eol ? text.size() : first_eol) - body_begin + 1));
+		builder.expect_edges(u64(double(text.size() - body_begin) / double(line_bytes) * 1.1) + 1024);
+	}
+
 	// ---- chunks of whole lines, parsed by worker threads, merged in file order -------------------------------------
 	if (0 == threads) threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
 	std::size_t const target_chunk(std::size_t(8) << 20);
@@ -352,6 +383,7 @@ void build_variant_graph(
 	std::size_t next_chunk(0), consumed(0);
 	std::size_t const window(std::max<std::size_t>(2, 2 * threads));
 	bool abort_workers(false);
+	std::vector<std::vector<parsed_genotype>> spare_genos;           // (under `mutex`)
 
 	auto const worker([&] {
 		for (;;) {
@@ -361,6 +393,12 @@ void build_variant_graph(
 				cv_window.wait(lock, [&] { return abort_workers || next_chunk >= n_chunks || next_chunk < consumed + window; });
 				if (abort_workers || next_chunk >= n_chunks) return;
 				idx = next_chunk++;
+			}
+			{
+				// (a genotype list that an earlier chunk has been through: its pages are there already; fresh ones of this size
+				// come from mmap every time and cost a fault per page)
+				std::lock_guard<std::mutex> lock(mutex);
+				if (!spare_genos.empty()) { chunks[idx].genos.swap(spare_genos.back()); spare_genos.pop_back(); }
 			}
 			parse_chunk(text.substr(ranges[idx].first, ranges[idx].second - ranges[idx].first), ctx, chunks[idx]);
 			{
@@ -384,60 +422,202 @@ void build_variant_graph(
 	} const join_on_exit{pool, mutex, cv_window, abort_workers};
 
 	u64 lineno_base(header_lines), var_idx(0);
-	std::string_view cur_id;
-	u32 cur_sample(0), cur_copy(0);
-	u64 cur_lineno(0);
-	builder.on_overlap([&](overlap_info const &o) {
-		delegate.report_overlapping_alternative(cur_lineno, o.ref_pos, cur_id, vcf_sample_names[cur_sample], cur_copy, o.alt_number);
-	});
+
+	// row of the path matrix -> (sample column, copy of it), for the overlap reports
+	std::vector<std::pair<u32, u32>> row_origin;
+	for (std::size_t smp(0); smp < ctx.n_samples; ++smp)
+		for (u32 c(ctx.copy_begin[smp]); c < ctx.copy_begin[smp + 1]; ++c)
+			if (ctx.row_lookup[c] >= 0) {
+				if (row_origin.size() <= std::size_t(ctx.row_lookup[c])) row_origin.resize(std::size_t(ctx.row_lookup[c]) + 1);
+				row_origin[std::size_t(ctx.row_lookup[c])] = {u32(smp), c - ctx.copy_begin[smp]};
+			}
+
+	// The merge stage.  Per chunk, in file order: (A) the records go into the builder one by one -- nodes, edges, targets: cheap --
+	// and what their genotypes will need is kept (graph_builder::snapshot_record); (B) the chunk's genotypes are applied, every
+	// chromosome copy's in record order, by a few helper threads that own disjoint groups of 64 copies each (at population scale
+	// the genotypes ARE the merge stage: config 3 has 360 M of them, 2 s of one thread); overlaps are reported afterwards in the
+	// reference's order (record by record, copy by copy).
+	struct apply_pool {
+		std::vector<std::thread> threads;
+		std::mutex mutex;
+		std::condition_variable cv_start, cv_done;
+		u64 generation{};
+		unsigned remaining{};
+		bool quit{};
+		std::function<void(unsigned)> job;
+		std::exception_ptr error;
+		explicit apply_pool(unsigned n)
+		{
+			for (unsigned h(0); h < n; ++h) threads.emplace_back([this, h] {
+				u64 seen(0);
+				for (;;) {
+					{
+						std::unique_lock<std::mutex> lock(mutex);
+						cv_start.wait(lock, [&] { return quit || generation != seen; });
+						if (quit) return;
+						seen = generation;
+					}
+					try { job(h); }
+					catch (...) { std::lock_guard<std::mutex> lock(mutex); if (!error) error = std::current_exception(); }
+					{
+						std::lock_guard<std::mutex> lock(mutex);
+						--remaining;
+					}
+					cv_done.notify_all();
+				}
+			});
+		}
+		~apply_pool()
+		{
+			{ std::lock_guard<std::mutex> lock(mutex); quit = true; }
+			cv_start.notify_all();
+			for (auto &t : threads) t.join();
+		}
+		void run(std::function<void(unsigned)> f)
+		{
+			std::unique_lock<std::mutex> lock(mutex);
+			job = std::move(f);
+			remaining = unsigned(threads.size());
+			++generation;
+			cv_start.notify_all();
+			cv_done.wait(lock, [&] { return 0 == remaining; });
+			if (error) { auto const e(error); error = nullptr; std::rethrow_exception(e); }
+		}
+	};
+	u64 const n_copy_rows(builder.tracked_copies());
+	unsigned const n_helpers(threads > 1 ? unsigned(std::min<u64>(std::min(threads, 8u), std::max<u64>(1, (n_copy_rows + 63) / 64))) : 1u);
+	std::unique_ptr<apply_pool> helpers(n_helpers > 1 ? new apply_pool(n_helpers) : nullptr);
+	u64 const rows_per_helper((((n_copy_rows + 63) / 64 + n_helpers - 1) / n_helpers) * 64);   // whole 64-copy groups: disjoint words of the bit matrix
+
+	std::vector<graph_builder::record_snapshot> snaps;
+	std::vector<u64> edge_slots;
+	std::vector<std::vector<u64>> overlaps_found(n_helpers);         // per helper: indices into chunk.genos
+
+	// V2M_READER_TIMING=1: where the merge stage's time went (waiting for parsed chunks / records into the builder / genotypes), to stderr
+	bool const timing(nullptr != std::getenv("V2M_READER_TIMING"));
+	double t_wait(0), t_records(0), t_genotypes(0);
+	auto const now([] { return std::chrono::steady_clock::now(); });
+	auto const since([&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); });
+	struct report_timing {
+		bool on; double const &w, &r, &g;
+		~report_timing() { if (on) std::fprintf(stderr, "[vcf reader] merge stage: %.3f s waiting for parsed chunks, %.3f s records into the builder, %.3f s genotypes\n", w, r, g); }
+	} const report{timing, t_wait, t_records, t_genotypes};
 
 	for (std::size_t ci(0); ci < n_chunks; ++ci) {
+		auto const t0(now());
 		if (threads > 1) {
 			std::unique_lock<std::mutex> lock(mutex);
 			cv_ready.wait(lock, [&] { return 0 != ready[ci]; });
 		} else {
 			parse_chunk(text.substr(ranges[ci].first, ranges[ci].second - ranges[ci].first), ctx, chunks[ci]);
 		}
+		t_wait += since(t0);
+		auto const t1(now());
 		parsed_chunk &chunk(chunks[ci]);
-		// records parsed before an error are still merged first, so errors surface in file order
+		// (A) records parsed before an error are still merged first, so errors surface in file order
+		snaps.clear();
+		edge_slots.clear();
+		parsed_record const *stopped_at(nullptr);
 		for (auto const &rec : chunk.records) {
 			++stats.handled_variants;
-			cur_lineno = lineno_base + rec.line_in_chunk;
-			cur_id = rec.id;
 			u64 const this_var(var_idx + rec.data_line_in_chunk);
 			// the reference's order: the position check (variant_graph.cc:293-297) comes before the REF comparison (:307-314)
 			if (builder.would_go_back(rec.ref_pos))
 				throw std::runtime_error("variant " + std::to_string(this_var) + " has non-increasing position");
 			{                                                                            // :307-314
 				std::string_view const expected(rec.ref_pos <= ref_sv.size() ? ref_sv.substr(rec.ref_pos, rec.ref.size()) : std::string_view{});
-				if (rec.ref != expected && !delegate.ref_column_mismatch(this_var, rec.ref_pos, rec.ref, expected)) {
-					// the reference stops parsing here (variant_graph.cc:312-313) and still adds the sink node (:437-451); the
-					// records of other chromosomes it had passed by then have been counted (:203-207)
-					stats.chr_id_mismatches += rec.chr_mismatches_before;
-					builder.add_record_node_only(rec.ref_pos);
-					builder.finish(ref_seq.size());
-					return;
-				}
+				if (rec.ref != expected && !delegate.ref_column_mismatch(this_var, rec.ref_pos, rec.ref, expected)) { stopped_at = &rec; break; }
 			}
 			if (!builder.add_record(rec.ref_pos, rec.ref.size(), chunk.alts.data() + rec.alt_begin, rec.n_alts))
 				throw std::runtime_error("variant " + std::to_string(this_var) + " has non-increasing position");   // :293-297
-			for (u64 k(rec.geno_begin); k < rec.geno_end; ++k) {
-				auto const &gt(chunk.genos[k]);
-				cur_sample = gt.sample; cur_copy = gt.copy;
-				builder.set_genotype(gt.row, gt.alt_number);
+			snaps.emplace_back();
+			builder.snapshot_record(snaps.back(), edge_slots);
+		}
+		t_records += since(t1);
+		auto const t2(now());
+		// (B) the genotypes of the records that went in
+		{
+			auto const apply([&](unsigned h) {
+				auto const usable([&](parsed_genotype const &gt, graph_builder::record_snapshot const &snap, u64 &edge) {
+					if (0 == gt.alt_number || snap.n_alts < gt.alt_number) return false;             // (set_genotype's own checks)
+					edge = edge_slots[snap.first_edge_slot + gt.alt_number - 1];
+					return kEdgeMax != edge;                                                         // :401-403
+				});
+				// the path bits, by records: a run of records is a run of columns of the matrix, which nobody else writes
+				{
+					std::size_t const r_lo(snaps.size() * h / n_helpers), r_hi(snaps.size() * (h + 1) / n_helpers);
+					for (std::size_t r(r_lo); r < r_hi; ++r) {
+						auto const &rec(chunk.records[r]);
+						for (u64 k(rec.geno_begin); k < rec.geno_end; ++k) {
+							u64 edge;
+							if (usable(chunk.genos[k], snaps[r], edge)) builder.set_path_bit(chunk.genos[k].row, edge);
+						}
+					}
+				}
+				// where every copy is after each record, by copies (a record's genotypes are in sample order = ascending rows: the
+				// helper's rows are one run of them)
+				u64 const row_lo(u64(h) * rows_per_helper), row_hi(n_helpers > 1 ? row_lo + rows_per_helper : UINT64_MAX);
+				auto &found(overlaps_found[h]);
+				found.clear();
+				for (std::size_t r(0); r < snaps.size(); ++r) {
+					auto const &rec(chunk.records[r]);
+					u64 k(rec.geno_begin);
+					if (n_helpers > 1)
+						k = u64(std::lower_bound(chunk.genos.begin() + std::ptrdiff_t(rec.geno_begin), chunk.genos.begin() + std::ptrdiff_t(rec.geno_end), row_lo,
+							[](parsed_genotype const &g, u64 lo) { return g.row < lo; }) - chunk.genos.begin());
+					for (; k < rec.geno_end; ++k) {
+						auto const &gt(chunk.genos[k]);
+						if (gt.row >= row_hi) break;
+						u64 edge;
+						if (usable(gt, snaps[r], edge) && builder.move_copy(gt.row, snaps[r])) found.push_back(k);
+					}
+				}
+			});
+			u64 const n_genos(snaps.empty() ? 0 : chunk.records[snaps.size() - 1].geno_end);
+			if (helpers && n_genos >= 32768) helpers->run(apply);
+			else {
+				// (few genotypes: this thread, as every "helper" in turn -- the row ranges keep the per-copy order either way)
+				std::vector<u64> all;
+				for (unsigned h(0); h < n_helpers; ++h) { apply(h); all.insert(all.end(), overlaps_found[h].begin(), overlaps_found[h].end()); overlaps_found[h].clear(); }
+				overlaps_found[0].swap(all);
 			}
+			// overlaps in the reference's order: genotypes are stored record by record, copy by copy (variant_graph.cc:379-425)
+			std::vector<u64> order;
+			for (auto const &found : overlaps_found) order.insert(order.end(), found.begin(), found.end());
+			std::sort(order.begin(), order.end());
+			std::size_t r(0);
+			for (u64 const k : order) {
+				while (chunk.records[r].geno_end <= k) ++r;
+				auto const &gt(chunk.genos[k]);
+				delegate.report_overlapping_alternative(lineno_base + chunk.records[r].line_in_chunk, snaps[r].ref_pos, chunk.records[r].id, vcf_sample_names[row_origin[gt.row].first], row_origin[gt.row].second, gt.alt_number);
+			}
+		}
+		t_genotypes += since(t2);
+		if (stopped_at) {
+			// the reference stops parsing here (variant_graph.cc:312-313) and still adds the sink node (:437-451); the
+			// records of other chromosomes it had passed by then have been counted (:203-207)
+			stats.chr_id_mismatches += stopped_at->chr_mismatches_before;
+			builder.add_record_node_only(stopped_at->ref_pos);
+			builder.finish(ref_seq.size());
+			return;
 		}
 		if (!chunk.error.empty()) bad(lineno_base + chunk.error_line, chunk.error.c_str());
 		stats.chr_id_mismatches += chunk.chr_mismatches;
 		lineno_base += chunk.n_lines;
 		var_idx += chunk.n_data_lines;
 		parsed_chunk().records.swap(chunk.records);   // release the chunk's memory
-		std::vector<parsed_genotype>().swap(chunk.genos);
 		std::vector<alt_allele>().swap(chunk.alts);
 		if (threads > 1) {
-			{ std::lock_guard<std::mutex> lock(mutex); consumed = ci + 1; }
+			{
+				std::lock_guard<std::mutex> lock(mutex);
+				consumed = ci + 1;
+				chunk.genos.clear();
+				spare_genos.emplace_back();
+				spare_genos.back().swap(chunk.genos);
+			}
 			cv_window.notify_all();
 		}
+		else std::vector<parsed_genotype>().swap(chunk.genos);
 	}
 	builder.finish(ref_seq.size());                                                      // :437-451
 }
