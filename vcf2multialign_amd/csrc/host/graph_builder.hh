@@ -63,43 +63,6 @@ public:
 	// still inside an earlier ALT (variant_graph.cc:399-424 -- the bit is set even then).
 	void set_genotype(u32 copy_row, u32 alt_number);
 
-	// The same for many records at once and on several threads (the VCF reader's merge stage: at population scale the genotypes,
-	// hundreds of millions of them, are all that stage has to do).  After add_record() the caller keeps what set_genotype() would
-	// have looked up -- snapshot_record() -- and later hands the genotypes of all those records to apply_genotype(), every
-	// chromosome copy's in record order and every copy by ONE thread; copies of different 64-row groups may go to different
-	// threads (the per-copy state and the words of the bit matrix they touch are disjoint; see move_copy / set_path_bit below).  No add_record() may run meanwhile
-	// (it can grow the matrix).  apply_genotype() returns true when the copy was still inside an earlier ALT: the overlap that
-	// set_genotype() reports through the callback is then the caller's to report (variant_graph.cc:408-418).
-	struct record_snapshot {
-		u64 ref_pos{}, target_ref_pos{};
-		u32 first_edge_slot{}, n_alts{};    // the record's ALT -> edge table: n_alts entries of the side array from first_edge_slot on
-	};
-	void snapshot_record(record_snapshot &rec, std::vector<u64> &edge_slots) const
-	{
-		rec.ref_pos = m_cur_ref_pos;
-		rec.target_ref_pos = m_current_edge_targets.empty() ? 0 : m_current_edge_targets.front();   // (one target per record: ref_pos + the REF allele's length)
-		rec.first_edge_slot = u32(edge_slots.size());
-		rec.n_alts = u32(m_edges_by_alt.size());
-		edge_slots.insert(edge_slots.end(), m_edges_by_alt.begin(), m_edges_by_alt.end());
-	}
-	// The two halves of it, for callers that split the work differently: the per-copy half (ordered per copy: by copy ranges) and
-	// the path bit (any order: by records, i.e. by columns of the matrix -- threads that own copy ranges would share every cache
-	// line of every column with their neighbours).
-	bool move_copy(u32 copy_row, record_snapshot const &rec)
-	{
-		bool const overlaps(rec.ref_pos < m_target_ref_pos_by_copy[copy_row]);                      // :408-418
-		m_target_ref_pos_by_copy[copy_row] = rec.target_ref_pos;                                    // :422-423
-		return overlaps;
-	}
-	void set_path_bit(u32 copy_row, u64 edge) { m_graph.paths_by_edge_and_chrom_copy.set(copy_row, edge); }   // :424
-	bool apply_genotype(u32 copy_row, u64 edge, record_snapshot const &rec)
-	{
-		bool const overlaps(move_copy(copy_row, rec));
-		set_path_bit(copy_row, edge);
-		return overlaps;
-	}
-	u64 tracked_copies() const { return m_target_ref_pos_by_copy.size(); }
-
 	// Sink node and final column count (variant_graph.cc:437-451).  The transpose that follows in the
 	// reference (:453) is NOT done here: it is the GPU's job (gpu_path.hh: transpose_paths()).
 	void finish(u64 ref_length);

@@ -99,7 +99,17 @@ struct field_cursor {
 
 // ---- record parsing (runs on worker threads) ------------------------------------------------------------------
 
-struct parsed_genotype { u32 row, alt_number; };   // (which sample and copy a row is comes from the context when an overlap is reported: 8 bytes x 360 M genotypes at config 3)
+// What a worker leaves behind for a chunk.  Besides the records themselves, everything their genotypes amount to (at population
+// scale the genotypes ARE the work: config 3 has 360 M of them), so that the one thread that merges chunks in file order never
+// looks at a genotype:
+//   - the path bits, as the chunk's own slice of paths_by_edge_and_chrom_copy: one column per ALT that becomes an edge (the
+//     builder numbers the edges of consecutive records, and of a record's ALTs, consecutively: variant_graph.cc:328-364), in the
+//     matrix's own layout, so merging them is one memcpy;
+//   - per chromosome copy, its first ALT in the chunk (record, allele) and the reference position its last one reaches
+//     (variant_graph.cc:422-423): what the overlap check (:408-418) of the NEXT chunk's first ALT of that copy needs, and what
+//     this chunk's needs from the previous ones;
+//   - the overlaps that lie inside the chunk (a copy's second, third, ... ALT here), in the reference's order.
+struct chunk_overlap { u32 record, row, alt_number; };               // record = index in the chunk
 
 struct parsed_record {
 	u64 line_in_chunk;        // 1-based within the chunk
@@ -107,14 +117,21 @@ struct parsed_record {
 	u64 ref_pos;
 	std::string_view id, ref;
 	u32 alt_begin, n_alts;
-	u64 geno_begin, geno_end;
+	u64 first_column;         // columns of the chunk's bit slice before this record's
+	u64 overlap_begin;        // overlaps inside the chunk before this record's
 	u64 chr_mismatches_before;   // records of other chromosomes seen in the chunk before this one
 };
+
+constexpr u32 kNoRecord = UINT32_MAX;
 
 struct parsed_chunk {
 	std::vector<parsed_record> records;
 	std::vector<alt_allele> alts;
-	std::vector<parsed_genotype> genos;
+	std::vector<u64> bits;                      // [columns][words per column]
+	u64 n_columns{};
+	std::vector<u32> first_record, first_alt;   // per chromosome copy (row); kNoRecord: no ALT in this chunk
+	std::vector<u64> last_target;               // per row, valid where first_record is
+	std::vector<chunk_overlap> overlaps;
 	u64 n_lines{}, n_data_lines{}, chr_mismatches{};
 	std::string error;        // first error, with its chunk-relative line in error_line
 	u64 error_line{};
@@ -127,6 +144,8 @@ struct parse_context {
 	// copies of sample s are row_lookup[copy_begin[s] .. copy_begin[s + 1])
 	std::vector<std::int32_t> row_lookup;
 	std::vector<u32> copy_begin;
+	u64 n_rows{};               // included chromosome copies
+	u64 words_per_column{};     // of paths_by_edge_and_chrom_copy (its rows are padded)
 };
 
 struct chunk_error { u64 line; char const *what; };
@@ -139,6 +158,15 @@ static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "the column fast path c
 void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &out)
 {
 	std::size_t pos(0);
+	out.bits.clear();
+	out.n_columns = 0;
+	out.overlaps.clear();
+	out.first_record.assign(ctx.n_rows, kNoRecord);
+	out.first_alt.assign(ctx.n_rows, 0);
+	out.last_target.assign(ctx.n_rows, 0);
+	std::vector<u64> alt_column;                 // of the record at hand: ALT -> column of the chunk's slice, or UINT64_MAX (no edge)
+	u64 columns_before_record(0);
+	std::size_t overlaps_before_record(0);
 	try {
 		while (pos < text.size()) {
 			std::size_t eol(text.find('\n', pos));
@@ -181,9 +209,16 @@ void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &
 				for (std::string_view a; ac.next(a);) out.alts.push_back({classify_alt(a), a});
 			}
 			rec.n_alts = u32(out.alts.size()) - rec.alt_begin;
+			// the ALTs that become edges get the chunk's next columns, in ALT order (variant_graph.cc:328-364)
+			rec.first_column = columns_before_record = out.n_columns;
+			rec.overlap_begin = overlaps_before_record = out.overlaps.size();
+			alt_column.assign(rec.n_alts, UINT64_MAX);
+			for (u32 a(0); a < rec.n_alts; ++a) if (alt_kind::unhandled != out.alts[rec.alt_begin + a].kind) alt_column[a] = out.n_columns++;
+			out.bits.resize(out.n_columns * ctx.words_per_column, 0);
+			u32 const rec_index(u32(out.records.size()));
+			u64 const target_ref_pos(rec.ref_pos + rec.ref.size());                       // :333
 
-			// genotypes of the included copies (:379-425); allele 0 and '.' are not recorded (:393-397)
-			rec.geno_begin = out.genos.size();
+			// genotypes of the included copies (:379-425); allele 0 and '.' change nothing (:393-397)
 			std::size_t sample(0);
 			for (std::string_view field; ; ++sample) {
 				// Most of a population-scale VCF is "0|0\t": both copies on the reference allele, nothing to record (:393-397).  Runs of
@@ -224,7 +259,13 @@ void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &
 								for (char const c : tok) { if (c < '0' || '9' < c) throw chunk_error{out.n_lines, "bad GT allele"}; allele = 10 * allele + u32(c - '0'); }
 								if (allele) {
 									if (allele > rec.n_alts) throw chunk_error{out.n_lines, "GT allele exceeds the ALT count"};
-									out.genos.push_back({u32(row), allele});
+									u64 const column(alt_column[allele - 1]);
+									if (UINT64_MAX != column) {                                   // (an ALT without an edge: :401-403)
+										out.bits[column * ctx.words_per_column + (u32(row) >> 6)] |= u64(1) << (u32(row) & 63);   // :424
+										if (kNoRecord == out.first_record[row]) { out.first_record[row] = rec_index; out.first_alt[row] = allele; }
+										else if (rec.ref_pos < out.last_target[row]) out.overlaps.push_back({rec_index, u32(row), allele});   // :408-418
+										out.last_target[row] = target_ref_pos;                    // :422-423
+									}
 								}
 							}
 						}
@@ -236,12 +277,15 @@ void parse_chunk(std::string_view text, parse_context const &ctx, parsed_chunk &
 					if (ctx.row_lookup[c_begin + c] >= 0) throw chunk_error{out.n_lines, "GT has fewer alleles than in the first record"};
 			}
 			if (sample != ctx.n_samples) throw chunk_error{out.n_lines, "sample column count differs from the header"};
-			rec.geno_end = out.genos.size();
 			out.records.push_back(rec);
 		}
 	} catch (chunk_error const &e) {
 		out.error = e.what;
 		out.error_line = e.line;
+		// what the failing record had claimed before it failed (the records before it are still merged; the per-copy state it may
+		// have touched no longer matters: the error ends the build right after them)
+		out.n_columns = columns_before_record;
+		out.overlaps.resize(overlaps_before_record);
 	}
 }
 
@@ -337,6 +381,8 @@ void build_variant_graph(
 			}
 			if (s != ctx.n_samples) bad(lineno, "sample column count differs from the header");
 			builder.begin(std::move(names), ploidies);
+			ctx.n_rows = row;
+			ctx.words_per_column = graph.paths_by_edge_and_chrom_copy.words_per_column();
 			have_first = true;
 		}
 	}
@@ -383,7 +429,7 @@ void build_variant_graph(
 	std::size_t next_chunk(0), consumed(0);
 	std::size_t const window(std::max<std::size_t>(2, 2 * threads));
 	bool abort_workers(false);
-	std::vector<std::vector<parsed_genotype>> spare_genos;           // (under `mutex`)
+	std::vector<parsed_chunk> spare_chunks;                           // (under `mutex`) consumed chunks: their vectors' pages are there already
 
 	auto const worker([&] {
 		for (;;) {
@@ -395,10 +441,10 @@ void build_variant_graph(
 				idx = next_chunk++;
 			}
 			{
-				// (a genotype list that an earlier chunk has been through: its pages are there already; fresh ones of this size
-				// come from mmap every time and cost a fault per page)
+				// (the vectors of a chunk that has been merged: their pages are there already; fresh ones of this size come from
+				// mmap every time and cost a fault per page)
 				std::lock_guard<std::mutex> lock(mutex);
-				if (!spare_genos.empty()) { chunks[idx].genos.swap(spare_genos.back()); spare_genos.pop_back(); }
+				if (!spare_chunks.empty()) { chunks[idx] = std::move(spare_chunks.back()); spare_chunks.pop_back(); }
 			}
 			parse_chunk(text.substr(ranges[idx].first, ranges[idx].second - ranges[idx].first), ctx, chunks[idx]);
 			{
@@ -432,75 +478,21 @@ void build_variant_graph(
 				row_origin[std::size_t(ctx.row_lookup[c])] = {u32(smp), c - ctx.copy_begin[smp]};
 			}
 
-	// The merge stage.  Per chunk, in file order: (A) the records go into the builder one by one -- nodes, edges, targets: cheap --
-	// and what their genotypes will need is kept (graph_builder::snapshot_record); (B) the chunk's genotypes are applied, every
-	// chromosome copy's in record order, by a few helper threads that own disjoint groups of 64 copies each (at population scale
-	// the genotypes ARE the merge stage: config 3 has 360 M of them, 2 s of one thread); overlaps are reported afterwards in the
-	// reference's order (record by record, copy by copy).
-	struct apply_pool {
-		std::vector<std::thread> threads;
-		std::mutex mutex;
-		std::condition_variable cv_start, cv_done;
-		u64 generation{};
-		unsigned remaining{};
-		bool quit{};
-		std::function<void(unsigned)> job;
-		std::exception_ptr error;
-		explicit apply_pool(unsigned n)
-		{
-			for (unsigned h(0); h < n; ++h) threads.emplace_back([this, h] {
-				u64 seen(0);
-				for (;;) {
-					{
-						std::unique_lock<std::mutex> lock(mutex);
-						cv_start.wait(lock, [&] { return quit || generation != seen; });
-						if (quit) return;
-						seen = generation;
-					}
-					try { job(h); }
-					catch (...) { std::lock_guard<std::mutex> lock(mutex); if (!error) error = std::current_exception(); }
-					{
-						std::lock_guard<std::mutex> lock(mutex);
-						--remaining;
-					}
-					cv_done.notify_all();
-				}
-			});
-		}
-		~apply_pool()
-		{
-			{ std::lock_guard<std::mutex> lock(mutex); quit = true; }
-			cv_start.notify_all();
-			for (auto &t : threads) t.join();
-		}
-		void run(std::function<void(unsigned)> f)
-		{
-			std::unique_lock<std::mutex> lock(mutex);
-			job = std::move(f);
-			remaining = unsigned(threads.size());
-			++generation;
-			cv_start.notify_all();
-			cv_done.wait(lock, [&] { return 0 == remaining; });
-			if (error) { auto const e(error); error = nullptr; std::rethrow_exception(e); }
-		}
-	};
-	u64 const n_copy_rows(builder.tracked_copies());
-	unsigned const n_helpers(threads > 1 ? unsigned(std::min<u64>(std::min(threads, 8u), std::max<u64>(1, (n_copy_rows + 63) / 64))) : 1u);
-	std::unique_ptr<apply_pool> helpers(n_helpers > 1 ? new apply_pool(n_helpers) : nullptr);
-	u64 const rows_per_helper((((n_copy_rows + 63) / 64 + n_helpers - 1) / n_helpers) * 64);   // whole 64-copy groups: disjoint words of the bit matrix
+	// The merge stage.  Per chunk, in file order: the records go into the builder one by one -- nodes, edges, targets: cheap --,
+	// the chunk's slice of the path matrix is copied into place, and every chromosome copy's first ALT of the chunk is checked
+	// against where the copy's last ALT before the chunk reached (the overlap check, variant_graph.cc:408-418, across the chunk
+	// boundary; inside the chunk the parser has made it).  Overlaps are reported in the reference's order: record by record, copy by copy.
+	std::vector<u64> reaches(ctx.n_rows, 0);                          // per copy: target_ref_positions_by_chrom_copy (:422-423)
+	std::vector<chunk_overlap> reported;
 
-	std::vector<graph_builder::record_snapshot> snaps;
-	std::vector<u64> edge_slots;
-	std::vector<std::vector<u64>> overlaps_found(n_helpers);         // per helper: indices into chunk.genos
-
-	// V2M_READER_TIMING=1: where the merge stage's time went (waiting for parsed chunks / records into the builder / genotypes), to stderr
+	// V2M_READER_TIMING=1: where the merge stage's time went (waiting for parsed chunks / records into the builder / bits and overlaps), to stderr
 	bool const timing(nullptr != std::getenv("V2M_READER_TIMING"));
 	double t_wait(0), t_records(0), t_genotypes(0);
 	auto const now([] { return std::chrono::steady_clock::now(); });
 	auto const since([&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double>(now() - t).count(); });
 	struct report_timing {
 		bool on; double const &w, &r, &g;
-		~report_timing() { if (on) std::fprintf(stderr, "[vcf reader] merge stage: %.3f s waiting for parsed chunks, %.3f s records into the builder, %.3f s genotypes\n", w, r, g); }
+		~report_timing() { if (on) std::fprintf(stderr, "[vcf reader] merge stage: %.3f s waiting for parsed chunks, %.3f s records into the builder, %.3f s path bits and overlaps\n", w, r, g); }
 	} const report{timing, t_wait, t_records, t_genotypes};
 
 	for (std::size_t ci(0); ci < n_chunks; ++ci) {
@@ -514,9 +506,9 @@ void build_variant_graph(
 		t_wait += since(t0);
 		auto const t1(now());
 		parsed_chunk &chunk(chunks[ci]);
-		// (A) records parsed before an error are still merged first, so errors surface in file order
-		snaps.clear();
-		edge_slots.clear();
+		// records parsed before an error are still merged first, so errors surface in file order
+		u64 const first_edge(graph.edge_count());
+		std::size_t n_merged(0);
 		parsed_record const *stopped_at(nullptr);
 		for (auto const &rec : chunk.records) {
 			++stats.handled_variants;
@@ -530,67 +522,36 @@ void build_variant_graph(
 			}
 			if (!builder.add_record(rec.ref_pos, rec.ref.size(), chunk.alts.data() + rec.alt_begin, rec.n_alts))
 				throw std::runtime_error("variant " + std::to_string(this_var) + " has non-increasing position");   // :293-297
-			snaps.emplace_back();
-			builder.snapshot_record(snaps.back(), edge_slots);
+			++n_merged;
 		}
 		t_records += since(t1);
 		auto const t2(now());
-		// (B) the genotypes of the records that went in
 		{
-			auto const apply([&](unsigned h) {
-				auto const usable([&](parsed_genotype const &gt, graph_builder::record_snapshot const &snap, u64 &edge) {
-					if (0 == gt.alt_number || snap.n_alts < gt.alt_number) return false;             // (set_genotype's own checks)
-					edge = edge_slots[snap.first_edge_slot + gt.alt_number - 1];
-					return kEdgeMax != edge;                                                         // :401-403
-				});
-				// the path bits, by records: a run of records is a run of columns of the matrix, which nobody else writes
-				{
-					std::size_t const r_lo(snaps.size() * h / n_helpers), r_hi(snaps.size() * (h + 1) / n_helpers);
-					for (std::size_t r(r_lo); r < r_hi; ++r) {
-						auto const &rec(chunk.records[r]);
-						for (u64 k(rec.geno_begin); k < rec.geno_end; ++k) {
-							u64 edge;
-							if (usable(chunk.genos[k], snaps[r], edge)) builder.set_path_bit(chunk.genos[k].row, edge);
-						}
-					}
-				}
-				// where every copy is after each record, by copies (a record's genotypes are in sample order = ascending rows: the
-				// helper's rows are one run of them)
-				u64 const row_lo(u64(h) * rows_per_helper), row_hi(n_helpers > 1 ? row_lo + rows_per_helper : UINT64_MAX);
-				auto &found(overlaps_found[h]);
-				found.clear();
-				for (std::size_t r(0); r < snaps.size(); ++r) {
-					auto const &rec(chunk.records[r]);
-					u64 k(rec.geno_begin);
-					if (n_helpers > 1)
-						k = u64(std::lower_bound(chunk.genos.begin() + std::ptrdiff_t(rec.geno_begin), chunk.genos.begin() + std::ptrdiff_t(rec.geno_end), row_lo,
-							[](parsed_genotype const &g, u64 lo) { return g.row < lo; }) - chunk.genos.begin());
-					for (; k < rec.geno_end; ++k) {
-						auto const &gt(chunk.genos[k]);
-						if (gt.row >= row_hi) break;
-						u64 edge;
-						if (usable(gt, snaps[r], edge) && builder.move_copy(gt.row, snaps[r])) found.push_back(k);
-					}
-				}
-			});
-			u64 const n_genos(snaps.empty() ? 0 : chunk.records[snaps.size() - 1].geno_end);
-			if (helpers && n_genos >= 32768) helpers->run(apply);
-			else {
-				// (few genotypes: this thread, as every "helper" in turn -- the row ranges keep the per-copy order either way)
-				std::vector<u64> all;
-				for (unsigned h(0); h < n_helpers; ++h) { apply(h); all.insert(all.end(), overlaps_found[h].begin(), overlaps_found[h].end()); overlaps_found[h].clear(); }
-				overlaps_found[0].swap(all);
+			// the merged records' columns of the chunk's slice (all of them unless the build stops inside the chunk)
+			u64 const n_columns(n_merged < chunk.records.size() ? chunk.records[n_merged].first_column : chunk.n_columns);
+			if (graph.edge_count() - first_edge != n_columns) throw std::logic_error("VCF reader: the builder made other edges than the parser counted");
+			auto &m(graph.paths_by_edge_and_chrom_copy);
+			if (n_columns) {
+				if (m.cols < first_edge + n_columns || m.words_per_column() != ctx.words_per_column) throw std::logic_error("VCF reader: the path matrix is not what the parser filled its slice for");
+				std::memcpy(m.words.data() + first_edge * ctx.words_per_column, chunk.bits.data(), n_columns * ctx.words_per_column * sizeof(u64));
 			}
-			// overlaps in the reference's order: genotypes are stored record by record, copy by copy (variant_graph.cc:379-425)
-			std::vector<u64> order;
-			for (auto const &found : overlaps_found) order.insert(order.end(), found.begin(), found.end());
-			std::sort(order.begin(), order.end());
-			std::size_t r(0);
-			for (u64 const k : order) {
-				while (chunk.records[r].geno_end <= k) ++r;
-				auto const &gt(chunk.genos[k]);
-				delegate.report_overlapping_alternative(lineno_base + chunk.records[r].line_in_chunk, snaps[r].ref_pos, chunk.records[r].id, vcf_sample_names[row_origin[gt.row].first], row_origin[gt.row].second, gt.alt_number);
+			// overlaps: the parser's (inside the chunk) and, here, every copy's first ALT of the chunk against the chunks before
+			u64 const n_inside(n_merged < chunk.records.size() ? chunk.records[n_merged].overlap_begin : chunk.overlaps.size());
+			reported.assign(chunk.overlaps.begin(), chunk.overlaps.begin() + std::ptrdiff_t(n_inside));
+			for (u64 row(0); row < ctx.n_rows; ++row) {
+				u32 const r(chunk.first_record[row]);
+				if (kNoRecord == r || r >= n_merged) continue;
+				if (chunk.records[r].ref_pos < reaches[row]) reported.push_back({r, u32(row), chunk.first_alt[row]});
+				reaches[row] = chunk.last_target[row];
 			}
+			if (reported.size() > n_inside) {
+				auto const before([](chunk_overlap const &a, chunk_overlap const &b) { return a.record != b.record ? a.record < b.record : a.row < b.row; });
+				std::sort(reported.begin() + std::ptrdiff_t(n_inside), reported.end(), before);
+				std::inplace_merge(reported.begin(), reported.begin() + std::ptrdiff_t(n_inside), reported.end(), [](chunk_overlap const &a, chunk_overlap const &b) { return a.record != b.record ? a.record < b.record : a.row < b.row; });
+			}
+			for (auto const &o : reported)
+				delegate.report_overlapping_alternative(lineno_base + chunk.records[o.record].line_in_chunk, chunk.records[o.record].ref_pos, chunk.records[o.record].id,
+					vcf_sample_names[row_origin[o.row].first], row_origin[o.row].second, o.alt_number);
 		}
 		t_genotypes += since(t2);
 		if (stopped_at) {
@@ -605,19 +566,17 @@ void build_variant_graph(
 		stats.chr_id_mismatches += chunk.chr_mismatches;
 		lineno_base += chunk.n_lines;
 		var_idx += chunk.n_data_lines;
-		parsed_chunk().records.swap(chunk.records);   // release the chunk's memory
-		std::vector<alt_allele>().swap(chunk.alts);
 		if (threads > 1) {
 			{
 				std::lock_guard<std::mutex> lock(mutex);
 				consumed = ci + 1;
-				chunk.genos.clear();
-				spare_genos.emplace_back();
-				spare_genos.back().swap(chunk.genos);
+				chunk.records.clear(); chunk.alts.clear(); chunk.n_lines = chunk.n_data_lines = chunk.chr_mismatches = 0;
+				spare_chunks.emplace_back(std::move(chunk));
+				chunk = parsed_chunk{};
 			}
 			cv_window.notify_all();
 		}
-		else std::vector<parsed_genotype>().swap(chunk.genos);
+		else chunk = parsed_chunk{};
 	}
 	builder.finish(ref_seq.size());                                                      // :437-451
 }
