@@ -14,11 +14,20 @@ Haplotypes shard across ranks in blocks of 8 chromosome copies (whole bytes of t
 reference and graph replicated; there is no collective on the data path.  The total work is the
 named config's and is fixed as N grows, hence "scaling": "strong".
 
-Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).  Besides the contract's fields it carries
-`roofline` (the dominant kernel, splice_aligned_kernel), `roofline_transpose` (the transpose of a source at the reference's
-own 64-bit padding into the library's path matrix, inside the timed region; the ABI's dense form, forward and inverse, and a
-1024-bit-padded matrix measured after it), `unaligned`
-(a second, separately timed leg: the same rows without '-' padding), `parity` and `cpu_baseline`.
+What the ranks need from each other is a start barrier, the maximum of their times and the AND of their parity flags -- no
+data.  Typed as `python bench.py --gpus N` the parent process is that hub itself: it starts the N ranks as children and
+serves barriers and one gather over their pipes (no torch.distributed, no RCCL, nothing that could fail to initialise).
+Under `torch.distributed.run` the same three operations go through a torch.distributed group (--dist-backend, default gloo:
+CPU tensors only; `nccl` = RCCL is accepted, the data path never touches it either way).
+
+Rank 0 prints ONE JSON line (see README / DESIGN.md for the fields).  `value` is the HBM-resident rate (`residency`: "hbm":
+inputs in HBM, rows written to HBM, nothing crosses PCIe in the timed region); the rate a caller of output_a2m sees, with
+every row crossing the link into a host sink, is the separate `end_to_end` leg.  Besides the contract's fields the line
+carries `roofline` (the dominant kernel, splice_aligned_kernel; at N > 1 the SLOWEST rank's launches), `roofline_transpose`
+(the transpose of a source at the reference's own 64-bit padding into the library's path matrix, inside the timed region; the
+ABI's dense form, forward and inverse, and a 1024-bit-padded matrix measured after it), `unaligned` (a second, separately
+timed leg: the same rows without '-' padding), `end_to_end`, `parity` and -- at every N, timed on rank 0 after the timed
+region -- `cpu_baseline` (and `roofline_transpose.cpu_baseline`).
 """
 
 import argparse
@@ -36,7 +45,20 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
-KERNEL_SOURCES = ("vcf2multialign_amd/csrc/kernels.hpp", "vcf2multialign_amd/csrc/v2m_hip.hip")
+PCIE_PEAK_GBS = 63.0    # MI355X host link: PCIe Gen5 x16, 63 GB/s spec (MI355X_MICROARCH.md "Host link")
+
+
+def _kernel_sources():
+	"""Every file libv2m_hip.so is compiled from: v2m_hip.hip and what it reaches through #include "..." (the build's own
+	dependency list, read off the sources -- vcf2multialign_amd/build.py:include_closure)."""
+	import importlib.util
+	spec = importlib.util.spec_from_file_location("_v2m_build", os.path.join(ROOT, "vcf2multialign_amd", "build.py"))
+	b = importlib.util.module_from_spec(spec)
+	spec.loader.exec_module(b)
+	return tuple(sorted(os.path.relpath(p, ROOT) for p in b.HIP_DEPS))
+
+
+KERNEL_SOURCES = _kernel_sources()
 
 
 def log(*a):
@@ -78,53 +100,155 @@ def _device_bytes(ptr, nbytes):
 	return buf.raw
 
 
+HUB_ENV = "V2M_BENCH_HUB"   # set for the children of `python bench.py --gpus N`: the parent serves barrier / gather over their pipes
+
+
 def launch_ranks(n, argv):
 	"""`python bench.py --gpus N` typed as is (no WORLD_SIZE in the environment): this parent -- which has parsed its arguments
-	and nothing else, no torch import, no HIP call -- starts the N ranks as fresh child processes with the torch.distributed
-	environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT) and waits for them.  Rank 0's single JSON line is
-	relayed on stdout; everything else any rank prints goes to stderr.  Never os.exec*: the children are children."""
-	import socket
+	and nothing else, no torch import, no HIP call -- builds the libraries (in a child), starts the N ranks as fresh child
+	processes (RANK / LOCAL_RANK / WORLD_SIZE as under torch.distributed.run, plus V2M_BENCH_HUB) and is their hub: each rank's
+	real stdout is a pipe to the parent, its stdin a pipe from it.  A rank writes `#B` to enter a barrier and is released by a
+	`go` line once all N have; `#G <json>` contributes to the one gather, whose N objects go to rank 0 as one line; the line
+	rank 0 prints that starts with `{` is the result and is relayed on stdout.  Everything else any rank prints goes to stderr.
+	There is no torch.distributed group and no RCCL on this path.  Never os.exec*: the children are children."""
+	import queue
 	import subprocess
-	with socket.socket() as sock:
-		sock.bind(("127.0.0.1", 0))
-		port = sock.getsockname()[1]
+	import threading
+	if "--hub-selftest" not in argv:
+		rc = subprocess.call([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from vcf2multialign_amd import build; build.build_native()" % ROOT], stdout=sys.stderr)
+		if rc != 0:
+			sys.exit("[bench] building the native libraries failed (exit %d)" % rc)
 	procs = []
 	for r in range(n):
-		env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+		env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+		env[HUB_ENV] = "1"
 		env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-		procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-			stdout=subprocess.PIPE if r == 0 else sys.stderr, stderr=sys.stderr))
-	import threading
-	chunks = []
-	reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
-	reader.start()
-	# a rank that dies leaves the others waiting at a barrier: end them (by their own PIDs) instead of hanging until a timeout
-	while any(p.poll() is None for p in procs):
-		if any(p.poll() not in (None, 0) for p in procs):
-			time.sleep(5.0)
-			for p in procs:
-				if p.poll() is None:
-					p.terminate()
-			break
-		time.sleep(0.2)
+		procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=sys.stderr))
+	events = queue.Queue()
+
+	def pump(r):
+		for raw in procs[r].stdout:
+			events.put((r, raw.decode(errors="replace").rstrip("\n")))
+		events.put((r, None))
+
+	for r in range(n):
+		threading.Thread(target=pump, args=(r,), daemon=True).start()
+
+	def send(r, text):
+		try:
+			procs[r].stdin.write((text + "\n").encode())
+			procs[r].stdin.flush()
+		except (BrokenPipeError, OSError):
+			pass   # the rank is gone: its exit code is reported below
+
+	line, at_barrier, gathered, open_pipes, failed = None, set(), {}, n, False
+	while open_pipes:
+		try:
+			r, msg = events.get(timeout=0.5)
+		except queue.Empty:
+			# a rank that dies leaves the others waiting at a barrier: end them (by their own PIDs) instead of hanging until a timeout
+			if any(p.poll() not in (None, 0) for p in procs):
+				failed = True
+				time.sleep(2.0)
+				for p in procs:
+					if p.poll() is None:
+						p.terminate()
+			continue
+		if msg is None:
+			open_pipes -= 1
+		elif msg == "#B":
+			at_barrier.add(r)
+			if len(at_barrier) == n:
+				at_barrier.clear()
+				for k in range(n):
+					send(k, "go")
+		elif msg.startswith("#G "):
+			gathered[r] = msg[3:]
+			if len(gathered) == n:
+				send(0, "[" + ",".join(gathered[k] for k in range(n)) + "]")
+				gathered = {}
+		elif r == 0 and msg.startswith("{") and line is None:
+			line = msg
+		elif msg.strip():
+			log(msg)
 	codes = [p.wait() for p in procs]
-	reader.join(timeout=30)
-	out0 = b"".join(chunks).decode(errors="replace")
-	line = None
-	for l in out0.splitlines():
-		if l.startswith("{") and line is None:
-			line = l
-		elif l.strip():
-			log(l)
 	bad = [(r, c) for r, c in enumerate(codes) if c != 0]
 	if bad:
 		log("[bench] rank(s) failed: " + ", ".join("rank %d -> exit %d" % rc for rc in bad))
-	if line is not None:
+	if line is not None and not (failed and bad):
 		print(line, flush=True)
 	if bad:
 		sys.exit(bad[0][1] if 0 < bad[0][1] < 256 else 1)
 	if line is None:
 		sys.exit("[bench] rank 0 printed no result line")
+
+
+class SoloHub:
+	"""N = 1: nothing to wait for."""
+	kind = "single process"
+
+	def barrier(self):
+		pass
+
+	def gather(self, obj):
+		return [obj]
+
+	def close(self):
+		pass
+
+
+class PipeHub(SoloHub):
+	"""A rank started by launch_ranks(): barrier and gather through the parent, over this process's own stdin / stdout pipes."""
+	kind = "parent process of `python bench.py --gpus N` over pipes (no torch.distributed, no RCCL)"
+
+	def __init__(self, rank, out):
+		self.rank, self.out = rank, out
+
+	def _say(self, text):
+		self.out.write(text + "\n")
+		self.out.flush()
+
+	def _hear(self):
+		line = sys.stdin.readline()
+		if not line:
+			sys.exit("[bench] rank %d: the parent went away" % self.rank)
+		return line.rstrip("\n")
+
+	def barrier(self):
+		self._say("#B")
+		if self._hear() != "go":
+			sys.exit("[bench] rank %d: unexpected reply at a barrier" % self.rank)
+
+	def gather(self, obj):
+		self._say("#G " + json.dumps(obj))
+		return json.loads(self._hear()) if self.rank == 0 else None
+
+
+class TorchHub(SoloHub):
+	"""Under torch.distributed.run: the same two operations through a torch.distributed group.  gloo (the default) moves CPU
+	objects only; with nccl (= RCCL) the objects travel through tensors on this rank's device."""
+
+	def __init__(self, backend, rank, dev):
+		import torch.distributed as dist
+		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		if backend == "nccl":
+			dist.init_process_group("nccl", device_id=dev)
+		else:
+			dist.init_process_group(backend)
+		self.dist, self.rank = dist, rank
+		self.kind = "torch.distributed (%s) under torch.distributed.run: barrier + all_gather_object of the ranks' figures, no data" % backend
+
+	def barrier(self):
+		self.dist.barrier()
+
+	def gather(self, obj):
+		everyone = [None] * self.dist.get_world_size()
+		self.dist.all_gather_object(everyone, obj)
+		return everyone if self.rank == 0 else None
+
+	def close(self):
+		self.dist.barrier()
+		self.dist.destroy_process_group()
 
 
 def main():
@@ -135,14 +259,17 @@ def main():
 	ap.add_argument("--config", default="config3", help="synthetic workload (vcf2multialign_amd/synth.py CONFIGS)")
 	ap.add_argument("--batch-rows", type=int, default=0, help="rows per splice launch (one device output buffer of this many rows is reused); 0 = as many as fit --batch-gb")
 	ap.add_argument("--batch-gb", type=float, default=64.0, help="size of the reused device output buffer when --batch-rows is 0: launches that write a ~64-GB address range reach the full HBM write rate (DESIGN.md section 4)")
-	ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a one-GPU rehearsal of N > 1)")
+	ap.add_argument("--dist-backend", default="gloo", help="under torch.distributed.run only: the torch.distributed backend of the barrier / gather of figures (gloo: CPU objects; nccl = RCCL).  The data path has no collective; `python bench.py --gpus N` as typed uses neither")
 	ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this HIP device")
 	ap.add_argument("--output-candidates", type=int, default=4, help="device buffers v2m_alloc_output may hold at once to choose the output buffer from (as many as fit are tried; 1 = plain allocation)")
-	ap.add_argument("--cpu-baseline-rows", type=int, default=320, help="haplotypes (plus REF) the CPU oracle is timed on (320 rows of config 3 = 32 Gbases, about 11 s on one core); 0 disables")
+	ap.add_argument("--cpu-baseline-rows", type=int, default=320, help="haplotypes (plus REF) the CPU oracle is timed on, on rank 0 after the timed region at every N (320 rows of config 3 = 32 Gbases, about 11 s on one core); 0 disables")
 	ap.add_argument("--verify-rows", type=int, default=1, help="after timing: rows per batch (every batch) checked against the CPU oracle, plus REF and the last batch's ragged final group; 0 disables")
 	ap.add_argument("--unaligned-rows", type=int, default=256, help="the separately timed --unaligned leg (rank 0, after the main timing) runs on as many rows as the output buffer holds and, beside it, on the first this-many rows; 0 disables")
-	ap.add_argument("--cpu-transpose", type=int, default=1, help="after timing (rank 0, N=1): time the CPU oracle's transpose_matrix on the same matrix and compare it bit for bit with the GPU's dense-form result (config 3: ~8 s); 0 disables")
+	ap.add_argument("--cpu-transpose", type=int, default=1, help="after timing (rank 0, every N): time the CPU oracle's transpose_matrix on rank 0's matrix and compare it bit for bit with the GPU's dense-form result (config 3: ~5 s); 0 disables")
 	ap.add_argument("--transpose-extras", type=int, default=1, help="after timing, also measure the inverse transpose and a 1024-bit-padded matrix (rank 0); 0 disables")
+	ap.add_argument("--e2e-gb", type=float, default=64.0, help="the end-to-end leg (every rank, after the main timing): this many GB of the rank's rows through v2m_splice_rows -- device slots, D2H copies on the copy stream, pinned slots -- into a C sink that checksums every row on the host; 0 disables")
+	ap.add_argument("--e2e-threads", type=int, default=16, help="host threads of the end-to-end leg's checksumming sink (a GPU box gives 16 cores per GPU)")
+	ap.add_argument("--hub-selftest", action="store_true", help="no GPU work: the ranks only exercise the barrier / gather plumbing of their launch form and rank 0 prints what it gathered (CPU test suite)")
 	args = ap.parse_args()
 
 	rank = int(os.environ.get("RANK", "0"))
@@ -158,29 +285,40 @@ def main():
 	result_out = os.fdopen(os.dup(1), "w")
 	os.dup2(2, 1)
 
+	under_parent = os.environ.get(HUB_ENV) == "1"
+	if args.hub_selftest:
+		hub = SoloHub() if world == 1 else PipeHub(rank, result_out) if under_parent else TorchHub(args.dist_backend, rank, None)
+		hub.barrier()
+		t_begin = time.perf_counter()
+		hub.barrier()
+		everyone = hub.gather({"rank": rank, "pid": os.getpid(), "elapsed_s": time.perf_counter() - t_begin})
+		if rank == 0:
+			result_out.write(json.dumps({"hub_selftest": everyone, "ranks_coordinated_by": hub.kind}) + "\n")
+			result_out.flush()
+		hub.close()
+		return
+
 	import torch
-	import torch.distributed as dist
 
 	dev_index = local_rank if args.force_device is None else args.force_device
 	torch.cuda.set_device(dev_index)
 	dev = torch.device("cuda", dev_index)
-	red_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")   # where the timing / parity reductions live
-	if world > 1:
-		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-		if args.dist_backend == "nccl":
-			dist.init_process_group("nccl", device_id=dev)
-		else:
-			dist.init_process_group(args.dist_backend)
+	if world == 1:
+		hub = SoloHub()
+	elif under_parent:
+		hub = PipeHub(rank, result_out)
+	else:
+		hub = TorchHub(args.dist_backend, rank, dev)
 
 	from vcf2multialign_amd import build as _build
-	if local_rank == 0:
-		_build.build_native()   # no-op when the in-tree libraries are newer than their sources (hipcc cross-compiles gfx950)
-	if world > 1:
-		dist.barrier()          # nobody loads the libraries before the (possible) rebuild is over
+	if not under_parent:            # (the parent of `python bench.py --gpus N` has built before it started the ranks)
+		if local_rank == 0:
+			_build.build_native()   # no-op when the in-tree libraries are newer than their sources (hipcc cross-compiles gfx950)
+		hub.barrier()               # nobody loads the libraries before the (possible) rebuild is over
 	import vcf2multialign_amd as v2m
 	from vcf2multialign_amd import _native as N
 	from vcf2multialign_amd import synth
-	from vcf2multialign_amd.sharding import max_over_ranks, shard_copies
+	from vcf2multialign_amd.sharding import shard_copies
 
 	# ---- workload: generated on every rank (deterministic), resident in HBM before timing ----------
 	t0 = time.time()
@@ -239,8 +377,7 @@ def main():
 		step()
 	ctx.synchronize()
 	torch.cuda.synchronize()
-	if world > 1:
-		dist.barrier()
+	hub.barrier()
 	ctx.profile_enable(True)
 	ctx.profile_reset()
 	t_begin = time.perf_counter()
@@ -249,17 +386,10 @@ def main():
 	ctx.synchronize()
 	torch.cuda.synchronize()
 	elapsed = time.perf_counter() - t_begin
-	per_rank = [{"rank": 0, "rows": n_rows, "batches": len(batches), "ms_per_step": round(1e3 * elapsed / args.steps, 3)}]
-	if world > 1:
-		dist.barrier()
-		mine = torch.tensor([elapsed, float(n_rows), float(len(batches))], dtype=torch.float64, device=red_dev)
-		everyone = [torch.zeros_like(mine) for _ in range(world)]
-		dist.all_gather(everyone, mine)      # reporting only (after the timed region): rank 0 carries REF, so imbalance should be visible
-		per_rank = [{"rank": r, "rows": int(t[1].item()), "batches": int(t[2].item()), "ms_per_step": round(1e3 * t[0].item() / args.steps, 3)} for r, t in enumerate(everyone)]
-		elapsed = max_over_ranks(elapsed, dist, red_dev)
+	hub.barrier()
 	ctx.profile_enable(False)
 
-	# ---- roofline of the dominant kernel, from HIP events on the kernel's own stream ---------------
+	# ---- this rank's kernel figures, from HIP events on the kernels' own stream ----------------------
 	launches, splice_ms = ctx.profile_get(N.KERNEL_SPLICE_ALIGNED)
 	per_launch = ctx.profile_launches(N.KERNEL_SPLICE_ALIGNED)
 	if rank == 0 and os.environ.get("V2M_BENCH_LOG_LAUNCHES"):
@@ -272,10 +402,136 @@ def main():
 	shared_bytes = R + 24 * NN + 8 * E + label_bytes
 	alg_bytes_total = sum(b.n_rows * L + b.n_rows * Ep // 8 + shared_bytes for b in batches)
 	alg_bytes_per_launch = alg_bytes_total / max(1, len(batches))
-	avg_launch_s = (splice_ms / 1e3) / max(1, launches)
-	achieved = alg_bytes_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+	mine = {
+		"rank": rank, "rows": n_rows, "batches": len(batches), "elapsed_s": elapsed,
+		"launches": launches, "splice_ms": splice_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
+		"resolve_ms": resolve_ms, "transpose_launches": transpose_launches, "transpose_ms": transpose_ms,
+	}
 
-	value = total_rows * L * args.steps / elapsed / 1e9
+	# ---- CPU oracle: every rank checks rows of every batch of its own shard ----------------------------
+	def oracle_graph(copies):
+		"""Oracle graph whose path matrix holds the CPU re-derivation (genotype hash) of the given global copies."""
+		import oracle
+		n_cols = 64 * ((len(copies) + 63) // 64)
+		cols = [ds.copy_column(c) for c in copies] + [np.zeros(Ep // 64, np.uint64)] * (n_cols - len(copies))
+		return oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
+			g.label_offsets, g.label_bytes, np.concatenate(cols) if Ep else np.zeros(0, np.uint64), Ep, n_cols,
+			["S%d" % i for i in range(n_cols // ds.ploidy)], np.arange(n_cols // ds.ploidy + 1, dtype=np.uint32) * ds.ploidy)
+
+	host_threads = max(1, min(16, os.cpu_count() or 1))
+	mine["parity_ok"], mine["parity_checked"] = True, 0
+	if args.verify_rows and batches:
+		import oracle
+		# which rows: per batch `verify_rows` rows spread over the batch (the first batch's includes row 0: REF on rank 0), and
+		# every row of the last batch's final, ragged 16-row group (the rows a wrong grid or tile bound would lose first)
+		picks = []   # (batch index, row within batch)
+		for bi, b in enumerate(batches):
+			for k in range(args.verify_rows):
+				picks.append((bi, (k * b.n_rows // args.verify_rows + 37 * bi) % b.n_rows if (bi or k) else 0))
+		last = batches[-1]
+		tail = last.n_rows % 16 or min(16, last.n_rows)
+		picks += [(len(batches) - 1, r) for r in range(last.n_rows - min(tail, 4), last.n_rows)]
+		picks = sorted(set(picks))
+		local_of = lambda bi, r: rows[bi * batch_rows + r]
+		copies = sorted({c0 + local_of(bi, r) for bi, r in picks if local_of(bi, r) != v2m.PLOIDY_MAX})
+		og = oracle_graph(copies)
+		col_of = {c: i for i, c in enumerate(copies)}
+		want_rows = [oracle.PLOIDY_MAX if local_of(bi, r) == v2m.PLOIDY_MAX else col_of[c0 + local_of(bi, r)] for bi, r in picks]
+		t_o = time.time()
+		want_sums, want_len = og.row_checksums(ds.reference, want_rows, threads=min(host_threads, len(want_rows)))
+		ok = bool((want_len == L).all())
+		got_sums = np.zeros(len(picks), dtype=np.uint64)
+		full_compare = None
+		for bi, b in enumerate(batches):          # re-run every batch of this rank's step and look at the picked rows on the device
+			mine_i = [i for i, (pb, _) in enumerate(picks) if pb == bi]
+			if not mine_i:
+				continue
+			ctx.splice_rows_device(b, out_ptr, pitch)
+			for i in mine_i:
+				got_sums[i] = ctx.checksum_rows_device(out_ptr + picks[i][1] * pitch, pitch, 1, length=L)[0]
+			if bi == len(batches) - 1:            # one row of the last batch byte for byte: its very last row
+				i = mine_i[-1]
+				body = og.output_sequence(ds.reference, copy_index=want_rows[i]) if want_rows[i] != oracle.PLOIDY_MAX else og.output_sequence(ds.reference)
+				full_compare = _device_bytes(out_ptr + picks[i][1] * pitch, L) == body
+		ok = ok and bool(np.array_equal(got_sums, want_sums)) and full_compare is not False
+		mine["parity_ok"], mine["parity_checked"] = ok, len(picks)
+		log("[bench] rank %d parity: %d rows of %d batches against the oracle in %.1f s: %s" % (rank, len(picks), len(batches), time.time() - t_o, "bit-exact" if ok else "MISMATCH"))
+		del og
+
+	# ---- end to end: what a caller of output::output_a2m gets (output.cc:47-76) -- every row crosses the link ------------
+	# v2m_splice_rows (the sink form the command-line driver uses): the batch is spliced slice by slice into two device slots,
+	# each slice's D2H copy runs on the copy stream under the next slice's kernels, and every finished row is handed to the sink
+	# from the library's pinned slot.  The sink here is C (libv2m_synth.so: v2ms_checksum_sink_fn): it reads every byte of every
+	# row -- the checksum of v2m_checksum_rows_device, on --e2e-threads host threads -- and keeps nothing.  All ranks run the leg
+	# together (one PCIe link each), between barriers.
+	e2e_rows = min(n_rows, max(1, int(args.e2e_gb * 1e9) // max(1, L))) if args.e2e_gb > 0 and n_rows else 0
+	if args.e2e_gb > 0:
+		import ctypes as C
+		sl = C.CDLL(_build.SYNTH_LIB_PATH)
+		sl.v2ms_checksum_sink_create.restype = C.c_void_p
+		sl.v2ms_checksum_sink_create.argtypes = [C.c_uint64, C.c_uint32]
+		sl.v2ms_checksum_sink_destroy.argtypes = [C.c_void_p]
+		for name in ("rows", "bytes"):
+			getattr(sl, "v2ms_checksum_sink_" + name).restype = C.c_uint64
+			getattr(sl, "v2ms_checksum_sink_" + name).argtypes = [C.c_void_p]
+		for name in ("checksums", "lengths"):
+			getattr(sl, "v2ms_checksum_sink_" + name).restype = C.POINTER(C.c_uint64)
+			getattr(sl, "v2ms_checksum_sink_" + name).argtypes = [C.c_void_p]
+		sink_fn = C.cast(sl.v2ms_checksum_sink_fn, N.SINK_FN)
+
+		def through_the_sink(batch):
+			state = sl.v2ms_checksum_sink_create(max(1, batch.n_rows), max(1, args.e2e_threads))
+			try:
+				t_s = time.perf_counter()
+				rc = ctx._lib.v2m_splice_rows(ctx._h, C.byref(batch.struct), 0, sink_fn, state)
+				secs = time.perf_counter() - t_s
+				ctx._check(rc)
+				n = int(sl.v2ms_checksum_sink_rows(state))
+				sums = np.ctypeslib.as_array(sl.v2ms_checksum_sink_checksums(state), shape=(max(1, batch.n_rows),))[:n].copy()
+				lens = np.ctypeslib.as_array(sl.v2ms_checksum_sink_lengths(state), shape=(max(1, batch.n_rows),))[:n].copy()
+				return secs, n, int(sl.v2ms_checksum_sink_bytes(state)), sums, lens
+			finally:
+				sl.v2ms_checksum_sink_destroy(state)
+
+		if e2e_rows:
+			through_the_sink(v2m.RowBatch(rows[:min(8, e2e_rows)]))   # first use of the sink path: its device and pinned slots are set up here
+		hub.barrier()
+		if e2e_rows:
+			e_secs, e_n, e_bytes, e_sums, e_lens = through_the_sink(v2m.RowBatch(rows[:e2e_rows]))
+		hub.barrier()
+		if e2e_rows:
+			import oracle
+			t_o = time.time()
+			ecopies = [c0 + r for r in rows[:e2e_rows] if r != v2m.PLOIDY_MAX]
+			eog = oracle_graph(ecopies)
+			ecol = {c: i for i, c in enumerate(ecopies)}
+			ewant, ewant_len = eog.row_checksums(ds.reference, [oracle.PLOIDY_MAX if r == v2m.PLOIDY_MAX else ecol[c0 + r] for r in rows[:e2e_rows]], threads=host_threads)
+			e_ok = e_n == e2e_rows and e_bytes == e2e_rows * L and bool(np.array_equal(e_lens, ewant_len)) and bool(np.array_equal(e_sums, ewant))
+			del eog
+			log("[bench] rank %d end to end: %d rows = %.1f GB through the sink in %.3f s = %.1f GB/s; every row against the oracle (%.1f s on %d threads): %s"
+				% (rank, e_n, e_bytes / 1e9, e_secs, e_bytes / e_secs / 1e9, time.time() - t_o, host_threads, "bit-exact" if e_ok else "MISMATCH"))
+			mine["e2e"] = {"rows": e_n, "bytes": e_bytes, "seconds": e_secs, "bit_exact": e_ok}
+
+	everyone = hub.gather(mine)
+
+	if rank != 0:
+		hub.close()
+		ctx.free_output(out_ptr)
+		ctx.close()
+		return
+
+	# ================= rank 0: the line ================================================================================
+	slowest = max(everyone, key=lambda f: f["elapsed_s"])
+	elapsed_max = slowest["elapsed_s"]
+	value = total_rows * L * args.steps / elapsed_max / 1e9
+	avg_ms = lambda f: f["splice_ms"] / max(1, f["launches"])
+	per_rank = [{"rank": f["rank"], "rows": f["rows"], "batches": f["batches"], "ms_per_step": round(1e3 * f["elapsed_s"] / args.steps, 3),
+		"launches": f["launches"], "avg_launch_ms": round(avg_ms(f), 4)} for f in everyone]
+	# the roofline is the SLOWEST rank's kernel average over that rank's own launches (its rows per launch may differ by a few)
+	roof_rank = max(everyone, key=avg_ms)
+	avg_launch_s = avg_ms(roof_rank) / 1e3
+	roof_alg = roof_rank["algorithmic_bytes_per_launch"]
+	achieved = roof_alg / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
 
 	# HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same command
 	# (profiles/pmc_traffic.json).  It is quoted only for the run it was measured on: same config, rows per launch and GPU
@@ -296,10 +552,12 @@ def main():
 		"metric": "aligned A2M Gbases/sec",
 		"value": round(value, 3),
 		"unit": "Gbases/s",
+		"residency": "hbm",
+		"residency_note": "value is the HBM-resident rate: inputs in HBM, rows written to HBM, nothing crosses PCIe in the timed region; the rate with every row delivered to the host is end_to_end.value",
 		"n_gpus": world,
 		"steps": args.steps,
 		"warmup": args.warmup,
-		"ms_per_step": round(1e3 * elapsed / args.steps, 3),
+		"ms_per_step": round(1e3 * elapsed_max / args.steps, 3),
 		"higher_is_better": True,
 		"scaling": "strong",
 		"vs_baseline": None,
@@ -309,19 +567,47 @@ def main():
 			"workload": "%s: synthetic %d bp reference, %d variant records (%d ALT edges), %d diploid samples = %d haplotype rows + REF, --haplotypes aligned A2M, L=%d"
 				% (args.config, R, ds.n_variants, E, ds.samples, H, L),
 			"rows_total": total_rows, "aligned_length": L, "batch_rows": batch_rows,
-			"path_matrix": "%d x %d bits per rank: this rank's copies x ALT edges, both padded to multiples of 64 as in the reference (variant_graph.cc:277,449), nothing more" % (hp_local, Ep),
+			"path_matrix": "%d x %d bits on rank 0: a rank's copies x ALT edges, both padded to multiples of 64 as in the reference (variant_graph.cc:277,449), nothing more" % (hp_local, Ep),
 			"sharding": "contiguous chromosome copies per rank (multiples of 8), graph + reference replicated, no collective",
+			"ranks_coordinated_by": hub.kind,
 			"per_rank": per_rank,
 			"tuning": ctx.info,
 		},
 		"roofline": {
 			"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
 			"frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_unit": "bytes per launch (PMC: WRITE_SIZE + 2*FETCH_SIZE)", "traffic_source": traffic_source,
-			"kernel": "splice_aligned_kernel", "launches": launches, "avg_launch_ms": round(1e3 * avg_launch_s, 4),
-			"algorithmic_bytes_per_launch": int(alg_bytes_per_launch),
-			"other_kernels_ms_per_step": {"resolve_effective_edges_kernel": round(resolve_ms / args.steps, 3), "transpose_bits_kernel": round(transpose_ms / args.steps, 3)},
+			"kernel": "splice_aligned_kernel", "rank": roof_rank["rank"], "of_ranks": "the slowest rank's launches (largest avg_launch_ms of config.per_rank)",
+			"launches": roof_rank["launches"], "avg_launch_ms": round(1e3 * avg_launch_s, 4),
+			"algorithmic_bytes_per_launch": int(roof_alg),
+			"other_kernels_ms_per_step": {"resolve_effective_edges_kernel": round(roof_rank["resolve_ms"] / args.steps, 3), "transpose_bits_kernel": round(roof_rank["transpose_ms"] / args.steps, 3)},
 		},
 	}
+
+	checked = sum(f["parity_checked"] for f in everyone)
+	if checked:
+		ok = all(f["parity_ok"] for f in everyone)
+		result["parity"] = {"rows_checked": checked, "batches_covered": sum(f["batches"] for f in everyone), "bit_exact": ok,
+			"method": "per rank, after timing: every batch of the step re-run; device checksums (v2m_checksum_rows_device) of %d row(s) per batch, REF and the last batch's final ragged group against the CPU oracle's rows, plus the last row of the last batch byte for byte" % args.verify_rows}
+		if not ok:
+			log("[bench] PARITY FAILURE against the CPU oracle")
+
+	legs = [f["e2e"] for f in everyone if f.get("e2e")]
+	if legs:
+		e_bytes, e_secs = sum(l["bytes"] for l in legs), max(l["seconds"] for l in legs)
+		e_ok = all(l["bit_exact"] for l in legs)
+		slow = min(legs, key=lambda l: l["bytes"] / l["seconds"])
+		result["end_to_end"] = {
+			"metric": "aligned A2M Gbases/sec delivered to a host sink (PCIe-inclusive)", "value": round(e_bytes / e_secs / 1e9, 3), "unit": "Gbases/s", "GBs": round(e_bytes / e_secs / 1e9, 3),
+			"rows": sum(l["rows"] for l in legs), "bytes": e_bytes, "seconds": round(e_secs, 4),
+			"path": "v2m_splice_rows: slices of the batch spliced into two device slots, D2H on the copy stream under the next slice's kernels, rows handed to a C sink from the library's pinned slots (what output::output_a2m does, output.cc:47-76); the sink reads every byte (checksum on %d host threads) and keeps nothing; all ranks at once, one link each" % args.e2e_threads,
+			"roofline": {"bound": "pcie", "achieved": round(slow["bytes"] / slow["seconds"] / 1e9, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": round(slow["bytes"] / slow["seconds"] / 1e9 / PCIE_PEAK_GBS, 4),
+				"note": "per GPU (the slowest rank's link): PCIe Gen5 x16, 63 GB/s spec per direction; a row byte crosses the link exactly once"},
+			"per_rank_GBs": [round(l["bytes"] / l["seconds"] / 1e9, 2) for l in legs],
+			"parity": {"rows_checked": sum(l["rows"] for l in legs), "bit_exact": e_ok, "method": "length and checksum of EVERY delivered row, computed on the host inside the sink, against the CPU oracle's rows"},
+		}
+		if not e_ok:
+			log("[bench] PARITY FAILURE (end-to-end leg) against the CPU oracle")
+			result.setdefault("parity", {})["bit_exact"] = False
 
 	# ---- the transpose, at the reference's padding: algorithmic 2 * Hp * Ep / 8 bytes per call -----------------------
 	tr_bytes = 2 * hp_local * Ep // 8
@@ -329,7 +615,7 @@ def main():
 		t_ms = transpose_ms / transpose_launches
 		result["roofline_transpose"] = {
 			"bound": "hbm", "kernel": "transpose_bits (v2m_bind_path_matrix_device: source in the reference's layout and padding, destination the library's own line-aligned copy; the kernel is chosen per matrix shape by measurement, see config.tuning)",
-			"matrix_bits": [hp_local, Ep], "algorithmic_bytes": tr_bytes, "launches": transpose_launches,
+			"rank": 0, "matrix_bits": [hp_local, Ep], "algorithmic_bytes": tr_bytes, "launches": transpose_launches,
 			"avg_launch_ms": round(t_ms, 4), "achieved": round(tr_bytes / t_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
 			"frac": round(tr_bytes / t_ms / 1e6 / HBM_PEAK_GBS, 4),
 		}
@@ -345,7 +631,7 @@ def main():
 		ctx.profile_enable(False)
 		return ms / max(1, n)
 
-	if rank == 0 and args.transpose_extras and hp_local:
+	if args.transpose_extras and hp_local:
 		# the ABI's dense form (v2m_transpose_bits_device: caller-visible destination, so both sides at the reference's padding)
 		fwd_ms = time_transpose(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())
 		back = torch.empty_like(paths_src)
@@ -368,88 +654,32 @@ def main():
 		}
 		if not involution:
 			log("[bench] PARITY FAILURE: transpose(transpose(m)) != m")
+			result.setdefault("parity", {})["bit_exact"] = False
 		ctx.bind_path_matrix_device(paths_src.data_ptr(), hp_local, Ep)
 
 	# Context for the roofline number: what a plain device memset of the very same output buffer reaches in this
 	# process (the achievable write rate varies by +-10 % between processes / boxes).
-	if rank == 0:
-		ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-		fills = []
-		for _ in range(3):
-			ev0.record()
-			_hip_memset(torch, out_ptr, out_bytes)
-			ev1.record()
-			torch.cuda.synchronize()
-			fills.append(ev0.elapsed_time(ev1))
-		result["roofline"]["memset_same_buffer_GBs"] = round(out_bytes / (min(fills) * 1e-3) / 1e9, 1)
-
-	# ---- CPU oracle: every rank checks rows of every batch of its own shard; rank 0 at N=1 times the baseline ----
-	def oracle_graph(copies):
-		"""Oracle graph whose path matrix holds the CPU re-derivation (genotype hash) of the given global copies."""
-		import oracle
-		n_cols = 64 * ((len(copies) + 63) // 64)
-		cols = [ds.copy_column(c) for c in copies] + [np.zeros(Ep // 64, np.uint64)] * (n_cols - len(copies))
-		return oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
-			g.label_offsets, g.label_bytes, np.concatenate(cols) if Ep else np.zeros(0, np.uint64), Ep, n_cols,
-			["S%d" % i for i in range(n_cols // ds.ploidy)], np.arange(n_cols // ds.ploidy + 1, dtype=np.uint32) * ds.ploidy)
-
-	if args.verify_rows and batches:
-		import oracle
-		# which rows: per batch `verify_rows` rows spread over the batch (the first batch's includes row 0: REF on rank 0), and
-		# every row of the last batch's final, ragged 16-row group (the rows a wrong grid or tile bound would lose first)
-		picks = []   # (batch index, row within batch)
-		for bi, b in enumerate(batches):
-			for k in range(args.verify_rows):
-				picks.append((bi, (k * b.n_rows // args.verify_rows + 37 * bi) % b.n_rows if (bi or k) else 0))
-		last = batches[-1]
-		tail = last.n_rows % 16 or min(16, last.n_rows)
-		picks += [(len(batches) - 1, r) for r in range(last.n_rows - min(tail, 4), last.n_rows)]
-		picks = sorted(set(picks))
-		local_of = lambda bi, r: rows[bi * batch_rows + r]
-		copies = sorted({c0 + local_of(bi, r) for bi, r in picks if local_of(bi, r) != v2m.PLOIDY_MAX})
-		og = oracle_graph(copies)
-		col_of = {c: i for i, c in enumerate(copies)}
-		want_rows = [oracle.PLOIDY_MAX if local_of(bi, r) == v2m.PLOIDY_MAX else col_of[c0 + local_of(bi, r)] for bi, r in picks]
-		t_o = time.time()
-		want_sums, want_len = og.row_checksums(ds.reference, want_rows, threads=min(16, os.cpu_count() or 1, len(want_rows)))
-		ok = bool((want_len == L).all())
-		got_sums = np.zeros(len(picks), dtype=np.uint64)
-		full_compare = None
-		for bi, b in enumerate(batches):          # re-run every batch of this rank's step and look at the picked rows on the device
-			mine = [i for i, (pb, _) in enumerate(picks) if pb == bi]
-			if not mine:
-				continue
-			ctx.splice_rows_device(b, out_ptr, pitch)
-			for i in mine:
-				got_sums[i] = ctx.checksum_rows_device(out_ptr + picks[i][1] * pitch, pitch, 1, length=L)[0]
-			if bi == len(batches) - 1:            # one row of the last batch byte for byte: its very last row
-				i = mine[-1]
-				body = og.output_sequence(ds.reference, copy_index=want_rows[i]) if want_rows[i] != oracle.PLOIDY_MAX else og.output_sequence(ds.reference)
-				full_compare = _device_bytes(out_ptr + picks[i][1] * pitch, L) == body
-		ok = ok and bool(np.array_equal(got_sums, want_sums)) and full_compare is not False
-		checked = len(picks)
-		if rank == 0:
-			log("[bench] parity: %d rows of %d batches against the oracle in %.1f s: %s" % (checked, len(batches), time.time() - t_o, "bit-exact" if ok else "MISMATCH"))
-		if world > 1:
-			flags = torch.tensor([1 if ok else 0, checked], dtype=torch.int64, device=red_dev)
-			lo = flags.clone()
-			dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-			dist.all_reduce(flags, op=dist.ReduceOp.SUM)
-			ok, checked = bool(lo[0].item()), int(flags[1].item())
-		result["parity"] = {"rows_checked": checked, "batches_covered": sum(p["batches"] for p in per_rank), "bit_exact": ok,
-			"method": "per rank, after timing: every batch of the step re-run; device checksums (v2m_checksum_rows_device) of %d row(s) per batch, REF and the last batch's final ragged group against the CPU oracle's rows, plus the last row of the last batch byte for byte" % args.verify_rows}
-		if not ok:
-			log("[bench] PARITY FAILURE against the CPU oracle")
+	ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+	fills = []
+	for _ in range(3):
+		ev0.record()
+		_hip_memset(torch, out_ptr, out_bytes)
+		ev1.record()
+		torch.cuda.synchronize()
+		fills.append(ev0.elapsed_time(ev1))
+	result["roofline"]["memset_same_buffer_GBs"] = round(out_bytes / (min(fills) * 1e-3) / 1e9, 1)
+	result["roofline"]["memset_same_buffer_rank"] = 0
 
 	# ---- second leg, timed on its own: --unaligned (sequence_writer.cc:80: no '-' padding) -----------------------------
 	# Measured on the SAME address footprint as the aligned leg (as many rows as the ~63-GB output buffer holds at the unaligned
 	# pitch: the store pattern only reaches its full rate when a launch spans several tens of GB, DESIGN.md section 4), and, for
 	# continuity with rounds 1-2, on the first --unaligned-rows (256) rows as well.
-	if rank == 0 and args.unaligned_rows and n_rows > 1:
+	if args.unaligned_rows and n_rows > 1:
 		import oracle
 		upitch = (ctx.max_unaligned_length + 255) // 256 * 256
 		n_tiles = -(-L // 16384)
-		aligned_ms_per_base = (splice_ms / max(1, launches)) / max(1, batch_rows * L)
+		f0 = everyone[0]
+		aligned_ms_per_base = avg_ms(f0) / max(1, batch_rows * L)
 
 		def unaligned_leg(n_u, reps=3):
 			ub = v2m.RowBatch(rows[:n_u])
@@ -496,7 +726,7 @@ def main():
 		n_small = max(1, min(args.unaligned_rows, n_full))
 		small = unaligned_leg(n_small)
 		full = unaligned_leg(n_full) if n_full != n_small else small
-		result["unaligned"] = dict(full, metric="unaligned (--unaligned) Gbases/sec, one batch on the aligned leg's output buffer (same ~%.0f-GB address footprint), kernels only" % (out_bytes / 1e9),
+		result["unaligned"] = dict(full, metric="unaligned (--unaligned) Gbases/sec, one batch on the aligned leg's output buffer (same ~%.0f-GB address footprint), kernels only, rank 0" % (out_bytes / 1e9),
 			first_rows_only=small, tuning=ctx.info)
 		for leg in (small, full):
 			if not leg["parity"]["bit_exact"]:
@@ -504,7 +734,7 @@ def main():
 				result.setdefault("parity", {})["bit_exact"] = False
 
 	# ---- the CPU path beside the GPU transpose ("time the whole matrix on CPU, one call per run") ---------
-	if rank == 0 and world == 1 and args.cpu_transpose and hp_local and "roofline_transpose" in result:
+	if args.cpu_transpose and hp_local and "roofline_transpose" in result:
 		import oracle
 		host_src = np.frombuffer(_device_bytes(paths_src.data_ptr(), tr_bytes // 2), dtype=np.uint64)      # copied to the host once, after all GPU timing
 		ctx.transpose_bits_device(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())                # the ABI's dense form: caller-visible destination
@@ -517,7 +747,7 @@ def main():
 		gpu_ms = result["roofline_transpose"]["avg_launch_ms"]
 		result["roofline_transpose"]["cpu_baseline"] = {
 			"seconds": round(secs_c, 3), "value": round(tr_bytes / secs_c / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-			"sample": "the whole %d x %d-bit matrix of this run (%.3f GB read + written), one call of the oracle's v2mo_transpose_matrix (the 8x8-block traversal of transpose_matrix.cc:41-109), including its zero-fill of the destination; host has %d logical CPUs"
+			"sample": "the whole %d x %d-bit matrix of rank 0 in this run (%.3f GB read + written), one call of the oracle's v2mo_transpose_matrix (the 8x8-block traversal of transpose_matrix.cc:41-109), including its zero-fill of the destination; host has %d logical CPUs"
 				% (hp_local, Ep, tr_bytes / 1e9, os.cpu_count()),
 			"bit_exact_vs_gpu_dense_form": same, "gpu_over_cpu": round(secs_c * 1e3 / gpu_ms, 1) if gpu_ms > 0 else None,
 		}
@@ -526,23 +756,21 @@ def main():
 			result.setdefault("parity", {})["bit_exact"] = False
 		del host_src, gpu_dense, cpu_dst
 
-	if rank == 0 and world == 1 and args.cpu_baseline_rows:
+	# ---- the CPU path beside the GPU splice: same run, same host, at every N (the other ranks have finished or wait) -------
+	if args.cpu_baseline_rows:
 		nb = min(args.cpu_baseline_rows, H)
 		og = oracle_graph(list(range(nb)))
 		nbytes, secs = og.haplotype_output_a2m(ds.reference, None, first_copy=0, n_copies=nb)
 		bases = (nb + 1) * L
 		result["cpu_baseline"] = {
 			"value": round(bases / secs / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
-			"sample": "REF + first %d haplotypes of %s (%.2f Gbases) through the oracle's output_sequence/haplotype_output_a2m into a discarding std::ostream, %.1f s; rows are independent, so the rate carries to the full %d rows; host has %d logical CPUs"
+			"sample": "REF + first %d haplotypes of %s (%.2f Gbases) through the oracle's output_sequence/haplotype_output_a2m (sequence_writer.cc:22-85 driven by haplotype_output.cc:38-82) into a discarding std::ostream, %.1f s, on rank 0's host cores after the timed region; rows are independent, so the rate carries to the full %d rows; host has %d logical CPUs"
 				% (nb, args.config, bases / 1e9, secs, total_rows, os.cpu_count()),
 		}
 
-	if rank == 0:
-		result_out.write(json.dumps(result) + "\n")
-		result_out.flush()
-	if world > 1:
-		dist.barrier()
-		dist.destroy_process_group()
+	result_out.write(json.dumps(result) + "\n")
+	result_out.flush()
+	hub.close()
 	ctx.free_output(out_ptr)
 	ctx.close()
 	if result.get("parity", {}).get("bit_exact") is False:

@@ -1018,7 +1018,7 @@ bool build_variant_graph(std::string const &ref_seq, char const *vcf_path, char 
 		g.add_or_update_node(ref_pos, aln_pos + (ref_pos - prev_ref_pos));
 	}
 
-	if (!g.paths_by_edge_and_chrom_copy.words.empty() || g.paths_by_edge_and_chrom_copy.rows) {   // :445-451
+	if (!g.paths_by_edge_and_chrom_copy.words.empty()) {   // :445-451 (`if (graph.paths_by_edge_and_chrom_copy.size())`: the 1 x 0 matrix of a graph without chromosome copies, :280, stays as it is)
 		auto &m(g.paths_by_edge_and_chrom_copy);
 		std::uint64_t const ncol(64 * ((g.edge_count() + 63) / 64));
 		m.resize_total_bits(m.rows * ncol);

@@ -154,3 +154,92 @@ def test_refuses_what_it_cannot_hold(v2m):
 		u = (C.c_uint32 * 4)()
 		rc = ctx._lib.v2m_pbwt_cut_trials(ctx._h, 4, 0, 2, u, a, 1, a, u, u, 16, u, u, a, u)
 		assert rc == N.V2M_ERR_STATE
+
+
+def test_refuses_bad_candidates_and_start_states(v2m):
+	"""v2m_pbwt_cut_trials has the input discipline of v2m_pbwt_cut_records: candidate edges that do not ascend or leave the graph,
+	aligned positions that go back (find_cut_positions.cc:129,151), a start order that is no permutation of the copies (it indexes
+	the workgroup's LDS state) and a bound matrix wider than the LDS column stash are errors -- before any kernel sees them."""
+	from vcf2multialign_amd import _native as N
+	import ctypes as C
+	d = os.path.join(HERE, "golden", "reference-fixtures", "founder-sequences")
+	og = oracle.build_variant_graph(os.path.join(d, "test-1.fa"), os.path.join(d, "test-1.vcf"), "1")
+	n_copies, n_edges = og.total_chromosome_copies, og.edge_count
+	assert n_edges >= 3
+	u32, u64 = C.c_uint32, C.c_uint64
+
+	def arr(t, values):
+		return (t * len(values))(*values)
+
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(v2m.VariantGraph.from_object(og), og.ref)
+		cap = 4096
+		out32, out32b, out64, status = (u32 * cap)(), (u32 * cap)(), (u64 * 8)(), (u32 * 2)()
+		order = arr(u32, list(range(n_copies)))
+		div = arr(u32, [0] * n_copies)
+		chunk_first = arr(u64, [1, 3])
+
+		def trials(cand_edge, cand_aln, start_order=order, copies=n_copies):
+			return ctx._lib.v2m_pbwt_cut_trials(ctx._h, copies, 0, len(cand_edge), arr(u32, cand_edge), arr(u64, cand_aln), 1, chunk_first, start_order, div,
+				cap, out32, out32b, out64, status)
+
+		good_edge, good_aln = [0, 1, 2], [0, 5, 9]
+		assert trials(good_edge, good_aln) == N.V2M_OK and status[0] in (0, 1)
+		for bad_edge in ([0, 2, 1], [0, 1, 1], [0, 1, n_edges + 1]):
+			assert trials(bad_edge, good_aln) == N.V2M_ERR_INVALID_ARGUMENT
+			assert b"candidate edges" in ctx._lib.v2m_last_error(ctx._h)
+		assert trials(good_edge, [0, 9, 5]) == N.V2M_ERR_INVALID_ARGUMENT
+		assert b"aligned positions" in ctx._lib.v2m_last_error(ctx._h)
+		bad_order = list(range(n_copies)); bad_order[-1] = n_copies
+		assert trials(good_edge, good_aln, start_order=arr(u32, bad_order)) == N.V2M_ERR_INVALID_ARGUMENT
+		assert b"start_order" in ctx._lib.v2m_last_error(ctx._h)
+		# the sibling entry point refuses the same start order, and a first cut edge outside the graph
+		cut_edge = arr(u32, [0, 1, 2])
+		z32 = (u32 * cap)()
+		def records(cut_edges, start_order=order):
+			return ctx._lib.v2m_pbwt_cut_records(ctx._h, n_copies, len(cut_edges), arr(u32, cut_edges), 1, arr(u64, [1, len(cut_edges)]), arr(u32, [0]), start_order, div,
+				cap, z32, (u32 * cap)(), (u32 * cap)(), (u64 * 8)(), (u32 * 8)(), (u32 * 8)(), (u32 * 8)(), status)
+		assert records([0, 1, 2]) == N.V2M_OK
+		assert records([0, 1, 2], start_order=arr(u32, bad_order)) == N.V2M_ERR_INVALID_ARGUMENT
+		assert records([n_edges + 1, n_edges + 2, n_edges + 3]) == N.V2M_ERR_INVALID_ARGUMENT
+
+		# a bound matrix with more copy columns than the kernels' LDS column stash holds (8192), walked with fewer copies: refused
+		import torch
+		wide = 8192 + 64
+		words = torch.zeros(og.path_rows // 64 * wide, dtype=torch.int64, device="cuda:0")
+		ctx.set_paths_device(words.data_ptr(), og.path_rows, wide)
+		assert trials(good_edge, good_aln) == N.V2M_ERR_UNSUPPORTED
+		assert b"columns" in ctx._lib.v2m_last_error(ctx._h)
+		assert records([0, 1, 2]) == N.V2M_ERR_UNSUPPORTED
+
+
+def test_edge_major_copy_is_kept_between_the_two_searches_and_dropped_with_the_binding(v2m, HostGraph, tmp_path):
+	"""One founder run makes two v2m_pbwt_* calls on one binding: the second reuses the first's edge-major copy of the matrix (one
+	transpose launch, not two), and a new binding -- another matrix at the same address included -- makes a new one."""
+	from vcf2multialign_amd import _native as N
+	rng = np.random.default_rng(5)
+	ref = synth.random_reference(rng, 40000)
+	recs = synth.random_records(rng, ref, 3000, 40, mix=(0.8, 0.1, 0.1))
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, 40)
+	og = oracle.build_variant_graph(fa, vcf, "1")
+	hg = HostGraph(fa, vcf, "1")
+	hg.set_transposed_paths(og.paths_by_chrom_copy_and_edge, og.path_rows, og.path_cols)
+	want = hg.find_founders(5, 20, threads=1)
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(v2m.VariantGraph.from_object(og), og.ref)
+		ctx.profile_enable(True)
+		ctx.profile_reset()
+		assert hg.find_founders_gpu(ctx, 5, 20, threads=2) == want
+		assert ctx.profile_get(N.KERNEL_TRANSPOSE)[0] == 1                 # cut search + matching: one transpose back
+		assert hg.find_founders_gpu(ctx, 5, 20, threads=2) == want
+		assert ctx.profile_get(N.KERNEL_TRANSPOSE)[0] == 1                 # and none for a second run on the same binding
+		# the same graph with every path bit cleared, uploaded again: the copy must not survive the binding
+		import copy
+		vg = v2m.VariantGraph.from_object(og)
+		vg0 = copy.copy(vg)
+		vg0.paths_by_chrom_copy_and_edge = np.zeros_like(vg.paths_by_chrom_copy_and_edge)
+		ctx.upload_graph(vg0, og.ref)
+		hg0 = HostGraph(fa, vcf, "1")
+		hg0.set_transposed_paths(vg0.paths_by_chrom_copy_and_edge, og.path_rows, og.path_cols)
+		assert hg0.find_founders_gpu(ctx, 5, 20, threads=2) == hg0.find_founders(5, 20, threads=1)
+		assert ctx.profile_get(N.KERNEL_TRANSPOSE)[0] == 2

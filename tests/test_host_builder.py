@@ -104,6 +104,29 @@ def test_sample_exclusion(HostGraph, tmp_path):   # variant_graph.cc:215-273
 	assert g.total_chromosome_copies == 10
 
 
+def test_every_copy_excluded(HostGraph, tmp_path):
+	"""A haploid one-sample VCF with that sample's only copy excluded (variant_graph.cc:215-273): no chromosome copy is left, the path
+	matrix has no rows, and the graph -- nodes, edges, labels -- is still built, on one thread and on several (round 3's chunked merge
+	refused it: the parser counts a column per ALT edge, the builder grows none for a matrix without rows)."""
+	records = [(2, b"G", [b"T"], np.array([[1]])), (5, b"CG", [b"C"], np.array([[1]])), (9, b"C", [b"G", b"CAA"], np.array([[2]]))]
+	fa, vcf = synth.write_inputs(str(tmp_path), b"ACGTACGTACGTACGT", records, 1)      # one genotype column per sample: haploid
+	for threads in (1, 3):
+		o = oracle.build_variant_graph(fa, vcf, "1", exclude_sample="S0", exclude_copy=0)
+		h = HostGraph(fa, vcf, "1", exclude_sample="S0", exclude_copy=0, threads=threads)
+		for k in ARRAYS:
+			if not k.startswith("paths_"):
+				assert np.array_equal(getattr(o, k), getattr(h, k)), k
+		assert o.label_bytes == h.label_bytes and o.sample_names == h.sample_names and o.overlaps() == h.overlaps
+		# the reference keeps a 1 x 0 matrix here (variant_graph.cc:280, never resized: :445 tests size()), the host builder a 0 x Ep one:
+		# either way a matrix that holds no word, and an empty transpose (transpose_matrix.cc:48-49)
+		assert o.paths_by_edge_and_chrom_copy_dims == (1, 0) and h.paths_by_edge_and_chrom_copy_dims[0] == 0
+		assert o.paths_by_edge_and_chrom_copy.size == 0 and h.paths_by_edge_and_chrom_copy.size == 0
+		assert o.paths_by_chrom_copy_and_edge.size == 0          # (the host graph's transpose is the GPU's to make)
+		assert int(h.ploidy_csum[-1]) == 0 and len(h.alt_edge_targets) == 4
+	full = HostGraph(fa, vcf, "1")
+	assert int(full.ploidy_csum[-1]) == 1 and len(full.alt_edge_targets) == 4
+
+
 def test_malformed_input_is_an_error(HostGraph, tmp_path):
 	fa, vcf = synth.write_inputs(str(tmp_path), b"ACGTACGT", [(5, b"C", [b"T"], np.array([[1, 0]])), (2, b"G", [b"T"], np.array([[1, 0]]))], 1)
 	with pytest.raises(ValueError):

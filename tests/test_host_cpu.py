@@ -205,6 +205,128 @@ def test_traffic_is_quoted_only_for_the_sources_it_was_measured_on():
 			assert set(r["kernel_sources"]) == set(bench.KERNEL_SOURCES), name
 
 
+def test_every_quoted_include_is_a_build_dependency_and_a_stamped_kernel_source():
+	"""The library is rebuilt for -- and a PMC traffic figure is tied to -- every file v2m_hip.hip reaches through #include "...":
+	the lists are read off the sources (build.include_closure), so a header cannot be forgotten again (round 3: founder_kernels.hpp)."""
+	import sys
+	from vcf2multialign_amd import build
+	sys.path.insert(0, ROOT)
+	import bench
+	csrc = os.path.join(ROOT, "vcf2multialign_amd", "csrc")
+	quoted = re.compile(r'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', re.M)
+	def reach(path, seen):
+		path = os.path.normpath(path)
+		if path in seen:
+			return seen
+		seen.add(path)
+		with open(path) as f:
+			for inc in quoted.findall(f.read()):
+				reach(os.path.join(os.path.dirname(path), inc), seen)
+		return seen
+	for sources, deps in ((build.HIP_SOURCES, build.HIP_DEPS), (build.HOST_SOURCES, build.HOST_DEPS), (build.SYNTH_SOURCES, build.SYNTH_DEPS), (build.CLI_SOURCES, build.CLI_DEPS)):
+		want = set()
+		for src in sources:
+			reach(src, want)
+		assert want <= set(deps), sorted(want - set(deps))
+	hip = {os.path.relpath(p, ROOT) for p in build.HIP_DEPS}
+	assert os.path.join("vcf2multialign_amd", "csrc", "founder_kernels.hpp") in hip and os.path.join("vcf2multialign_amd", "csrc", "kernels.hpp") in hip
+	assert set(bench.KERNEL_SOURCES) == hip
+	# every header under csrc/ belongs to some target: none is an orphan that a list could miss
+	every = set(build.HIP_DEPS) | set(build.HOST_DEPS) | set(build.SYNTH_DEPS) | set(build.CLI_DEPS)
+	for dirpath, _, files in os.walk(csrc):
+		for fn in files:
+			if fn.endswith((".hpp", ".hh", ".h")):
+				assert os.path.join(dirpath, fn) in every, fn + " is included by nothing that is built"
+
+
+def test_a_stale_library_is_noticed_through_any_header(tmp_path):
+	from vcf2multialign_amd import build
+	target = tmp_path / "lib.so"
+	target.write_bytes(b"")
+	old = os.path.getmtime(str(target)) - 1000
+	for dep in build.HIP_DEPS:
+		assert os.path.exists(dep)
+	os.utime(str(target), (old - 10 ** 9, old - 10 ** 9))          # older than every source
+	assert build._stale(str(target), build.HIP_DEPS)
+	header = tmp_path / "founder_kernels.hpp"
+	header.write_text("// stand-in")
+	os.utime(str(target), None)
+	os.utime(str(header), (old, old))
+	assert not build._stale(str(target), [str(header)])
+	os.utime(str(header), (os.path.getmtime(str(target)) + 5, os.path.getmtime(str(target)) + 5))
+	assert build._stale(str(target), [str(header)])
+
+
+def _clean_env():
+	return {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "V2M_BENCH_HUB")}
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_hub_over_pipes(n):
+	"""`python bench.py --gpus N` as typed: the parent is the ranks' hub (barriers + one gather over pipes), with no torch.distributed
+	group at all.  --hub-selftest runs exactly that plumbing with no GPU work."""
+	import json
+	import subprocess
+	import sys
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--hub-selftest"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=_clean_env())
+	assert r.returncode == 0, r.stderr.decode()[-2000:]
+	lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+	assert len(lines) == 1
+	d = json.loads(lines[0])
+	assert [f["rank"] for f in d["hub_selftest"]] == list(range(n)) and len({f["pid"] for f in d["hub_selftest"]}) == n
+	assert "no torch.distributed" in d["ranks_coordinated_by"]
+	with open(os.path.join(ROOT, "bench.py")) as f:
+		text = f.read()
+	hub = text[text.index("class PipeHub"):text.index("class TorchHub")] + text[text.index("def launch_ranks"):text.index("class SoloHub")]
+	assert "import torch" not in hub and "dist." not in hub.replace("torch.distributed.", "") and "init_process_group" not in hub
+
+
+def test_bench_hub_under_torch_distributed_run():
+	"""The driver's launch form, world size 2 on CPU: the same barrier / gather through a gloo group."""
+	import json
+	import subprocess
+	import sys
+	r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+		os.path.join(ROOT, "bench.py"), "--gpus", "2", "--hub-selftest"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=_clean_env())
+	assert r.returncode == 0, r.stderr.decode()[-2000:]
+	lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+	assert len(lines) == 1
+	d = json.loads(lines[0])
+	assert [f["rank"] for f in d["hub_selftest"]] == [0, 1] and "torch.distributed (gloo)" in d["ranks_coordinated_by"]
+
+
+def test_checksum_sink_of_the_end_to_end_leg(v2m):
+	"""bench.py's end-to-end sink (libv2m_synth.so: v2ms_checksum_sink_fn) computes the checksum of include/v2m_hip.h for rows of
+	every length class, whatever the number of threads it cuts a row over."""
+	import ctypes as C
+	from vcf2multialign_amd import build
+	sl = C.CDLL(build.SYNTH_LIB_PATH)
+	sl.v2ms_checksum_sink_create.restype = C.c_void_p
+	sl.v2ms_checksum_sink_create.argtypes = [C.c_uint64, C.c_uint32]
+	sl.v2ms_checksum_sink_fn.argtypes = [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64]
+	sl.v2ms_checksum_sink_fn.restype = C.c_int
+	sl.v2ms_checksum_sink_checksums.restype = C.POINTER(C.c_uint64)
+	sl.v2ms_checksum_sink_checksums.argtypes = [C.c_void_p]
+	sl.v2ms_checksum_sink_lengths.restype = C.POINTER(C.c_uint64)
+	sl.v2ms_checksum_sink_lengths.argtypes = [C.c_void_p]
+	sl.v2ms_checksum_sink_rows.restype = C.c_uint64
+	sl.v2ms_checksum_sink_rows.argtypes = [C.c_void_p]
+	sl.v2ms_checksum_sink_destroy.argtypes = [C.c_void_p]
+	rng = np.random.default_rng(7)
+	rows = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (0, 1, 7, 8, 9, 63, 64, 1000, 100003, 3_000_001)]
+	want = v2m.checksum_rows_host(rows).tolist()
+	for threads in (1, 2, 5, 16):
+		s = sl.v2ms_checksum_sink_create(len(rows), threads)
+		for rep in range(3):            # the pool is reused row after row
+			for i, body in enumerate(rows):
+				assert sl.v2ms_checksum_sink_fn(s, i, body, len(body)) == 0
+		assert sl.v2ms_checksum_sink_fn(s, len(rows), b"", 0) != 0     # a row index beyond the capacity is refused
+		assert [sl.v2ms_checksum_sink_checksums(s)[i] for i in range(len(rows))] == want
+		assert [sl.v2ms_checksum_sink_lengths(s)[i] for i in range(len(rows))] == [len(b) for b in rows]
+		assert sl.v2ms_checksum_sink_rows(s) == 3 * len(rows)
+		sl.v2ms_checksum_sink_destroy(s)
+
+
 def test_ring_transpose_indexing_model():
 	"""tools/ring_transpose_model.py: the ring transpose kernel's slot / flush / window indexing, replayed on the CPU, writes
 	every destination word exactly once with the right value on awkward shapes (the GPU suite then checks the real kernel)."""
@@ -244,7 +366,7 @@ def test_bench_as_typed_starts_child_ranks_and_relays_their_failure():
 	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
 	if os.path.exists("/dev/kfd"):
 		pytest.skip("a GPU is present: the working path is covered by tests/test_gpu_bench.py")
-	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "mini3", "--dist-backend", "gloo"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "mini3"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=env)
 	assert r.returncode != 0 and not r.stdout.strip()
 	assert b"rank 0 -> exit" in r.stderr and b"rank 1 -> exit" in r.stderr
 	with open(os.path.join(ROOT, "bench.py")) as f:

@@ -11,6 +11,7 @@ hipcc cross-compiles for gfx950 without a GPU present.
 import contextlib
 import fcntl
 import os
+import re
 import shutil
 import subprocess
 
@@ -19,15 +20,38 @@ ROOT = os.path.dirname(PKG_DIR)
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libv2m_hip.so")
 
+_QUOTED_INCLUDE = re.compile(r'^[ \t]*#[ \t]*include[ \t]*"([^"]+)"', re.M)
+
+
+def include_closure(sources):
+	"""The sources plus every file they reach through `#include "..."`, transitively: what a target has to be rebuilt for.
+	Read off the files themselves so that a new header cannot be forgotten (round 3 shipped a library older than
+	founder_kernels.hpp because a hand-kept list did not name it)."""
+	seen, todo = [], [os.path.normpath(s) for s in sources]
+	while todo:
+		path = todo.pop()
+		if path in seen:
+			continue
+		seen.append(path)
+		with open(path, errors="replace") as f:
+			text = f.read()
+		for inc in _QUOTED_INCLUDE.findall(text):
+			dep = os.path.normpath(os.path.join(os.path.dirname(path), inc))
+			if not os.path.exists(dep):
+				raise RuntimeError('%s includes "%s", which does not exist' % (path, inc))
+			todo.append(dep)
+	return sorted(seen)
+
+
 HIP_SOURCES = [os.path.join(CSRC, "v2m_hip.hip")]
-HIP_DEPS = HIP_SOURCES + [os.path.join(CSRC, "kernels.hpp"), os.path.join(ROOT, "include", "v2m_hip.h")]
+HIP_DEPS = include_closure(HIP_SOURCES)
 HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wextra"]
 TUNING_LIB_PATH = os.path.join(PKG_DIR, "libv2m_hip_tuning.so")
 
 # synthetic-input generator (bench + scale tests): host generator + the HIP kernel filling genotype bits
 SYNTH_LIB_PATH = os.path.join(PKG_DIR, "libv2m_synth.so")
 SYNTH_SOURCES = [os.path.join(CSRC, "synth", "synth_capi.hip"), os.path.join(CSRC, "synth", "synth.cc"), os.path.join(CSRC, "host", "graph_builder.cc")]
-SYNTH_DEPS = SYNTH_SOURCES + [os.path.join(CSRC, "synth", "synth.hh"), os.path.join(CSRC, "host", "graph_builder.hh"), os.path.join(CSRC, "host", "variant_graph.hh")]
+SYNTH_DEPS = include_closure(SYNTH_SOURCES)
 
 
 def find_hipcc():
@@ -48,9 +72,10 @@ def _stale(target, deps):
 HOST_LIB_PATH = os.path.join(PKG_DIR, "libv2m_host.so")
 HOST_DIR = os.path.join(CSRC, "host")
 HOST_SOURCES = [os.path.join(HOST_DIR, f) for f in ("graph_builder.cc", "readers.cc", "gpu_path.cc", "output.cc", "founder.cc", "graph_file.cc", "host_capi.cc")]
-HOST_DEPS = HOST_SOURCES + [os.path.join(HOST_DIR, f) for f in ("graph_builder.hh", "readers.hh", "gpu_path.hh", "output.hh", "founder.hh", "graph_file.hh", "variant_graph.hh")] + [os.path.join(ROOT, "include", "v2m_hip.h")]
+HOST_DEPS = include_closure(HOST_SOURCES)
 CLI_PATH = os.path.join(PKG_DIR, "bin", "vcf2multialign")
 CLI_SOURCES = [os.path.join(HOST_DIR, "main.cc")]
+CLI_DEPS = include_closure(CLI_SOURCES)
 CXX_FLAGS = ["-O2", "-g", "-std=c++20", "-Wall", "-Wextra"]
 
 
@@ -86,7 +111,7 @@ def _build_host(force, verbose):
 		raise RuntimeError("g++ not found")
 	if force or _stale(HOST_LIB_PATH, HOST_DEPS + [LIB_PATH]):
 		_link([cxx] + CXX_FLAGS + ["-fPIC", "-shared"], HOST_LIB_PATH, HOST_SOURCES + ["-L" + PKG_DIR, "-lv2m_hip", "-Wl,-rpath,$ORIGIN"], verbose)
-	if force or _stale(CLI_PATH, CLI_SOURCES + HOST_DEPS + [HOST_LIB_PATH]):
+	if force or _stale(CLI_PATH, CLI_DEPS + HOST_DEPS + [HOST_LIB_PATH]):
 		os.makedirs(os.path.dirname(CLI_PATH), exist_ok=True)
 		_link([cxx] + CXX_FLAGS, CLI_PATH, CLI_SOURCES + ["-L" + PKG_DIR, "-lv2m_host", "-lv2m_hip", "-Wl,-rpath,$ORIGIN/.."], verbose)
 

@@ -913,11 +913,14 @@ bool find_matchings_walked(
 	for (std::size_t j(0); j < n_cuts; ++j) cut_edge[j] = u32(graph.alt_edge_count_csum[cut_positions[j]]);
 
 	// start states: the cut search's if it has just run on this graph, else one every 8192 edges
-	if (walker.state_edge.empty() || walker.state_copies != copies || 0 != walker.state_edge.front()) {
+	if (walker.state_edge.empty() || walker.state_copies != copies || 0 != walker.state_edge.front()
+		|| walker.state_edges != n_edges || walker.state_matrix != static_cast<void const *>(graph.paths_by_chrom_copy_and_edge.words.data())) {
 		walker.state_edge.clear();
 		for (u64 e(0); e < std::max<u64>(1, n_edges); e += 8192) walker.state_edge.push_back(u32(e));
 		build_states(graph, walker.state_edge, threads, walker.state_order, walker.state_divergence);
 		walker.state_copies = copies;
+		walker.state_edges = n_edges;
+		walker.state_matrix = graph.paths_by_chrom_copy_and_edge.words.data();
 	}
 	timer.mark("matching: start states");
 	std::size_t const n_chunks(walker.state_edge.size());
@@ -1320,6 +1323,8 @@ u32 find_cut_positions_walked(variant_graph const &graph, u64 min_distance, std:
 	walker.state_order = std::move(start_order);
 	walker.state_divergence = std::move(start_div);
 	walker.state_copies = copies;
+	walker.state_edges = graph.edge_count();
+	walker.state_matrix = graph.paths_by_chrom_copy_and_edge.words.data();
 	return collect_cut_positions(cuts, graph, out);
 }
 

@@ -64,6 +64,10 @@ struct founder_walker {
 	std::vector<u32> state_edge;
 	std::unique_ptr<u32[]> state_order, state_divergence;
 	u64 state_copies{};
+	// which graph the states were built for: its edge count and the address of its transposed matrix's words (a walker reused on
+	// another graph with as many copies must not start from the first one's states)
+	u64 state_edges{};
+	void const *state_matrix{};
 };
 typedef founder_walker cut_trial_walker;
 

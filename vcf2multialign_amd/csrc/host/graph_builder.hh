@@ -12,6 +12,10 @@
 #include <string_view>
 #include <vector>
 
+#include <algorithm>
+#include <new>
+#include <stdexcept>
+
 #include "variant_graph.hh"
 
 namespace v2m::host {
@@ -71,10 +75,18 @@ public:
 
 	// A hint, after begin(): about this many ALT edges are coming.  The path matrix grows by doubling (:368-376 grows it by 2048
 	// columns at a time); with its final size reserved the doublings no longer copy it (config 3: 632 MB, 0.3 s of the merge stage).
+	// The hint may be far off (a multi-chromosome VCF filtered to one chromosome: the caller's estimate counts every record), so it
+	// is capped -- 8 GiB, more than the config-5 matrix needs -- and a reserve that fails is simply not made: growth by doubling
+	// builds the same matrix.
 	void expect_edges(u64 n_edges)
 	{
 		auto &m(m_graph.paths_by_edge_and_chrom_copy);
-		if (m_track_paths && m.rows) m.words.reserve(m.rows / 64 * (m_path_alignment * ((n_edges + m_path_alignment - 1) / m_path_alignment)));
+		if (!m_track_paths || !m.rows) return;
+		u64 const words(m.rows / 64 * (m_path_alignment * ((n_edges + m_path_alignment - 1) / m_path_alignment)));
+		u64 const cap_words((u64(8) << 30) / sizeof(u64));
+		try { m.words.reserve(std::min(words, cap_words)); }
+		catch (std::bad_alloc const &) {}
+		catch (std::length_error const &) {}
 	}
 
 private:

@@ -227,23 +227,28 @@ uint64_t v2mh_find_founders_gpu(void *h, void *ctx, uint64_t min_distance, uint3
 // The walked searches with the chunk walks done by the host's own edge-by-edge walker (founder.hh: make_host_founder_walker):
 // the plumbing of find_cut_positions_walked / find_matchings_walked without a GPU.  chunks as in v2mh_find_founders_gpu.
 uint64_t v2mh_find_founders_walked_on_host(void *h, uint64_t min_distance, uint32_t founder_count, int keep_ref_edges, unsigned threads, uint64_t max_copies,
-	uint64_t *cuts_out, uint32_t *assigned_out, uint64_t assigned_capacity, uint32_t *score_out, uint64_t *chunks)
+	uint64_t *cuts_out, uint32_t *assigned_out, uint64_t assigned_capacity, uint32_t *score_out, uint64_t *chunks, char *err, size_t errlen)
 {
-	auto const &g(HG(h).graph);
-	auto walker(vh::make_host_founder_walker(g, max_copies));
-	std::vector<vh::u64> cuts;
-	vh::u32 const score(vh::find_cut_positions(g, min_distance, cuts, threads, walker.get()));
-	if (chunks) { chunks[0] = walker->chunks_walked; chunks[1] = walker->chunks_left; }
-	if (score_out) *score_out = score;
-	if (vh::kCutPositionScoreMax == score) return 0;
-	std::vector<vh::u32> assigned;
-	walker->chunks_walked = walker->chunks_left = 0;
-	if (!vh::find_matchings(g, cuts, founder_count, 0 != keep_ref_edges, assigned, threads, walker.get())) return 0;
-	if (chunks) { chunks[2] = walker->chunks_walked; chunks[3] = walker->chunks_left; }
-	if (assigned.size() > assigned_capacity) return 0;
-	std::copy(cuts.begin(), cuts.end(), cuts_out);
-	std::copy(assigned.begin(), assigned.end(), assigned_out);
-	return cuts.size();
+	try {
+		auto const &g(HG(h).graph);
+		auto walker(vh::make_host_founder_walker(g, max_copies));
+		std::vector<vh::u64> cuts;
+		vh::u32 const score(vh::find_cut_positions(g, min_distance, cuts, threads, walker.get()));
+		if (chunks) { chunks[0] = walker->chunks_walked; chunks[1] = walker->chunks_left; }
+		if (score_out) *score_out = score;
+		if (vh::kCutPositionScoreMax == score) return 0;
+		std::vector<vh::u32> assigned;
+		walker->chunks_walked = walker->chunks_left = 0;
+		if (!vh::find_matchings(g, cuts, founder_count, 0 != keep_ref_edges, assigned, threads, walker.get())) return 0;
+		if (chunks) { chunks[2] = walker->chunks_walked; chunks[3] = walker->chunks_left; }
+		if (assigned.size() > assigned_capacity) return 0;
+		std::copy(cuts.begin(), cuts.end(), cuts_out);
+		std::copy(assigned.begin(), assigned.end(), assigned_out);
+		return cuts.size();
+	} catch (std::exception const &e) {      // nothing may cross the C boundary (an exception would end the caller's process)
+		if (err && errlen) { std::strncpy(err, e.what(), errlen - 1); err[errlen - 1] = 0; }
+		return 0;
+	}
 }
 
 uint64_t v2mh_find_founders(void *h, uint64_t min_distance, uint32_t founder_count, int keep_ref_edges,

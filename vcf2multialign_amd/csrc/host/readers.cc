@@ -531,7 +531,9 @@ void build_variant_graph(
 			u64 const n_columns(n_merged < chunk.records.size() ? chunk.records[n_merged].first_column : chunk.n_columns);
 			if (graph.edge_count() - first_edge != n_columns) throw std::logic_error("VCF reader: the builder made other edges than the parser counted");
 			auto &m(graph.paths_by_edge_and_chrom_copy);
-			if (n_columns) {
+			// (no chromosome copy included -- every sample excluded: the matrix has no rows, graph_builder grows no columns for it,
+			// and there is nothing to copy; the edge count above is still checked)
+			if (n_columns && ctx.words_per_column) {
 				if (m.cols < first_edge + n_columns || m.words_per_column() != ctx.words_per_column) throw std::logic_error("VCF reader: the path matrix is not what the parser filled its slice for");
 				std::memcpy(m.words.data() + first_edge * ctx.words_per_column, chunk.bits.data(), n_columns * ctx.words_per_column * sizeof(u64));
 			}

@@ -5,9 +5,14 @@
 
 #include <unistd.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 #include "synth.hh"
 
@@ -130,5 +135,133 @@ int v2ms_fd_sink(void *user, uint64_t row, char const *bytes, uint64_t length)
 	}
 	return 1 == ::write(st->fd, "\n", 1) ? 0 : 1;
 }
+
+
+
+// A second C sink for bench.py's end-to-end leg: discards every row AFTER reading all of it -- the checksum of
+// v2m_checksum_rows_device (include/v2m_hip.h) of every row body as it arrives in the library's pinned slot, so that what
+// crossed the link can be compared with the CPU oracle's rows.  A row has to be consumed before the sink returns (the slot
+// is the library's), and one core checksums ~6 GB/s against the link's 55, so the row is cut into parts for a small pool
+// of threads that live as long as the sink (the parts' sums add up: the checksum is a sum over (index, word)).
+struct v2ms_checksum_sink {
+	std::vector <uint64_t> checksums, lengths;
+	uint64_t rows{}, bytes{};
+	std::vector <std::thread> workers;
+	std::mutex mutex;
+	std::condition_variable wake, finished;
+	uint64_t generation{};
+	bool stopping{};
+	char const *row_bytes{};
+	uint64_t row_words{}, tail_word{};   // whole words; the zero-padded last word when the length is not a multiple of 8
+	std::atomic <uint64_t> next_part{}, sum{};
+	uint64_t parts{}, parts_done{};
+	unsigned active{};                   // workers inside run_parts(): the next row is only set up once none is
+
+	static uint64_t mix64(uint64_t z) { z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31; return z; }
+
+	void run_parts()
+	{
+		uint64_t const per_part((row_words + parts - 1) / parts);
+		uint64_t local(0), done(0);
+		for (;;) {
+			uint64_t const p(next_part.fetch_add(1, std::memory_order_relaxed));
+			if (p >= parts) break;
+			uint64_t const k0(p * per_part), k1(k0 + per_part < row_words ? k0 + per_part : row_words);
+			uint64_t acc(0);
+			for (uint64_t k(k0); k < k1; ++k) {
+				uint64_t w;
+				std::memcpy(&w, row_bytes + 8 * k, 8);
+				acc += mix64((k + 1) * 0x9E3779B97F4A7C15ULL ^ w);
+			}
+			local += acc;
+			++done;
+		}
+		if (done) {
+			sum.fetch_add(local, std::memory_order_relaxed);
+			std::lock_guard <std::mutex> lock(mutex);
+			parts_done += done;
+			if (parts_done == parts) finished.notify_all();
+		}
+	}
+
+	void worker()
+	{
+		uint64_t seen(0);
+		for (;;) {
+			{
+				std::unique_lock <std::mutex> lock(mutex);
+				wake.wait(lock, [&]{ return stopping || generation != seen; });
+				if (stopping) return;
+				seen = generation;
+				++active;
+			}
+			run_parts();
+			std::lock_guard <std::mutex> lock(mutex);
+			if (0 == --active) finished.notify_all();
+		}
+	}
+};
+
+void *v2ms_checksum_sink_create(uint64_t capacity_rows, uint32_t threads)
+{
+	auto *s(new v2ms_checksum_sink);
+	s->checksums.assign(capacity_rows, 0);
+	s->lengths.assign(capacity_rows, 0);
+	for (uint32_t i(1); i < threads; ++i)
+		s->workers.emplace_back([s]{ s->worker(); });
+	return s;
+}
+
+void v2ms_checksum_sink_destroy(void *user)
+{
+	auto *s(static_cast<v2ms_checksum_sink *>(user));
+	{
+		std::lock_guard <std::mutex> lock(s->mutex);
+		s->stopping = true;
+	}
+	s->wake.notify_all();
+	for (auto &t : s->workers) t.join();
+	delete s;
+}
+
+// a v2m_sink_fn; `user` is what v2ms_checksum_sink_create returned
+int v2ms_checksum_sink_fn(void *user, uint64_t row, char const *bytes, uint64_t length)
+{
+	auto *s(static_cast<v2ms_checksum_sink *>(user));
+	if (row >= s->checksums.size()) return 1;
+	s->row_bytes = bytes;
+	s->row_words = length / 8;
+	s->sum.store(0, std::memory_order_relaxed);
+	s->next_part.store(0, std::memory_order_relaxed);
+	s->parts = s->row_words ? 4 * (s->workers.size() + 1) : 0;
+	if (s->parts) {
+		{
+			std::lock_guard <std::mutex> lock(s->mutex);
+			s->parts_done = 0;
+			++s->generation;
+		}
+		s->wake.notify_all();
+		s->run_parts();
+		std::unique_lock <std::mutex> lock(s->mutex);
+		s->finished.wait(lock, [&]{ return s->parts_done == s->parts && 0 == s->active; });
+	}
+	uint64_t acc(s->sum.load(std::memory_order_relaxed));
+	if (length % 8) {
+		uint64_t w(0);
+		std::memcpy(&w, bytes + 8 * s->row_words, length % 8);
+		acc += v2ms_checksum_sink::mix64((s->row_words + 1) * 0x9E3779B97F4A7C15ULL ^ w);
+	}
+	acc += v2ms_checksum_sink::mix64(length);
+	s->checksums[row] = acc;
+	s->lengths[row] = length;
+	++s->rows;
+	s->bytes += length;
+	return 0;
+}
+
+uint64_t v2ms_checksum_sink_rows(void *user) { return static_cast<v2ms_checksum_sink *>(user)->rows; }
+uint64_t v2ms_checksum_sink_bytes(void *user) { return static_cast<v2ms_checksum_sink *>(user)->bytes; }
+uint64_t const *v2ms_checksum_sink_checksums(void *user) { return static_cast<v2ms_checksum_sink *>(user)->checksums.data(); }
+uint64_t const *v2ms_checksum_sink_lengths(void *user) { return static_cast<v2ms_checksum_sink *>(user)->lengths.data(); }
 
 } // extern "C"

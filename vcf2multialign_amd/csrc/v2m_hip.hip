@@ -101,6 +101,10 @@ struct v2m_ctx {
 	dev_buf d_slice_src;     // v2m_upload_path_slice: the un-transposed slice (released after the transpose)
 	u64 path_rows{}, path_cols{};
 	u64 path_pitch{};        // words from one copy's column to the next (path_rows / 64 for caller-supplied matrices)
+	// founder search: the bound matrix transposed back to edge-major bits (paths_by_edge_and_chrom_copy), made by the first of the
+	// v2m_pbwt_* calls after a matrix is bound and kept for the following ones (one founder run makes two); dropped with the binding
+	dev_buf d_by_edge;
+	bool by_edge_valid{};
 
 	struct transpose_pick { u64 rows, cols, src_pitch, dst_pitch; std::string kernel; };
 	std::vector<transpose_pick> transpose_choice;   // per matrix shape: which transpose kernel measured fastest
@@ -1138,6 +1142,7 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 	V2M_HIP_TRY(ctx, hipGetLastError());
 
 	ctx->d_paths = nullptr;
+	ctx->by_edge_valid = false;
 	ctx->path_rows = ctx->path_cols = ctx->path_pitch = 0;
 	if (g->paths_by_chrom_copy_and_edge) {
 		size_t const bytes(g->path_rows / 64 * g->path_cols * sizeof(u64));
@@ -1166,6 +1171,7 @@ int v2m_set_paths_device(v2m_ctx *ctx, const void *d_words, uint64_t path_rows, 
 		return fail(ctx, V2M_ERR_PRECONDITION, "path matrix must be (>= edge_count) x copies with both dimensions multiples of 64");
 	if (path_rows && path_cols && (!d_words || ((uintptr_t) d_words & 7))) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "d_words must be a non-NULL 8-byte aligned device pointer");
 	ctx->d_paths = static_cast<u64 const *>(d_words);
+	ctx->by_edge_valid = false;
 	ctx->path_rows = path_rows;
 	ctx->path_cols = path_cols;
 	ctx->path_pitch = path_rows / 64;
@@ -1188,6 +1194,7 @@ int transpose_into_owned_paths(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n
 	// (the pad words between a column's n_cols / 64 words and its pitch are neither written here nor read by any kernel)
 	if (int const rc = launch_transpose(ctx, d_src, n_rows, n_cols, ctx->owned_paths.as<u64>(), src_pitch, pitch)) return rc;
 	ctx->d_paths = ctx->owned_paths.as<u64>();
+	ctx->by_edge_valid = false;
 	ctx->path_rows = n_cols;
 	ctx->path_cols = n_rows;
 	ctx->path_pitch = pitch;
@@ -1205,6 +1212,7 @@ int v2m_bind_path_matrix_device(v2m_ctx *ctx, const void *d_paths_by_edge_and_ch
 	if (n_cols < ctx->n_edges) return fail(ctx, V2M_ERR_PRECONDITION, "path matrix has %llu edge columns, the graph %llu edges", (unsigned long long) n_cols, (unsigned long long) ctx->n_edges);
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ctx->d_paths = nullptr;
+	ctx->by_edge_valid = false;
 	ctx->path_rows = ctx->path_cols = ctx->path_pitch = 0;
 	if (0 == n_rows || 0 == n_cols) return V2M_OK;
 	if (!d_paths_by_edge_and_chrom_copy || ((uintptr_t) d_paths_by_edge_and_chrom_copy & 7)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the matrix must be a non-NULL 8-byte aligned device pointer");
@@ -1232,6 +1240,7 @@ int v2m_upload_path_blocks(v2m_ctx *ctx, const uint64_t *src_words, uint64_t n_r
 	if (copy_end > n_rows) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "copies up to %llu are outside the matrix (%llu rows)", (unsigned long long) copy_end, (unsigned long long) n_rows);
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
 	ctx->d_paths = nullptr;
+	ctx->by_edge_valid = false;
 	ctx->path_rows = ctx->path_cols = ctx->path_pitch = 0;
 
 	// this GPU's copies: blocks j = 0, 1, ... at first_copy + j * stride_copies, the last one possibly cut short by copy_end
@@ -1305,6 +1314,31 @@ uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx) { return (ctx && ctx->has_
 
 namespace {
 
+// What both founder entry points ask of the ctx and of their start states, and the edge-major bits they walk.
+int pbwt_check_state(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_chunks, const uint32_t *start_order)
+{
+	if (0 == n_copies || n_copies > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk holds at most %d chromosome copies (got %llu)", v2m::kPbwtMaxCopies, (unsigned long long) n_copies);
+	if (n_copies > ctx->path_cols) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the bound path matrix has %llu copies, %llu asked for", (unsigned long long) ctx->path_cols, (unsigned long long) n_copies);
+	// (the kernels stage a whole edge column -- path_cols / 64 words -- in an LDS array sized for kPbwtMaxCopies)
+	if (ctx->path_cols > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk reads edge columns of at most %d copies; the bound path matrix has %llu columns", v2m::kPbwtMaxCopies, (unsigned long long) ctx->path_cols);
+	// the start order indexes the workgroup's state arrays in LDS
+	for (u64 i(0), n(n_chunks * n_copies); i < n; ++i)
+		if (start_order[i] >= n_copies) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "start_order[%llu] = %u is not a chromosome copy (%llu copies)", (unsigned long long) i, start_order[i], (unsigned long long) n_copies);
+	return V2M_OK;
+}
+
+int edge_major_paths(v2m_ctx *ctx, u64 const **d_by_edge_out)
+{
+	u64 const rows(ctx->path_rows), cols(ctx->path_cols);              // both multiples of 64
+	if (!ctx->by_edge_valid) {
+		V2M_HIP_TRY(ctx, ctx->d_by_edge.ensure(std::max<size_t>(16, rows * (cols / 64) * sizeof(u64))));
+		if (int const rc = launch_transpose(ctx, ctx->d_paths, rows, cols, ctx->d_by_edge.as<u64>(), ctx->path_pitch, 0)) return rc;
+		ctx->by_edge_valid = true;
+	}
+	*d_by_edge_out = ctx->d_by_edge.as<u64>();
+	return V2M_OK;
+}
+
 // v2m_pbwt_cut_trials (the pairs land in the caller's arrays) and v2m_pbwt_cut_trials_streamed (they pass through two pinned
 // slots and a callback takes them chunk by chunk while the next slice is on its way).
 int pbwt_cut_trials_impl(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
@@ -1318,18 +1352,22 @@ int pbwt_cut_trials_impl(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	if (0 == n_chunks) return V2M_OK;
 	if (!cand_edge || !cand_aligned_pos || !chunk_first || !start_order || !start_divergence || (!sink && (!trial_pred || !trial_class_count)) || !trial_end || !chunk_status)
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL array");
-	if (0 == n_copies || n_copies > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk holds at most %d chromosome copies (got %llu)", v2m::kPbwtMaxCopies, (unsigned long long) n_copies);
-	if (n_copies > ctx->path_cols) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the bound path matrix has %llu copies, %llu asked for", (unsigned long long) ctx->path_cols, (unsigned long long) n_copies);
+	if (int const rc = pbwt_check_state(ctx, n_copies, n_chunks, start_order)) return rc;
 	if (n_candidates >= 0xFFFFFFFFull || ctx->n_edges >= 0xFFFFFFFDull) return fail(ctx, V2M_ERR_UNSUPPORTED, "candidate and edge indices are kept in 32 bits");
 	if (chunk_first[0] < 1 || chunk_first[n_chunks] > n_candidates) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds outside the candidate list");
 	for (u64 k(0); k < n_chunks; ++k) if (chunk_first[k] > chunk_first[k + 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds must not decrease");
+	// the candidates as find_cut_positions.cc:126-151 makes them: one per distinct edge index, in node order (so both columns ascend)
+	for (u64 c(0); c < n_candidates; ++c) {
+		if (cand_edge[c] > ctx->n_edges || (c && cand_edge[c] <= cand_edge[c - 1])) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "candidate edges must ascend strictly and stay inside the graph (candidate %llu)", (unsigned long long) c);
+		if (c && cand_aligned_pos[c] < cand_aligned_pos[c - 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "candidate aligned positions must not decrease (candidate %llu)", (unsigned long long) c);
+	}
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
 
-	// edge-major bits: the bound matrix (rows = edges, columns = copies) transposed back on the device
-	u64 const rows(ctx->path_rows), cols(ctx->path_cols);              // both multiples of 64
-	dev_buf d_by_edge, d_first, d_cand_edge, d_cand_aln, d_chunk_first, d_order, d_div, d_pred, d_class, d_end, d_status;
-	V2M_HIP_TRY(ctx, d_by_edge.ensure(rows * (cols / 64) * sizeof(u64)));
-	if (int const rc = launch_transpose(ctx, ctx->d_paths, rows, cols, d_by_edge.as<u64>(), ctx->path_pitch, 0)) return rc;
+	// edge-major bits: the bound matrix (rows = edges, columns = copies) transposed back on the device, once per binding
+	u64 const cols(ctx->path_cols);
+	u64 const *d_by_edge(nullptr);
+	if (int const rc = edge_major_paths(ctx, &d_by_edge)) return rc;
+	dev_buf d_first, d_cand_edge, d_cand_aln, d_chunk_first, d_order, d_div, d_pred, d_class, d_end, d_status;
 
 	auto const up([&](dev_buf &dst, void const *src, size_t bytes) -> int {
 		V2M_HIP_TRY(ctx, dst.ensure(std::max<size_t>(bytes, 16)));
@@ -1351,7 +1389,7 @@ int pbwt_cut_trials_impl(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	hipLaunchKernelGGL(v2m::pbwt_first_candidate_kernel, dim3(unsigned((u64(n_edges) + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
 		d_cand_edge.as<u32>(), u32(n_candidates), n_edges, d_first.as<u32>());
 	hipLaunchKernelGGL(v2m::pbwt_cut_trials_kernel, dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
-		d_by_edge.as<u64>(), u32(cols / 64), u32(n_copies), n_edges, d_first.as<u32>(), d_cand_edge.as<u32>(), d_cand_aln.as<u64>(), min_distance,
+		d_by_edge, u32(cols / 64), u32(n_copies), n_edges, d_first.as<u32>(), d_cand_edge.as<u32>(), d_cand_aln.as<u64>(), min_distance,
 		d_chunk_first.as<u64>(), d_order.as<u32>(), d_div.as<u32>(), trial_capacity, d_pred.as<u32>(), d_class.as<u32>(), d_end.as<u64>(), d_status.as<u32>());
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
@@ -1456,20 +1494,19 @@ int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const
 	if (!cut_edge || !chunk_first_cut || !start_edge || !start_order || !start_divergence || !pool_lhs || !pool_rhs || !pool_size
 		|| !rec_pool_end || !rec_distinct || !rec_first_class || !rec_first_is_ref || !chunk_status)
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL array");
-	if (0 == n_copies || n_copies > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk holds at most %d chromosome copies (got %llu)", v2m::kPbwtMaxCopies, (unsigned long long) n_copies);
-	if (n_copies > ctx->path_cols) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the bound path matrix has %llu copies, %llu asked for", (unsigned long long) ctx->path_cols, (unsigned long long) n_copies);
+	if (int const rc = pbwt_check_state(ctx, n_copies, n_chunks, start_order)) return rc;
 	if (chunk_first_cut[0] < 1 || chunk_first_cut[n_chunks] > n_cuts) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds outside the cut list");
 	for (u64 k(0); k < n_chunks; ++k) {
 		if (chunk_first_cut[k] > chunk_first_cut[k + 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds must not decrease");
 		if (chunk_first_cut[k] < chunk_first_cut[k + 1] && start_edge[k] > cut_edge[chunk_first_cut[k] - 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk %llu: the start state lies past the cut before its first one", (unsigned long long) k);
 	}
-	for (u64 j(1); j < n_cuts; ++j) if (cut_edge[j] < cut_edge[j - 1] || cut_edge[j] > ctx->n_edges) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut edges must ascend and stay inside the graph");
+	for (u64 j(0); j < n_cuts; ++j) if ((j && cut_edge[j] < cut_edge[j - 1]) || cut_edge[j] > ctx->n_edges) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut edges must ascend and stay inside the graph");
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
 
 	u64 const rows(ctx->path_rows), cols(ctx->path_cols);
-	dev_buf d_by_edge, d_cut_edge, d_chunk_first, d_start_edge, d_order, d_div, d_lhs, d_rhs, d_size, d_end, d_distinct, d_first, d_ref, d_status;
-	V2M_HIP_TRY(ctx, d_by_edge.ensure(rows * (cols / 64) * sizeof(u64)));
-	if (int const rc = launch_transpose(ctx, ctx->d_paths, rows, cols, d_by_edge.as<u64>(), ctx->path_pitch, 0)) return rc;
+	u64 const *d_by_edge(nullptr);
+	if (int const rc = edge_major_paths(ctx, &d_by_edge)) return rc;
+	dev_buf d_cut_edge, d_chunk_first, d_start_edge, d_order, d_div, d_lhs, d_rhs, d_size, d_end, d_distinct, d_first, d_ref, d_status;
 	auto const up([&](dev_buf &dst, void const *src, size_t bytes) -> int {
 		V2M_HIP_TRY(ctx, dst.ensure(std::max<size_t>(bytes, 16)));
 		if (bytes) V2M_HIP_TRY(ctx, hipMemcpyAsync(dst.p, src, bytes, hipMemcpyHostToDevice, ctx->stream));
@@ -1491,7 +1528,7 @@ int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const
 	V2M_HIP_TRY(ctx, d_status.ensure(n_chunks * sizeof(u32)));
 	V2M_HIP_TRY(ctx, hipMemsetAsync(d_status.p, 0xFF, n_chunks * sizeof(u32), ctx->stream));
 	hipLaunchKernelGGL(v2m::pbwt_cut_records_kernel, dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
-		d_by_edge.as<u64>(), u32(cols / 64), u32(n_copies), u32(rows), d_cut_edge.as<u32>(), d_chunk_first.as<u64>(), d_start_edge.as<u32>(), d_order.as<u32>(), d_div.as<u32>(),
+		d_by_edge, u32(cols / 64), u32(n_copies), u32(rows), d_cut_edge.as<u32>(), d_chunk_first.as<u64>(), d_start_edge.as<u32>(), d_order.as<u32>(), d_div.as<u32>(),
 		pool_capacity, d_lhs.as<u32>(), d_rhs.as<u32>(), d_size.as<u32>(), d_end.as<u64>(), d_distinct.as<u32>(), d_first.as<u32>(), d_ref.as<u32>(), d_status.as<u32>());
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));

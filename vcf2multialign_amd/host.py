@@ -221,15 +221,18 @@ class HostGraph:
 		its kernels, testable without a GPU.  self.gpu_chunks = chunks (search: walked, handed back; matching: walked, handed back)."""
 		L = _load()
 		L.v2mh_find_founders_walked_on_host.restype = C.c_uint64
-		L.v2mh_find_founders_walked_on_host.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_void_p]
+		L.v2mh_find_founders_walked_on_host.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint32), C.c_void_p, C.c_char_p, C.c_size_t]
 		n = len(self.reference_positions)
 		cuts = np.zeros(n, dtype=np.uint64)
 		assigned = np.zeros(max(1, n * founder_count), dtype=np.uint32)
 		score = C.c_uint32()
 		chunks = (C.c_uint64 * 4)()
-		k = L.v2mh_find_founders_walked_on_host(self._h, min_distance, founder_count, int(keep_ref_edges), threads, max_copies, cuts.ctypes.data, assigned.ctypes.data, assigned.size, C.byref(score), chunks)
+		err = C.create_string_buffer(512)
+		k = L.v2mh_find_founders_walked_on_host(self._h, min_distance, founder_count, int(keep_ref_edges), threads, max_copies, cuts.ctypes.data, assigned.ctypes.data, assigned.size, C.byref(score), chunks, err, len(err))
 		self.gpu_chunks = tuple(int(x) for x in chunks)
 		if k == 0:
+			if err.value:
+				raise RuntimeError(err.value.decode())
 			return None
 		return cuts[:k].tolist(), assigned[:(k - 1) * founder_count].tolist(), score.value
 
