@@ -247,8 +247,13 @@ uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx);
  * prefixes plus their divergence values; csrc/host/founder.cc builds it from the transposed matrix).  One workgroup walks
  * one chunk; the score updates of find_cut_positions.cc:55-63, which depend on each other, stay with the caller.
  *
- * The ctx must hold the uploaded graph WITH its path matrix (v2m_upload_graph with paths_by_chrom_copy_and_edge): the call
- * transposes it back to edge-major bits on the device.  n_copies <= 8192 (V2M_ERR_UNSUPPORTED beyond).
+ * The ctx must hold the uploaded graph WITH its path matrix (v2m_upload_graph with paths_by_chrom_copy_and_edge): the first
+ * v2m_pbwt_* call after a matrix is bound transposes it back to edge-major bits on the device, and that copy (as large as the
+ * matrix) is kept for the following calls until the matrix is bound anew or the ctx is destroyed -- one founder run makes two.
+ * n_copies <= 8192 and a bound matrix of at most 8192 copy columns (V2M_ERR_UNSUPPORTED beyond: a workgroup keeps the pBWT state
+ * and one edge column in LDS).  V2M_ERR_INVALID_ARGUMENT for candidate edges that decrease or lie outside the graph, aligned
+ * positions that decrease (find_cut_positions.cc:129,151) and start_order entries >= n_copies -- checked on the host before any
+ * kernel indexes with them.
  *   cand_edge[c], cand_aligned_pos[c]   of all n_candidates candidates: the index of the node's first ALT edge (ascending, one
  *                                       candidate per distinct edge index, :129) and the node's aligned position (:151)
  *   chunk_first[k] .. chunk_first[k+1]  the candidates of chunk k (n_chunks + 1 entries, ascending, chunk_first[0] >= 1)
@@ -288,7 +293,8 @@ int v2m_pbwt_cut_trials_streamed(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_d
  * Outputs (host): per chunk up to pool_capacity joined classes at pool_lhs / pool_rhs / pool_size + k * pool_capacity
  * (0xFFFFFFFF = PLOIDY_MAX, "no class"); per cut j >= 1 rec_pool_end[j] (the chunk's joined classes up to and including cut j),
  * rec_distinct[j], rec_first_class[j], rec_first_is_ref[j]; chunk_status[k] = 0, or 1 when the chunk was left undone
- * (pool_capacity exceeded).  Same requirements on the ctx as v2m_pbwt_cut_trials.  Synchronous. */
+ * (pool_capacity exceeded).  Same requirements on the ctx and the start states as v2m_pbwt_cut_trials; cut edges that decrease or
+ * lie outside the graph are V2M_ERR_INVALID_ARGUMENT.  Synchronous. */
 int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const uint32_t *cut_edge,
 	uint64_t n_chunks, const uint64_t *chunk_first_cut, const uint32_t *start_edge, const uint32_t *start_order, const uint32_t *start_divergence,
 	uint64_t pool_capacity, uint32_t *pool_lhs, uint32_t *pool_rhs, uint32_t *pool_size,

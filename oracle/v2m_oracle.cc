@@ -1226,7 +1226,61 @@ std::uint64_t v2mo_row_checksum(
 	std::uint64_t *length_out
 )
 {
-	std::ostringstream os;
+	// output_sequence() writes into a stream whose buffer folds the bytes into the checksum as they arrive (a 100-250 MB row is never
+	// held: sixteen threads each growing a string of that size spent their time in the allocator, not in the walk)
+	class checksum_streambuf final : public std::streambuf {
+	public:
+		checksum_streambuf() { setp(m_buf, m_buf + sizeof(m_buf)); }
+		std::uint64_t finish(std::uint64_t &length)
+		{
+			take(true);
+			length = m_total;
+			return m_acc + mix64(m_total);
+		}
+	private:
+		static std::uint64_t mix64(std::uint64_t z)
+		{
+			z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
+			z ^= z >> 27; z *= 0x94D049BB133111EBULL;
+			z ^= z >> 31;
+			return z;
+		}
+		// whole 8-byte little-endian words of what has been written so far; the (< 8) bytes left over move to the front, and at
+		// the row's end they make the last word, zero padded
+		void take(bool last)
+		{
+			std::size_t const n(std::size_t(pptr() - pbase()));
+			std::size_t const whole(n / 8);
+			for (std::size_t w(0); w < whole; ++w) {
+				std::uint64_t v;
+				std::memcpy(&v, m_buf + 8 * w, 8);                                   // little-endian host
+				m_acc += mix64((++m_words) * 0x9E3779B97F4A7C15ULL ^ v);
+			}
+			std::size_t const rest(n - 8 * whole);
+			m_total += 8 * whole;
+			if (last && rest) {
+				std::uint64_t v(0);
+				std::memcpy(&v, m_buf + 8 * whole, rest);
+				m_acc += mix64((++m_words) * 0x9E3779B97F4A7C15ULL ^ v);
+				m_total += rest;
+				setp(m_buf, m_buf + sizeof(m_buf));
+				return;
+			}
+			std::memmove(m_buf, m_buf + 8 * whole, rest);
+			setp(m_buf, m_buf + sizeof(m_buf));
+			pbump(int(rest));
+		}
+		int_type overflow(int_type ch) override
+		{
+			take(false);
+			if (!traits_type::eq_int_type(ch, traits_type::eof())) { *pptr() = traits_type::to_char_type(ch); pbump(1); }
+			return traits_type::not_eof(ch);
+		}
+		char m_buf[1 << 16];
+		std::uint64_t m_acc{}, m_words{}, m_total{};
+	};
+	checksum_streambuf buf;
+	std::ostream os(&buf);
 	if (n_cuts) {
 		founder_delegate d;
 		d.cut_nodes = cut_nodes; d.copies = cut_copies; d.n_cuts = n_cuts;
@@ -1235,21 +1289,8 @@ std::uint64_t v2mo_row_checksum(
 		fixed_copy_delegate d(copy_index);
 		output_sequence(ref_seq, G(h), os, nullptr, unaligned, d);
 	}
-	auto const s(std::move(os).str());
-	auto const mix64([](std::uint64_t z) {
-		z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL;
-		z ^= z >> 27; z *= 0x94D049BB133111EBULL;
-		z ^= z >> 31;
-		return z;
-	});
-	std::uint64_t const golden(0x9E3779B97F4A7C15ULL), n(s.size());
-	std::uint64_t acc(0);
-	for (std::uint64_t w(0); w * 8 < n; ++w) {
-		std::uint64_t v(0);
-		std::memcpy(&v, s.data() + w * 8, std::min<std::uint64_t>(8, n - w * 8));   // little-endian host
-		acc += mix64((w + 1) * golden ^ v);
-	}
-	acc += mix64(n);
+	std::uint64_t n(0);
+	std::uint64_t const acc(buf.finish(n));
 	if (length_out) *length_out = n;
 	return acc;
 }

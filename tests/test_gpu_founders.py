@@ -185,7 +185,7 @@ def test_refuses_bad_candidates_and_start_states(v2m):
 
 		good_edge, good_aln = [0, 1, 2], [0, 5, 9]
 		assert trials(good_edge, good_aln) == N.V2M_OK and status[0] in (0, 1)
-		for bad_edge in ([0, 2, 1], [0, 1, 1], [0, 1, n_edges + 1]):
+		for bad_edge in ([0, 2, 1], [1, 0, 2], [0, 1, n_edges + 1]):
 			assert trials(bad_edge, good_aln) == N.V2M_ERR_INVALID_ARGUMENT
 			assert b"candidate edges" in ctx._lib.v2m_last_error(ctx._h)
 		assert trials(good_edge, [0, 9, 5]) == N.V2M_ERR_INVALID_ARGUMENT
@@ -241,5 +241,7 @@ def test_edge_major_copy_is_kept_between_the_two_searches_and_dropped_with_the_b
 		ctx.upload_graph(vg0, og.ref)
 		hg0 = HostGraph(fa, vcf, "1")
 		hg0.set_transposed_paths(vg0.paths_by_chrom_copy_and_edge, og.path_rows, og.path_cols)
-		assert hg0.find_founders_gpu(ctx, 5, 20, threads=2) == hg0.find_founders(5, 20, threads=1)
+		got0 = hg0.find_founders_gpu(ctx, 5, 20, threads=2)
 		assert ctx.profile_get(N.KERNEL_TRANSPOSE)[0] == 2
+		# no copy follows any ALT edge now: one path class from the first node to the last (the stale copy would give `want` again)
+		assert got0 != want and got0[0] == [0, len(hg0.reference_positions) - 1] and got0[2] == 1

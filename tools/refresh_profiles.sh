@@ -3,7 +3,7 @@
 #   pmc_hbm.json                     HBM bytes per launch from two separate --pmc passes (one step each)
 #   pmc_traffic.json                 the record bench.py reads roofline.traffic from, stamped with the kernel sources' hashes
 #   bench.json                       plain run (after the counter passes, so that it carries the traffic figure)
-#   bench_under_rocprof.json         the same command under rocprofv3 --kernel-trace --stats
+#   bench_under_rocprof.json         the same command (minus the end-to-end leg, --e2e-gb 0) under rocprofv3 --kernel-trace --stats
 #   kernel_stats.csv                 its per-kernel summary
 # Run on the GPU box from the repository root; copy the files into profiles/rNN/ (and pmc_traffic.json into profiles/) afterwards.
 set -e -o pipefail
@@ -12,17 +12,19 @@ OUT=gpurun_out/refresh
 mkdir -p $OUT
 # the counter passes run with the store flavour fixed, so that every splice launch they see is one of the step's own
 # (the flavour calibration would add four same-size launches, two of them with plain stores)
-PMC_ARGS="--steps 1 --warmup 0 --cpu-baseline-rows 0 --verify-rows 0 --unaligned-rows 0 --transpose-extras 0"
+PMC_ARGS="--steps 1 --warmup 0 --cpu-baseline-rows 0 --verify-rows 0 --unaligned-rows 0 --transpose-extras 0 --cpu-transpose 0 --e2e-gb 0"
 V2M_NT_STORES=1 timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_w -o w -- python3 bench.py $PMC_ARGS > $OUT/pmc_w.json 2> $OUT/pmc_w.err
 echo "pmc write done"
 V2M_NT_STORES=1 timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_f -o f -- python3 bench.py $PMC_ARGS > $OUT/pmc_f.json 2> $OUT/pmc_f.err
 echo "pmc fetch done"
-python3 tools/pmc_summary.py $OUT/pmc_hbm.json "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE (separate passes, one step of bench.py's default run each; counter unit KiB; hbm_bytes = 1024*(WRITE_SIZE + 2*FETCH_SIZE), the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md). Store flavour fixed (V2M_NT_STORES=1): the splice average covers the step's own launches only." WRITE_SIZE=$OUT/pmc_w FETCH_SIZE=$OUT/pmc_f "record=config3,$(python3 -c "import json;print(json.loads(open('$OUT/pmc_w.json').read().strip().splitlines()[-1])['config']['batch_rows'])"),1,${PROFILE_DEST:-profiles/r03}/config3_1gpu_pmc_hbm.json"
+python3 tools/pmc_summary.py $OUT/pmc_hbm.json "rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE (separate passes, one step of bench.py's default run each; counter unit KiB; hbm_bytes = 1024*(WRITE_SIZE + 2*FETCH_SIZE), the gfx950 FETCH_SIZE correction of MI355X_MICROARCH.md). Store flavour fixed (V2M_NT_STORES=1): the splice average covers the step's own launches only." WRITE_SIZE=$OUT/pmc_w FETCH_SIZE=$OUT/pmc_f "record=config3,$(python3 -c "import json;print(json.loads(open('$OUT/pmc_w.json').read().strip().splitlines()[-1])['config']['batch_rows'])"),1,${PROFILE_DEST:-profiles/r04}/config3_1gpu_pmc_hbm.json"
 cp profiles/pmc_traffic.json $OUT/pmc_traffic.json
 rm -rf $OUT/pmc_w $OUT/pmc_f
 timeout -k 10 400 python3 bench.py > $OUT/bench.json 2> $OUT/bench.err
 echo "bench done"
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
+# (without the end-to-end leg: it launches splice_aligned_kernel another ~500 times on the sink path's 5-row slices, which would average
+# into the per-kernel summary; the 63-GB launches of the timed region are what the line's roofline is about)
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 bench.py --e2e-gb 0 > $OUT/bench_under_rocprof.json 2> $OUT/trace.err
 cp $(find $OUT/trace -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats.csv
 rm -rf $OUT/trace
 echo "trace done"

@@ -1356,9 +1356,10 @@ int pbwt_cut_trials_impl(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	if (n_candidates >= 0xFFFFFFFFull || ctx->n_edges >= 0xFFFFFFFDull) return fail(ctx, V2M_ERR_UNSUPPORTED, "candidate and edge indices are kept in 32 bits");
 	if (chunk_first[0] < 1 || chunk_first[n_chunks] > n_candidates) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds outside the candidate list");
 	for (u64 k(0); k < n_chunks; ++k) if (chunk_first[k] > chunk_first[k + 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds must not decrease");
-	// the candidates as find_cut_positions.cc:126-151 makes them: one per distinct edge index, in node order (so both columns ascend)
+	// the candidates as find_cut_positions.cc:113,126-151 makes them: the sentinel (edge 0, node 0), then one per distinct edge index in
+	// node order -- both columns ascend (the first real candidate may share edge 0 with the sentinel)
 	for (u64 c(0); c < n_candidates; ++c) {
-		if (cand_edge[c] > ctx->n_edges || (c && cand_edge[c] <= cand_edge[c - 1])) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "candidate edges must ascend strictly and stay inside the graph (candidate %llu)", (unsigned long long) c);
+		if (cand_edge[c] > ctx->n_edges || (c && cand_edge[c] < cand_edge[c - 1])) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "candidate edges must ascend and stay inside the graph (candidate %llu)", (unsigned long long) c);
 		if (c && cand_aligned_pos[c] < cand_aligned_pos[c - 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "candidate aligned positions must not decrease (candidate %llu)", (unsigned long long) c);
 	}
 	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
