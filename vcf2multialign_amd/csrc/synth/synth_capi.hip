@@ -148,56 +148,60 @@ struct v2ms_checksum_sink {
 	uint64_t rows{}, bytes{};
 	std::vector <std::thread> workers;
 	std::mutex mutex;
-	std::condition_variable wake, finished;
+	std::condition_variable wake, idle;
+	// the row being summed; written by the sink only under `mutex` and only while no worker is active, read by a worker under
+	// `mutex` when it takes notice of a new generation (a worker that wakes late finds either the finished row -- no part left --
+	// or the next one, never a mixture)
+	struct job { char const *bytes{}; uint64_t words{}, parts{}; } current;
 	uint64_t generation{};
 	bool stopping{};
-	char const *row_bytes{};
-	uint64_t row_words{}, tail_word{};   // whole words; the zero-padded last word when the length is not a multiple of 8
+	unsigned active{};                   // workers between noticing a generation and having finished with it
+	uint64_t parts_done{};
 	std::atomic <uint64_t> next_part{}, sum{};
-	uint64_t parts{}, parts_done{};
-	unsigned active{};                   // workers inside run_parts(): the next row is only set up once none is
 
 	static uint64_t mix64(uint64_t z) { z ^= z >> 30; z *= 0xBF58476D1CE4E5B9ULL; z ^= z >> 27; z *= 0x94D049BB133111EBULL; z ^= z >> 31; return z; }
 
-	void run_parts()
+	// takes parts of `j` until none is left; returns how many it took
+	uint64_t run_parts(job const &j)
 	{
-		uint64_t const per_part((row_words + parts - 1) / parts);
+		if (0 == j.parts) return 0;
+		uint64_t const per_part((j.words + j.parts - 1) / j.parts);
 		uint64_t local(0), done(0);
 		for (;;) {
 			uint64_t const p(next_part.fetch_add(1, std::memory_order_relaxed));
-			if (p >= parts) break;
-			uint64_t const k0(p * per_part), k1(k0 + per_part < row_words ? k0 + per_part : row_words);
+			if (p >= j.parts) break;
+			uint64_t const k0(p * per_part), k1(k0 + per_part < j.words ? k0 + per_part : j.words);
 			uint64_t acc(0);
 			for (uint64_t k(k0); k < k1; ++k) {
 				uint64_t w;
-				std::memcpy(&w, row_bytes + 8 * k, 8);
+				std::memcpy(&w, j.bytes + 8 * k, 8);
 				acc += mix64((k + 1) * 0x9E3779B97F4A7C15ULL ^ w);
 			}
 			local += acc;
 			++done;
 		}
-		if (done) {
-			sum.fetch_add(local, std::memory_order_relaxed);
-			std::lock_guard <std::mutex> lock(mutex);
-			parts_done += done;
-			if (parts_done == parts) finished.notify_all();
-		}
+		if (done) sum.fetch_add(local, std::memory_order_relaxed);
+		return done;
 	}
 
 	void worker()
 	{
 		uint64_t seen(0);
 		for (;;) {
+			job j;
 			{
 				std::unique_lock <std::mutex> lock(mutex);
 				wake.wait(lock, [&]{ return stopping || generation != seen; });
 				if (stopping) return;
 				seen = generation;
+				j = current;
 				++active;
 			}
-			run_parts();
+			uint64_t const done(run_parts(j));
 			std::lock_guard <std::mutex> lock(mutex);
-			if (0 == --active) finished.notify_all();
+			parts_done += done;
+			--active;
+			if (0 == active) idle.notify_all();
 		}
 	}
 };
@@ -229,27 +233,31 @@ int v2ms_checksum_sink_fn(void *user, uint64_t row, char const *bytes, uint64_t 
 {
 	auto *s(static_cast<v2ms_checksum_sink *>(user));
 	if (row >= s->checksums.size()) return 1;
-	s->row_bytes = bytes;
-	s->row_words = length / 8;
+	v2ms_checksum_sink::job j;
+	j.bytes = bytes;
+	j.words = length / 8;
+	j.parts = j.words ? 4 * (s->workers.size() + 1) : 0;
 	s->sum.store(0, std::memory_order_relaxed);
-	s->next_part.store(0, std::memory_order_relaxed);
-	s->parts = s->row_words ? 4 * (s->workers.size() + 1) : 0;
-	if (s->parts) {
+	if (j.parts) {
 		{
-			std::lock_guard <std::mutex> lock(s->mutex);
+			std::unique_lock <std::mutex> lock(s->mutex);
+			s->idle.wait(lock, [&]{ return 0 == s->active; });        // (a worker that noticed the previous row late is let out first)
+			s->current = j;
 			s->parts_done = 0;
+			s->next_part.store(0, std::memory_order_relaxed);
 			++s->generation;
 		}
 		s->wake.notify_all();
-		s->run_parts();
+		uint64_t const mine(s->run_parts(j));
 		std::unique_lock <std::mutex> lock(s->mutex);
-		s->finished.wait(lock, [&]{ return s->parts_done == s->parts && 0 == s->active; });
+		s->parts_done += mine;
+		s->idle.wait(lock, [&]{ return s->parts_done == j.parts && 0 == s->active; });
 	}
 	uint64_t acc(s->sum.load(std::memory_order_relaxed));
 	if (length % 8) {
 		uint64_t w(0);
-		std::memcpy(&w, bytes + 8 * s->row_words, length % 8);
-		acc += v2ms_checksum_sink::mix64((s->row_words + 1) * 0x9E3779B97F4A7C15ULL ^ w);
+		std::memcpy(&w, bytes + 8 * j.words, length % 8);
+		acc += v2ms_checksum_sink::mix64((j.words + 1) * 0x9E3779B97F4A7C15ULL ^ w);
 	}
 	acc += v2ms_checksum_sink::mix64(length);
 	s->checksums[row] = acc;
