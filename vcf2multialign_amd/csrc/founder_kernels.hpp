@@ -38,24 +38,23 @@ __device__ __forceinline__ void pbwt_block_sync()
 }
 
 // "p -> is_const ? value : max(p, value)": what a run of copies does to a running maximum that is reset after every copy of
-// its own class.
-struct max_chain {
-	uint32_t value;
-	uint32_t is_const;
-};
+// its own class -- packed into one register: bit 31 = is_const, the low bits the value (biased divergence values are edge
+// indices + 2, far below 2^31; the host refuses graphs where they are not).  0 is the identity.
+constexpr uint32_t kChainConst = 0x80000000u;
 
-// first `then`, after that `next`
-__device__ __forceinline__ max_chain chain_then(max_chain first, max_chain next)
+// first `first`, after that `next`
+__device__ __forceinline__ uint32_t chain_then(uint32_t first, uint32_t next)
 {
-	if (next.is_const) return next;
-	return max_chain{first.value > next.value ? first.value : next.value, first.is_const};
+	uint32_t const keep = (first & kChainConst) | next;               // v_and_or_b32
+	uint32_t const m = first > keep ? first : keep;                   // a constant stays one, its value grows; otherwise a plain max
+	return (int32_t) next < 0 ? next : m;
 }
 
-__device__ __forceinline__ uint32_t chain_apply(max_chain c, uint32_t p) { return c.is_const ? c.value : (p > c.value ? p : c.value); }
+__device__ __forceinline__ uint32_t chain_apply(uint32_t c, uint32_t p) { return (int32_t) c < 0 ? (c & ~kChainConst) : (p > c ? p : c); }
 
 struct pbwt_scan_item {
 	uint32_t zeros;       // copies that do not use the edge
-	max_chain p, q;       // the running maxima of the two classes (pbwt.hh:93-131)
+	uint32_t p, q;        // the running maxima of the two classes (pbwt.hh:93-131), as packed chains
 };
 
 __device__ __forceinline__ pbwt_scan_item scan_combine(pbwt_scan_item const &a, pbwt_scan_item const &b)   // a, then b
@@ -63,25 +62,82 @@ __device__ __forceinline__ pbwt_scan_item scan_combine(pbwt_scan_item const &a, 
 	return pbwt_scan_item{a.zeros + b.zeros, chain_then(a.p, b.p), chain_then(a.q, b.q)};
 }
 
-__device__ __forceinline__ pbwt_scan_item scan_shfl_up(pbwt_scan_item const &x, int delta)
+// v_mov_b32_dpp with zeros where a lane has no source (or its row is masked out): the identity of every scan below, so a
+// round of a scan is "fetch, combine" with no per-lane select.  No LDS round trip, unlike __shfl_up (ds_bpermute_b32).
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ uint32_t pbwt_dpp(uint32_t v) { return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, kCtrl, kRowMask, 0xf, false); }
+
+constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118, kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138;
+
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ pbwt_scan_item scan_round(pbwt_scan_item const &x)
 {
-	pbwt_scan_item y;
-	y.zeros = __shfl_up(x.zeros, delta, 64);
-	y.p.value = __shfl_up(x.p.value, delta, 64);
-	y.p.is_const = __shfl_up(x.p.is_const, delta, 64);
-	y.q.value = __shfl_up(x.q.value, delta, 64);
-	y.q.is_const = __shfl_up(x.q.is_const, delta, 64);
-	return y;
+	pbwt_scan_item const up{pbwt_dpp<kCtrl, kRowMask>(x.zeros), pbwt_dpp<kCtrl, kRowMask>(x.p), pbwt_dpp<kCtrl, kRowMask>(x.q)};
+	return scan_combine(up, x);
 }
 
-// One step of Durbin's algorithm 2 for edge `edge` (pbwt.hh:77-134) by the whole workgroup: state order[cur] / divergence[cur]
-// -> order[cur ^ 1] / divergence[cur ^ 1].  Thread t owns the copies [my_begin, my_end) of the order.  Returns how many copies do
-// NOT use the edge (workgroup-uniform).  Contains three barriers; the caller flips `cur`.
-// The edge's bit column (words_per_edge <= 128 words, one per thread) travels in a register: `column_word` holds thread t's word of
-// THIS edge on entry -- fetched while the previous step ran, or by pbwt_fetch_column() before the first one -- and of the next
-// edge on return (steps always visit consecutive edges; `edge_limit` clamps the fetch after the last one).  Fetched at the top of
-// the step instead, every step stood still for one global-memory latency (config 4: 58.3 -> 56.9 ms and 28.3 -> 27.0 ms for the two
-// kernels -- most of a step is barriers and dependent LDS passes, not this).
+// inclusive scan inside every row of 16 lanes (four shifts)
+__device__ __forceinline__ pbwt_scan_item row_inclusive_scan(pbwt_scan_item x)
+{
+	x = scan_round<kDppRowShr1, 0xf>(x);
+	x = scan_round<kDppRowShr2, 0xf>(x);
+	x = scan_round<kDppRowShr4, 0xf>(x);
+	x = scan_round<kDppRowShr8, 0xf>(x);
+	return x;
+}
+
+// ... and across the wave: lane 15 of rows 0 / 2 into rows 1 / 3, then lane 31 into rows 2 and 3 (the operator is not commutative;
+// what arrives always lies BEFORE the lane's own run)
+__device__ __forceinline__ pbwt_scan_item wave_inclusive_scan(pbwt_scan_item x)
+{
+	x = row_inclusive_scan(x);
+	x = scan_round<kDppBcast15, 0xa>(x);
+	x = scan_round<kDppBcast31, 0xc>(x);
+	return x;
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_add(uint32_t v)
+{
+	v += pbwt_dpp<kDppRowShr1, 0xf>(v);
+	v += pbwt_dpp<kDppRowShr2, 0xf>(v);
+	v += pbwt_dpp<kDppRowShr4, 0xf>(v);
+	v += pbwt_dpp<kDppRowShr8, 0xf>(v);
+	v += pbwt_dpp<kDppBcast15, 0xa>(v);
+	v += pbwt_dpp<kDppBcast31, 0xc>(v);
+	return v;
+}
+
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+
+__device__ __forceinline__ uint32_t row_inclusive_max(uint32_t v)
+{
+	v = umax(v, pbwt_dpp<kDppRowShr1, 0xf>(v));
+	v = umax(v, pbwt_dpp<kDppRowShr2, 0xf>(v));
+	v = umax(v, pbwt_dpp<kDppRowShr4, 0xf>(v));
+	v = umax(v, pbwt_dpp<kDppRowShr8, 0xf>(v));
+	return v;
+}
+
+__device__ __forceinline__ uint32_t wave_inclusive_max(uint32_t v)
+{
+	v = row_inclusive_max(v);
+	v = umax(v, pbwt_dpp<kDppBcast15, 0xa>(v));
+	v = umax(v, pbwt_dpp<kDppBcast31, 0xc>(v));
+	return v;
+}
+
+__device__ __forceinline__ uint32_t row_inclusive_add(uint32_t v)
+{
+	v += pbwt_dpp<kDppRowShr1, 0xf>(v);
+	v += pbwt_dpp<kDppRowShr2, 0xf>(v);
+	v += pbwt_dpp<kDppRowShr4, 0xf>(v);
+	v += pbwt_dpp<kDppRowShr8, 0xf>(v);
+	return v;
+}
+
+// The edge's bit column (words_per_edge <= 128 words, one per thread) is fetched a whole step ahead into a register and stashed in
+// the LDS buffer the NEXT step reads while the current one's second pass runs, so a step never stands still for a global load and
+// the stash needs no barrier of its own (steps always visit consecutive edges; `edge_limit` clamps the fetch after the last one).
 __device__ __forceinline__ uint64_t pbwt_fetch_column(uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge, uint32_t edge_limit, int t)
 {
 	if (0u == edge_limit) return 0;
@@ -89,61 +145,130 @@ __device__ __forceinline__ uint64_t pbwt_fetch_column(uint64_t const *__restrict
 	return (uint32_t) t < words_per_edge ? paths_by_edge[(uint64_t) e * words_per_edge + (uint32_t) t] : 0;
 }
 
-__device__ __forceinline__ uint32_t pbwt_step(
-	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge, uint32_t edge_limit, uint64_t &column_word,
-	unsigned short (*order)[kPbwtMaxCopies], uint32_t (*divergence)[kPbwtMaxCopies], uint64_t *column, pbwt_scan_item *wave_items,
-	int cur, uint32_t my_begin, uint32_t my_end, int t, int lane, int wave)
+struct pbwt_column_stream {
+	uint64_t next_word;   // thread t's word of the edge after the one whose words are in column[buf]
+	int buf;
+};
+
+// Before the first step: edge `edge`'s words into column[0], the next edge's on their way.  The caller's next barrier publishes them.
+__device__ __forceinline__ pbwt_column_stream pbwt_prime_columns(uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge, uint32_t edge_limit,
+	uint64_t (*column)[kPbwtMaxCopies / 64], int t)
 {
-	if ((uint32_t) t < words_per_edge) column[t] = column_word;
-	pbwt_block_sync();
-	column_word = pbwt_fetch_column(paths_by_edge, words_per_edge, edge + 1u, edge_limit, t);   // in flight while this step runs
+	if ((uint32_t) t < words_per_edge) column[0][t] = pbwt_fetch_column(paths_by_edge, words_per_edge, edge, edge_limit, t);
+	return pbwt_column_stream{pbwt_fetch_column(paths_by_edge, words_per_edge, edge + 1u, edge_limit, t), 0};
+}
+
+// One step of Durbin's algorithm 2 for edge `edge` (pbwt.hh:77-134) by the whole workgroup: state order[cur] / divergence[cur]
+// -> order[cur ^ 1] / divergence[cur ^ 1].  Thread t owns `my_count` <= per <= kPbwtPerThread consecutive copies of the order from
+// my_begin on (per is workgroup-uniform).  Returns how many copies do NOT use the edge (workgroup-uniform).  TWO barriers; the
+// caller flips `cur`.
+//   pass 1  the thread's copies, their divergence values and their bits of the edge into registers; what the run does to the zero
+//           count and to the two running maxima, folded locally; an inclusive scan of that over the wave (DPP)      -- barrier --
+//   pass 2  the 16 waves' totals scanned by every wave for itself (one LDS read + a row scan), the lane's exclusive prefix from its
+//           neighbour (DPP), then every copy placed (stable partition) with its new divergence value; the next edge's column
+//           stashed                                                                                                  -- barrier --
+// Round 3's form of this step took 5 us at config 4 (three barriers, ds_bpermute scans over five registers, the 16 wave totals
+// combined serially by all 1024 threads, every copy read twice).
+__device__ __forceinline__ uint32_t pbwt_step(
+	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge, uint32_t edge_limit, pbwt_column_stream &cols,
+	unsigned short (*order)[kPbwtMaxCopies], uint32_t (*divergence)[kPbwtMaxCopies], uint64_t (*column)[kPbwtMaxCopies / 64], uint4 *wave_items,
+	int cur, uint32_t per, uint32_t my_begin, uint32_t my_count, int t, int lane, int wave)
+{
 	unsigned short const *const ord = order[cur];
 	uint32_t const *const dv = divergence[cur];
-	// what this thread's run of copies does to the zero count and to the two running maxima
-	pbwt_scan_item mine{0u, max_chain{0u, 0u}, max_chain{0u, 0u}};
+	uint64_t const *const col = column[cols.buf];
+	uint32_t copy[kPbwtPerThread], d[kPbwtPerThread];
 	uint32_t flags = 0;
-	for (uint32_t i = my_begin; i < my_end; ++i) {
-		uint32_t const copy = ord[i], d = dv[i];
-		uint32_t const f = (uint32_t) (column[copy >> 6] >> (copy & 63)) & 1u;
-		flags |= f << (i - my_begin);
-		pbwt_scan_item one;
-		one.zeros = 1u - f;
-		one.p = f ? max_chain{d, 0u} : max_chain{1u, 1u};      // a copy of class 0 takes p and leaves biased 0 behind
-		one.q = f ? max_chain{1u, 1u} : max_chain{d, 0u};
-		mine = scan_combine(mine, one);
-	}
-	// exclusive scan over the threads: inside the wave, then over the waves' totals
-	pbwt_scan_item incl = mine;
+	pbwt_scan_item mine{0u, 0u, 0u};
 #pragma unroll
-	for (int delta = 1; delta < 64; delta <<= 1) {
-		pbwt_scan_item const up = scan_shfl_up(incl, delta);
-		if (lane >= delta) incl = scan_combine(up, incl);
+	for (int k = 0; k < kPbwtPerThread; ++k) {
+		if ((uint32_t) k < per) {                                           // (uniform)
+			bool const valid = (uint32_t) k < my_count;
+			copy[k] = valid ? (uint32_t) ord[my_begin + k] : 0u;             // (my_begin + k < 1024 * per <= kPbwtMaxCopies: inside the array either way)
+			d[k] = dv[my_begin + k];
+		}
 	}
-	if (lane == 63) wave_items[wave] = incl;
+#pragma unroll
+	for (int k = 0; k < kPbwtPerThread; ++k) {
+		if ((uint32_t) k < per) {
+			bool const valid = (uint32_t) k < my_count;
+			uint32_t const f = (uint32_t) (col[copy[k] >> 6] >> (copy[k] & 63u)) & 1u;
+			flags |= f << k;
+			// a copy of class 0 takes p and leaves biased 0 (= 1) behind; one of class 1 does that to q
+			uint32_t const one_p = f ? d[k] : (kChainConst | 1u), one_q = f ? (kChainConst | 1u) : d[k];
+			uint32_t const np = chain_then(mine.p, one_p), nq = chain_then(mine.q, one_q);
+			mine.zeros += valid ? 1u - f : 0u;
+			mine.p = valid ? np : mine.p;
+			mine.q = valid ? nq : mine.q;
+		}
+	}
+	pbwt_scan_item const incl = wave_inclusive_scan(mine);
+	if (lane == 63) wave_items[wave] = uint4{incl.zeros, incl.p, incl.q, 0u};
 	pbwt_block_sync();
-	pbwt_scan_item before{0u, max_chain{0u, 0u}, max_chain{0u, 0u}};      // identity: no copies
-	uint32_t zeros_total = 0;
-	for (int w = 0; w < kPbwtWaves; ++w) {
-		pbwt_scan_item const wi = wave_items[w];
-		if (w < wave) before = scan_combine(before, wi);
-		zeros_total += wi.zeros;
+
+	// the waves' totals: every wave scans the 16 of them for itself, in each of its rows of 16 lanes
+	uint4 const wi = wave_items[lane & (kPbwtWaves - 1)];
+	pbwt_scan_item const waves_incl = row_inclusive_scan(pbwt_scan_item{wi.x, wi.y, wi.z});
+	uint32_t const zeros_total = (uint32_t) __builtin_amdgcn_readlane((int) waves_incl.zeros, kPbwtWaves - 1);
+	int const w = __builtin_amdgcn_readfirstlane(wave);
+	pbwt_scan_item before{0u, 0u, 0u};                                       // identity: no copies
+	if (w > 0) {
+		before.zeros = (uint32_t) __builtin_amdgcn_readlane((int) waves_incl.zeros, w - 1);
+		before.p = (uint32_t) __builtin_amdgcn_readlane((int) waves_incl.p, w - 1);
+		before.q = (uint32_t) __builtin_amdgcn_readlane((int) waves_incl.q, w - 1);
 	}
-	pbwt_scan_item const lane_before = scan_shfl_up(incl, 1);
-	if (lane) before = scan_combine(before, lane_before);
+	// ... and the lanes before this one in its wave (lane 0: nothing = the identity)
+	pbwt_scan_item const lanes_before{pbwt_dpp<kDppWaveShr1, 0xf>(incl.zeros), pbwt_dpp<kDppWaveShr1, 0xf>(incl.p), pbwt_dpp<kDppWaveShr1, 0xf>(incl.q)};
+	before = scan_combine(before, lanes_before);
+
 	// second pass: place the copies (stable partition) with their new divergence values
 	uint32_t p = chain_apply(before.p, edge + 2u), q = chain_apply(before.q, edge + 2u);   // biased edge + 1 (pbwt.hh:93)
 	uint32_t zero_at = before.zeros, one_at = zeros_total + (my_begin - before.zeros);
 	unsigned short *const out_ord = order[cur ^ 1];
 	uint32_t *const out_dv = divergence[cur ^ 1];
-	for (uint32_t i = my_begin; i < my_end; ++i) {
-		uint32_t const copy = ord[i], d = dv[i];
-		p = p > d ? p : d;
-		q = q > d ? q : d;
-		if (!((flags >> (i - my_begin)) & 1u)) { out_ord[zero_at] = (unsigned short) copy; out_dv[zero_at] = p; ++zero_at; p = 1u; }
-		else { out_ord[one_at] = (unsigned short) copy; out_dv[one_at] = q; ++one_at; q = 1u; }
+#pragma unroll
+	for (int k = 0; k < kPbwtPerThread; ++k) {
+		if ((uint32_t) k < per) {
+			bool const valid = (uint32_t) k < my_count;
+			bool const f = 0u != ((flags >> k) & 1u);
+			p = p > d[k] ? p : d[k];
+			q = q > d[k] ? q : d[k];
+			uint32_t const at = f ? one_at : zero_at;
+			uint32_t const value = f ? q : p;
+			if (valid) { out_ord[at] = (unsigned short) copy[k]; out_dv[at] = value; }
+			zero_at += (valid && !f) ? 1u : 0u;
+			one_at += (valid && f) ? 1u : 0u;
+			p = (valid && !f) ? 1u : p;
+			q = (valid && f) ? 1u : q;
+		}
 	}
+	// the next edge's column into the other buffer (nobody reads that one during this step), the one after it on its way
+	if ((uint32_t) t < words_per_edge) column[cols.buf ^ 1][t] = cols.next_word;
+	cols.next_word = pbwt_fetch_column(paths_by_edge, words_per_edge, edge + 2u, edge_limit, t);
+	cols.buf ^= 1;
 	pbwt_block_sync();
 	return zeros_total;
+}
+
+// Puts `count` copies into the bin's slot of the candidate's hash table (claiming a slot for a bin seen for the first time).
+__device__ __forceinline__ void pbwt_bin_add(uint32_t *hash_key, uint32_t *hash_count, uint32_t *bin_slot, uint32_t *n_bins_s, uint32_t *failed_s, uint32_t bin, uint32_t count)
+{
+	uint32_t slot = (bin * 2654435761u) >> 20 & (uint32_t) (kPbwtHashSlots - 1);
+	bool placed = false;
+	for (int probe = 0; probe < kPbwtHashSlots && !placed; ++probe) {   // (bounded: a full table ends the chunk)
+		uint32_t const seen = atomicCAS(&hash_key[slot], 0u, bin + 1u);
+		if (0u == seen) {                                       // claimed a free slot
+			uint32_t const k = atomicAdd(n_bins_s, 1u);
+			if (k < (uint32_t) kPbwtMaxBins) bin_slot[k] = slot;
+			placed = true;
+		} else if (seen == bin + 1u) {
+			placed = true;
+		} else {
+			slot = (slot + 1u) & (uint32_t) (kPbwtHashSlots - 1);
+		}
+	}
+	if (placed) atomicAdd(&hash_count[slot], count);
+	else *failed_s = 1u;
 }
 
 // One workgroup per chunk.  See v2m_pbwt_cut_trials() in include/v2m_hip.h for the arguments.
@@ -160,13 +285,14 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 {
 	__shared__ unsigned short order[2][kPbwtMaxCopies];
 	__shared__ uint32_t divergence[2][kPbwtMaxCopies];
-	__shared__ uint64_t column[kPbwtMaxCopies / 64];
-	__shared__ pbwt_scan_item wave_items[kPbwtWaves];
+	__shared__ uint64_t column[2][kPbwtMaxCopies / 64];
+	__shared__ uint4 wave_items[kPbwtWaves];
 	__shared__ uint32_t hash_key[kPbwtHashSlots];         // bin + 1; 0 = free
 	__shared__ uint32_t hash_count[kPbwtHashSlots];
 	__shared__ uint32_t bin_slot[kPbwtMaxBins];           // hash slots in use, in claiming order
-	__shared__ uint32_t sorted_key[kPbwtMaxBins], sorted_count[kPbwtMaxBins], sorted_emit[kPbwtMaxBins];
-	__shared__ uint32_t n_bins_s, reduce_max[kPbwtWaves], reduce_cnt[kPbwtWaves], failed_s;
+	__shared__ __attribute__((aligned(16))) uint32_t bin_key[kPbwtMaxBins], bin_packed[kPbwtMaxBins];   // the candidate's bins, dense: key; copies | emits << 16
+	__shared__ uint32_t bin_sum[kPbwtMaxBins];            // per bin: the same two fields summed over the bins with a larger key
+	__shared__ uint32_t n_bins_s, reduce_max[kPbwtWaves], reduce_cnt[kPbwtWaves], failed_s, emitted_s, smallest_s;
 
 	int const t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	uint32_t const chunk = blockIdx.x;
@@ -174,19 +300,20 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 	uint32_t const per = (n_copies + kPbwtThreads - 1) / kPbwtThreads;          // <= kPbwtPerThread
 	uint32_t const my_begin = (uint32_t) t * per < n_copies ? (uint32_t) t * per : n_copies;
 	uint32_t const my_end = my_begin + per < n_copies ? my_begin + per : n_copies;
+	uint32_t const my_count = my_end - my_begin;
 
 	for (uint32_t i = t; i < n_copies; i += kPbwtThreads) {
 		order[0][i] = (unsigned short) start_order[(uint64_t) chunk * n_copies + i];
 		divergence[0][i] = start_divergence[(uint64_t) chunk * n_copies + i];
 	}
 	for (uint32_t i = t; i < (uint32_t) kPbwtHashSlots; i += kPbwtThreads) { hash_key[i] = 0; hash_count[i] = 0; }
-	if (t == 0) { n_bins_s = 0; failed_s = 0; }
+	if (t == 0) { n_bins_s = 0; failed_s = 0; emitted_s = 0; smallest_s = 0xFFFFFFFFu; }
+	int cur = 0;
+	uint32_t edge = cand_begin < cand_end ? cand_edge[cand_begin] : 0;
+	pbwt_column_stream cols = pbwt_prime_columns(paths_by_edge, words_per_edge, edge, n_edges, column, t);
 	pbwt_block_sync();
 
-	int cur = 0;
 	uint64_t n_trials = 0;                                 // (kept by every thread: all of them see the same counts)
-	uint32_t edge = cand_begin < cand_end ? cand_edge[cand_begin] : 0;
-	uint64_t column_word = pbwt_fetch_column(paths_by_edge, words_per_edge, edge, n_edges, t);
 	uint32_t *const my_pred = trial_pred + (uint64_t) chunk * trial_capacity;
 	uint32_t *const my_class = trial_class_count + (uint64_t) chunk * trial_capacity;
 
@@ -194,7 +321,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		// ---- the edges before this candidate's node (find_cut_positions.cc:170-176 over pbwt.hh:77-134) -----------------
 		uint32_t const upto = cand_edge[cand];
 		for (; edge < upto; ++edge) {
-			pbwt_step(paths_by_edge, words_per_edge, edge, n_edges, column_word, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
+			pbwt_step(paths_by_edge, words_per_edge, edge, n_edges, cols, order, divergence, column, wave_items, cur, per, my_begin, my_count, t, lane, wave);
 			cur ^= 1;
 		}
 
@@ -202,99 +329,141 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		uint32_t const next = (uint32_t) cand;
 		uint32_t const *const dv = divergence[cur];
 		// the largest divergence value and how many copies hold it
+		uint32_t d[kPbwtPerThread];
 		uint32_t my_max = 0;
-		for (uint32_t i = my_begin; i < my_end; ++i) my_max = dv[i] > my_max ? dv[i] : my_max;
 #pragma unroll
-		for (int delta = 32; delta >= 1; delta >>= 1) { uint32_t const o = __shfl_xor(my_max, delta, 64); my_max = o > my_max ? o : my_max; }
-		if (lane == 0) reduce_max[wave] = my_max;
-		pbwt_block_sync();
-		uint32_t d_max = 0;
-		for (int w = 0; w < kPbwtWaves; ++w) d_max = reduce_max[w] > d_max ? reduce_max[w] : d_max;
-		uint32_t my_cnt = 0;
-		// every other copy goes into the bin of the candidate its value points to (clipped to next + 1: "no earlier candidate")
-		for (uint32_t i = my_begin; i < my_end; ++i) {
-			uint32_t const d = dv[i];
-			if (d == d_max) { ++my_cnt; continue; }
-			// biased 0 ("no match yet") is the SMALLEST value: the walk reaches it last, it points to no candidate, and the only
-			// count that includes it is the final one (all copies): it takes no part in the bins
-			if (0u == d) continue;
-			uint32_t bin = next + 1u;
-			if (d - 1u <= n_edges) { uint32_t const c = first_candidate_from_edge[d - 1u]; bin = c < bin ? c : bin; }
-			uint32_t slot = (bin * 2654435761u) >> 20 & (uint32_t) (kPbwtHashSlots - 1);
-			bool placed = false;
-			for (int probe = 0; probe < kPbwtHashSlots && !placed; ++probe) {   // (bounded: a full table ends the chunk, below)
-				uint32_t const seen = atomicCAS(&hash_key[slot], 0u, bin + 1u);
-				if (0u == seen) {                                       // claimed a free slot
-					uint32_t const k = atomicAdd(&n_bins_s, 1u);
-					if (k < (uint32_t) kPbwtMaxBins) bin_slot[k] = slot;
-					placed = true;
-				} else if (seen == bin + 1u) {
-					placed = true;
-				} else {
-					slot = (slot + 1u) & (uint32_t) (kPbwtHashSlots - 1);
-				}
+		for (int k = 0; k < kPbwtPerThread; ++k) {
+			if ((uint32_t) k < per) {
+				d[k] = (uint32_t) k < my_count ? dv[my_begin + k] : 0u;
+				my_max = umax(my_max, d[k]);
 			}
-			if (placed) atomicAdd(&hash_count[slot], 1u);
-			else failed_s = 1u;
+		}
+		my_max = wave_inclusive_max(my_max);
+		if (lane == 63) reduce_max[wave] = my_max;
+		pbwt_block_sync();
+		uint32_t const d_max = (uint32_t) __builtin_amdgcn_readlane((int) row_inclusive_max(reduce_max[lane & (kPbwtWaves - 1)]), kPbwtWaves - 1);
+		// every other copy goes into the bin of the candidate its value points to (clipped to next + 1: "no earlier candidate");
+		// biased 0 ("no match yet") is the SMALLEST value: the walk reaches it last, it points to no candidate, and the only
+		// count that includes it is the final one (all copies): it takes no part in the bins
+		uint32_t my_cnt = 0;
+		uint32_t bin[kPbwtPerThread];
+#pragma unroll
+		for (int k = 0; k < kPbwtPerThread; ++k) {
+			if ((uint32_t) k < per) {
+				bool const valid = (uint32_t) k < my_count;
+				bool const binned = valid && 0u != d[k] && d[k] != d_max;
+				my_cnt += (valid && d[k] == d_max) ? 1u : 0u;
+				uint32_t c = next + 1u;
+				if (binned && d[k] - 1u <= n_edges) c = first_candidate_from_edge[d[k] - 1u];   // (all of a thread's loads go out before any is used)
+				bin[k] = binned ? (c < next + 1u ? c : next + 1u) : 0xFFFFFFFFu;
+			}
 		}
 #pragma unroll
-		for (int delta = 32; delta >= 1; delta >>= 1) my_cnt += __shfl_xor(my_cnt, delta, 64);
-		if (lane == 0) reduce_cnt[wave] = my_cnt;
+		for (int k = 0; k < kPbwtPerThread; ++k) {
+			if ((uint32_t) k < per) {
+				// Thousands of copies share a few dozen bins, and LDS atomics of one wave on one address run one after the other: the
+				// wave's two most frequent bins of this round (as seen from its first lanes) are counted with a ballot and added once.
+				bool active = 0xFFFFFFFFu != bin[k];
+				uint32_t count = 1u;
+				bool merged = false;
+#pragma unroll
+				for (int round = 0; round < 2; ++round) {
+					unsigned long long const open = __ballot(active && !merged);
+					if (0ull == open) break;                                  // (wave-uniform)
+					int const leader = __ffsll((long long) open) - 1;
+					uint32_t const lead_bin = (uint32_t) __builtin_amdgcn_readlane((int) bin[k], leader);
+					unsigned long long const same = __ballot(active && !merged && bin[k] == lead_bin);
+					if (active && !merged && bin[k] == lead_bin) {
+						if (lane == leader) { count = (uint32_t) __popcll(same); merged = true; }
+						else active = false;
+					}
+				}
+				if (active) pbwt_bin_add(hash_key, hash_count, bin_slot, &n_bins_s, &failed_s, bin[k], count);
+			}
+		}
+		my_cnt = wave_inclusive_add(my_cnt);
+		if (lane == 63) reduce_cnt[wave] = my_cnt;
 		pbwt_block_sync();
-		uint32_t count_max = 0;
-		for (int w = 0; w < kPbwtWaves; ++w) count_max += reduce_cnt[w];
+		uint32_t const count_max = (uint32_t) __builtin_amdgcn_readlane((int) row_inclusive_add(reduce_cnt[lane & (kPbwtWaves - 1)]), kPbwtWaves - 1);
 		uint32_t const n_bins = n_bins_s;
-		if (n_bins > (uint32_t) kPbwtMaxBins || failed_s) {                        // (workgroup-uniform) more bins than this kernel sorts: the host takes the chunk
+		if (n_bins > (uint32_t) kPbwtMaxBins || failed_s) {                        // (workgroup-uniform) more bins than this kernel holds: the host takes the chunk
 			if (t == 0) chunk_status[chunk] = 1u;
 			return;
 		}
-		// sort the bins by key, descending: rank by counting (a few dozen bins)
-		uint32_t key = 0, cnt = 0, rank = 0;
-		if ((uint32_t) t < n_bins) {
+		// The trials (find_cut_positions.cc:139-160): the bins in descending key order, bin r tried with class_count = copies in
+		// the bins before it (larger values) + the largest value's copies, unless it is the clipped bin, the candidate itself, or
+		// too close.  Config 4 has several hundred bins per candidate, so nothing here may walk the bins one by one (round 3 ranked
+		// them with a dependent LDS loop per thread and summed the counts with two more: ~14 us per candidate).  What bin i needs --
+		// the copies and the number of EMITTING bins among the bins with a larger key -- is one sum over the pairs (i, j) with
+		// key_j > key_i, spread over all 1024 threads; no sort, no scan: a trial's slot is that number.
+		// phase D: the table's entries into dense arrays (bin_key / bin_packed: copies | emits << 16), the table left empty
+		uint32_t my_key = 0, my_packed = 0;
+		bool const have = (uint32_t) t < n_bins;
+		if (have) {
 			uint32_t const slot = bin_slot[t];
-			key = hash_key[slot] - 1u;
-			cnt = hash_count[slot];
-			for (uint32_t j = 0; j < n_bins; ++j) rank += (hash_key[bin_slot[j]] - 1u) > key;
-		}
-		pbwt_block_sync();
-		if ((uint32_t) t < n_bins) {
-			sorted_key[rank] = key;
-			sorted_count[rank] = cnt;
-			uint32_t const slot = bin_slot[t];                       // leave the table empty for the next candidate
-			hash_key[slot] = 0;
+			my_key = hash_key[slot] - 1u;
+			uint32_t const cnt = hash_count[slot];
+			hash_key[slot] = 0;                                      // leave the table empty for the next candidate
 			hash_count[slot] = 0;
+			bool const emits = my_key != next + 1u && my_key != next && min_distance <= cand_aligned[next] - cand_aligned[my_key];
+			my_packed = cnt | (emits ? 0x10000u : 0u);
 		}
-		if (t == 0) n_bins_s = 0;
+		if ((uint32_t) t < ((n_bins + 3u) & ~3u)) { bin_key[t] = my_key; bin_packed[t] = my_packed; bin_sum[t] = 0u; }   // (padded to whole groups of four with key 0: larger than nothing)
+		{
+			uint32_t const emits_wave = wave_inclusive_add(my_packed >> 16);
+			uint32_t smallest = have ? my_key : 0xFFFFFFFFu;
+			smallest = ~wave_inclusive_max(~smallest);                   // (a running minimum)
+			if (lane == 63 && emits_wave) atomicAdd(&emitted_s, emits_wave);
+			if (lane == 63 && 0xFFFFFFFFu != smallest) atomicMin(&smallest_s, smallest);
+		}
 		pbwt_block_sync();
-		// the trials: bin r is tried with class_count = copies in the bins before it (larger values) + the largest value's copies,
-		// unless it is the clipped bin, the candidate itself, or too close (find_cut_positions.cc:139-160)
-		uint32_t class_before = count_max, emit = 0;
-		if ((uint32_t) t < n_bins) {
-			for (uint32_t j = 0; j < (uint32_t) t; ++j) class_before += sorted_count[j];
-			uint32_t const k = sorted_key[t];
-			emit = (k != next + 1u && k != next && min_distance <= cand_aligned[next] - cand_aligned[k]) ? 1u : 0u;
-			sorted_emit[t] = emit;
+		// phase R: thread t = (bin i, part): the pairs (i, j) with j in the part's slice of the bins
+		{
+			uint32_t n_pad = 64u;
+			while (n_pad < n_bins) n_pad <<= 1;                                 // 64 .. 1024: a wave's lanes share their slice (LDS broadcasts)
+			uint32_t const parts = (uint32_t) kPbwtThreads / n_pad;
+			uint32_t const i = (uint32_t) t & (n_pad - 1u), part = (uint32_t) t / n_pad;
+			uint32_t const groups = (n_bins + 3u) / 4u, per_part = (groups + parts - 1u) / parts;
+			uint32_t const g0 = part * per_part, g1 = g0 + per_part < groups ? g0 + per_part : groups;
+			if (i < n_bins && g0 < g1) {
+				uint32_t const key_i = bin_key[i];
+				uint32_t acc = 0;
+				for (uint32_t g = g0; g < g1; ++g) {
+					uint4 const kj = reinterpret_cast<uint4 const *>(bin_key)[g], pj = reinterpret_cast<uint4 const *>(bin_packed)[g];
+					acc += kj.x > key_i ? pj.x : 0u;
+					acc += kj.y > key_i ? pj.y : 0u;
+					acc += kj.z > key_i ? pj.z : 0u;
+					acc += kj.w > key_i ? pj.w : 0u;
+				}
+				if (acc) atomicAdd(&bin_sum[i], acc);
+			}
 		}
 		pbwt_block_sync();
-		uint32_t emitted = 0;                                           // how many bins emit (every thread computes it: small)
-		uint32_t my_slot = 0;
-		for (uint32_t j = 0; j < n_bins; ++j) { if (j == (uint32_t) t) my_slot = emitted; emitted += sorted_emit[j]; }
-		// after the loop: the segment may reach further left still (find_cut_positions.cc:162-165)
-		uint32_t right_bound = next + 1u;
-		if (n_bins) { uint32_t const smallest = sorted_key[n_bins - 1]; right_bound = smallest < right_bound ? smallest : right_bound; }
-		bool const last_trial = 0u != right_bound && right_bound - 1u != next;
-		if (n_trials + emitted + (last_trial ? 1u : 0u) > trial_capacity) {   // (workgroup-uniform)
-			if (t == 0) chunk_status[chunk] = 1u;
-			return;
+		// phase W: the trials
+		{
+			uint32_t const emitted = emitted_s;
+			// after the loop: the segment may reach further left still (find_cut_positions.cc:162-165)
+			uint32_t right_bound = next + 1u;
+			if (n_bins) right_bound = smallest_s < right_bound ? smallest_s : right_bound;
+			bool const last_trial = 0u != right_bound && right_bound - 1u != next;
+			if (n_trials + emitted + (last_trial ? 1u : 0u) > trial_capacity) {   // (workgroup-uniform) the trials do not fit: the host takes the chunk
+				if (t == 0) chunk_status[chunk] = 1u;
+				return;
+			}
+			if (have && (my_packed >> 16)) {
+				uint32_t const before = bin_sum[t];                              // copies | emitting bins << 16 of the bins with a larger key
+				my_pred[n_trials + (before >> 16)] = my_key;
+				my_class[n_trials + (before >> 16)] = count_max + (before & 0xFFFFu);
+			}
+			n_trials += emitted;
+			if (last_trial) {
+				if (t == 0) { my_pred[n_trials] = right_bound - 1u; my_class[n_trials] = n_copies; }
+				++n_trials;
+			}
+			if (t == 0) trial_end[cand] = n_trials;
 		}
-		if ((uint32_t) t < n_bins && emit) { my_pred[n_trials + my_slot] = sorted_key[t]; my_class[n_trials + my_slot] = class_before; }
-		n_trials += emitted;
-		if (last_trial) {
-			if (t == 0) { my_pred[n_trials] = right_bound - 1u; my_class[n_trials] = n_copies; }
-			++n_trials;
-		}
-		if (t == 0) trial_end[cand] = n_trials;
-		pbwt_block_sync();                                                // sorted_* are rewritten by the next candidate
+		pbwt_block_sync();                                                // bin_* and the two totals are rewritten by the next candidate
+		if (t == 0) { n_bins_s = 0; emitted_s = 0; smallest_s = 0xFFFFFFFFu; }   // (read again only behind the next candidate's barriers)
 	}
 	if (t == 0) chunk_status[chunk] = 0u;
 }
@@ -311,19 +480,38 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 constexpr uint32_t kPbwtNoClass = 0xFFFFu;            // the host's kPloidyMax in the 16-bit class arrays
 
 struct class_scan_item {
-	int last_block_start;     // last index with a block-class boundary, -1 = none yet
-	uint32_t block_starts;    // boundaries of the block (prev_cut_edge < d)
-	uint32_t span_starts;     // boundaries of the two-block span (cut_pair_edge < d)
+	uint32_t last_block_start;   // 1 + the last index with a block-class boundary, 0 = none yet (so that all-zero is the identity)
+	uint32_t block_starts;       // boundaries of the block (prev_cut_edge < d)
+	uint32_t span_starts;        // boundaries of the two-block span (cut_pair_edge < d)
 };
 
 __device__ __forceinline__ class_scan_item class_combine(class_scan_item const &a, class_scan_item const &b)
 {
-	return class_scan_item{b.last_block_start > a.last_block_start ? b.last_block_start : a.last_block_start, a.block_starts + b.block_starts, a.span_starts + b.span_starts};
+	return class_scan_item{umax(a.last_block_start, b.last_block_start), a.block_starts + b.block_starts, a.span_starts + b.span_starts};
 }
 
-__device__ __forceinline__ class_scan_item class_shfl_up(class_scan_item const &x, int delta)
+template <int kCtrl, int kRowMask>
+__device__ __forceinline__ class_scan_item class_round(class_scan_item const &x)
 {
-	return class_scan_item{__shfl_up(x.last_block_start, delta, 64), __shfl_up(x.block_starts, delta, 64), __shfl_up(x.span_starts, delta, 64)};
+	class_scan_item const up{pbwt_dpp<kCtrl, kRowMask>(x.last_block_start), pbwt_dpp<kCtrl, kRowMask>(x.block_starts), pbwt_dpp<kCtrl, kRowMask>(x.span_starts)};
+	return class_combine(up, x);
+}
+
+__device__ __forceinline__ class_scan_item class_row_scan(class_scan_item x)
+{
+	x = class_round<kDppRowShr1, 0xf>(x);
+	x = class_round<kDppRowShr2, 0xf>(x);
+	x = class_round<kDppRowShr4, 0xf>(x);
+	x = class_round<kDppRowShr8, 0xf>(x);
+	return x;
+}
+
+__device__ __forceinline__ class_scan_item class_wave_scan(class_scan_item x)
+{
+	x = class_row_scan(x);
+	x = class_round<kDppBcast15, 0xa>(x);
+	x = class_round<kDppBcast31, 0xc>(x);
+	return x;
 }
 
 // "threshold < unbiased(d)" with d biased: 0 is the reference's DIVERGENCE_MAX ("no match yet": starts a class)
@@ -342,9 +530,9 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 {
 	__shared__ unsigned short order[2][kPbwtMaxCopies];
 	__shared__ uint32_t divergence[2][kPbwtMaxCopies];
-	__shared__ uint64_t column[kPbwtMaxCopies / 64];
-	__shared__ pbwt_scan_item wave_items[kPbwtWaves];
-	__shared__ class_scan_item class_items[kPbwtWaves];
+	__shared__ uint64_t column[2][kPbwtMaxCopies / 64];
+	__shared__ uint4 wave_items[kPbwtWaves];
+	__shared__ uint4 class_items[kPbwtWaves];
 	__shared__ unsigned short copy_class[2][kPbwtMaxCopies];      // per copy: the representative of its class at the last / the previous cut
 	__shared__ unsigned short span_start_index[kPbwtMaxCopies];   // per joined class: where it starts in the order
 
@@ -355,6 +543,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	uint32_t const per = (n_copies + kPbwtThreads - 1) / kPbwtThreads;
 	uint32_t const my_begin = (uint32_t) t * per < n_copies ? (uint32_t) t * per : n_copies;
 	uint32_t const my_end = my_begin + per < n_copies ? my_begin + per : n_copies;
+	uint32_t const my_count = my_end - my_begin;
 
 	for (uint32_t i = t; i < n_copies; i += kPbwtThreads) {
 		order[0][i] = (unsigned short) start_order[(uint64_t) chunk * n_copies + i];
@@ -362,15 +551,15 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 		copy_class[0][i] = (unsigned short) kPbwtNoClass;
 		copy_class[1][i] = (unsigned short) kPbwtNoClass;
 	}
-	pbwt_block_sync();
-
 	int cur = 0, rhs = 0;                                  // copy_class[rhs]: the classes the last cut left behind
 	uint32_t edge = start_edge[chunk];
-	uint64_t column_word = pbwt_fetch_column(paths_by_edge, words_per_edge, edge, n_edge_columns, t);
+	pbwt_column_stream cols = pbwt_prime_columns(paths_by_edge, words_per_edge, edge, n_edge_columns, column, t);
+	pbwt_block_sync();
+
 	// up to the cut before the chunk's first one; the classes it left behind (founder.cc:scan_cut_chunk)
 	uint64_t const start_cut = cut_begin - 1;
 	for (uint32_t const upto = cut_edge[start_cut]; edge < upto; ++edge) {
-		pbwt_step(paths_by_edge, words_per_edge, edge, n_edge_columns, column_word, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
+		pbwt_step(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, cur, per, my_begin, my_count, t, lane, wave);
 		cur ^= 1;
 	}
 
@@ -378,50 +567,62 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	// with_span: also the joined classes of the two-block span, written to the pool.  Returns false when the pool is full.
 	uint64_t n_pool = 0;
 	uint32_t *const my_lhs = pool_lhs + (uint64_t) chunk * pool_capacity, *const my_rhs = pool_rhs + (uint64_t) chunk * pool_capacity, *const my_size = pool_size + (uint64_t) chunk * pool_capacity;
+	// Two barriers.  (What a call leaves in class_items / span_start_index / copy_class is only rewritten behind the first barrier of
+	// whatever runs next -- a pBWT step or another call -- and every read of it here lies before this call's last one.)
 	auto const classes_at_cut = [&](uint32_t block_threshold, bool with_span, uint32_t span_threshold, uint32_t &distinct_out) -> bool {
 		unsigned short const *const ord = order[cur];
 		uint32_t const *const dv = divergence[cur];
-		class_scan_item mine{-1, 0u, 0u};
-		for (uint32_t i = my_begin; i < my_end; ++i) {
-			uint32_t const d = dv[i];
-			if (past_edge(d, block_threshold)) { mine.last_block_start = (int) i; ++mine.block_starts; }
-			if (with_span && past_edge(d, span_threshold)) ++mine.span_starts;
-		}
-		class_scan_item incl = mine;
+		uint32_t copy[kPbwtPerThread], d[kPbwtPerThread];
+		class_scan_item mine{0u, 0u, 0u};
 #pragma unroll
-		for (int delta = 1; delta < 64; delta <<= 1) {
-			class_scan_item const up = class_shfl_up(incl, delta);
-			if (lane >= delta) incl = class_combine(up, incl);
+		for (int k = 0; k < kPbwtPerThread; ++k) {
+			if ((uint32_t) k < per) {                                       // (uniform)
+				bool const valid = (uint32_t) k < my_count;
+				copy[k] = ord[my_begin + k];
+				d[k] = dv[my_begin + k];
+				if (valid && past_edge(d[k], block_threshold)) { mine.last_block_start = my_begin + (uint32_t) k + 1u; ++mine.block_starts; }
+				if (valid && with_span && past_edge(d[k], span_threshold)) ++mine.span_starts;
+			}
 		}
-		if (lane == 63) class_items[wave] = incl;
+		class_scan_item const incl = class_wave_scan(mine);
+		if (lane == 63) class_items[wave] = uint4{incl.last_block_start, incl.block_starts, incl.span_starts, 0u};
 		pbwt_block_sync();
-		class_scan_item before{-1, 0u, 0u}, total{-1, 0u, 0u};
-		for (int w = 0; w < kPbwtWaves; ++w) {
-			class_scan_item const wi = class_items[w];
-			if (w < wave) before = class_combine(before, wi);
-			total = class_combine(total, wi);
+		uint4 const wi = class_items[lane & (kPbwtWaves - 1)];
+		class_scan_item const waves_incl = class_row_scan(class_scan_item{wi.x, wi.y, wi.z});
+		class_scan_item const total{0u, (uint32_t) __builtin_amdgcn_readlane((int) waves_incl.block_starts, kPbwtWaves - 1), (uint32_t) __builtin_amdgcn_readlane((int) waves_incl.span_starts, kPbwtWaves - 1)};
+		int const w = __builtin_amdgcn_readfirstlane(wave);
+		class_scan_item before{0u, 0u, 0u};
+		if (w > 0) {
+			before.last_block_start = (uint32_t) __builtin_amdgcn_readlane((int) waves_incl.last_block_start, w - 1);
+			before.block_starts = (uint32_t) __builtin_amdgcn_readlane((int) waves_incl.block_starts, w - 1);
+			before.span_starts = (uint32_t) __builtin_amdgcn_readlane((int) waves_incl.span_starts, w - 1);
 		}
-		class_scan_item const lane_before = class_shfl_up(incl, 1);
-		if (lane) before = class_combine(before, lane_before);
+		class_scan_item const lanes_before{pbwt_dpp<kDppWaveShr1, 0xf>(incl.last_block_start), pbwt_dpp<kDppWaveShr1, 0xf>(incl.block_starts), pbwt_dpp<kDppWaveShr1, 0xf>(incl.span_starts)};
+		before = class_combine(before, lanes_before);
 		distinct_out = total.block_starts;
 		bool const fits = !with_span || n_pool + total.span_starts <= pool_capacity;     // (workgroup-uniform)
 		// second pass: representatives, class arrays, joined-class heads
-		int last = before.last_block_start;
+		uint32_t last = before.last_block_start;                       // 1 + index, 0 = none
 		uint32_t span_at = before.span_starts;
 		unsigned short const *const lhs_class = copy_class[rhs];       // (the previous cut's classes: read)
 		unsigned short *const rhs_class = copy_class[rhs ^ 1];         // (this cut's: written; the arrays swap roles below)
-		for (uint32_t i = my_begin; i < my_end; ++i) {
-			uint32_t const d = dv[i], copy = ord[i];
-			if (past_edge(d, block_threshold)) last = (int) i;
-			uint32_t const rep = last >= 0 ? (uint32_t) ord[last] : kPbwtNoClass;
-			if (with_span && fits && past_edge(d, span_threshold)) {
-				uint32_t const l = lhs_class[copy];
-				my_lhs[n_pool + span_at] = kPbwtNoClass == l ? 0xFFFFFFFFu : l;
-				my_rhs[n_pool + span_at] = kPbwtNoClass == rep ? 0xFFFFFFFFu : rep;
-				span_start_index[span_at] = (unsigned short) i;
-				++span_at;
+#pragma unroll
+		for (int k = 0; k < kPbwtPerThread; ++k) {
+			if ((uint32_t) k < per) {
+				bool const valid = (uint32_t) k < my_count;
+				if (valid) {
+					if (past_edge(d[k], block_threshold)) last = my_begin + (uint32_t) k + 1u;
+					uint32_t const rep = last ? (uint32_t) ord[last - 1u] : kPbwtNoClass;
+					if (with_span && fits && past_edge(d[k], span_threshold)) {
+						uint32_t const l = lhs_class[copy[k]];
+						my_lhs[n_pool + span_at] = kPbwtNoClass == l ? 0xFFFFFFFFu : l;
+						my_rhs[n_pool + span_at] = kPbwtNoClass == rep ? 0xFFFFFFFFu : rep;
+						span_start_index[span_at] = (unsigned short) (my_begin + (uint32_t) k);
+						++span_at;
+					}
+					rhs_class[copy[k]] = (unsigned short) rep;
+				}
 			}
-			rhs_class[copy] = (unsigned short) rep;
 		}
 		pbwt_block_sync();
 		if (with_span && fits) {
@@ -430,7 +631,6 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 			n_pool += total.span_starts;
 		}
 		rhs ^= 1;
-		pbwt_block_sync();                                                // class_items / span_start_index are rewritten by the next call
 		return fits;
 	};
 
@@ -442,7 +642,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	bool first_is_ref = true;
 	for (uint64_t cut = cut_begin; cut < cut_end; ++cut) {
 		for (uint32_t const upto = cut_edge[cut]; edge < upto; ++edge) {
-			uint32_t const zeros = pbwt_step(paths_by_edge, words_per_edge, edge, n_edge_columns, column_word, order, divergence, column, wave_items, cur, my_begin, my_end, t, lane, wave);
+			uint32_t const zeros = pbwt_step(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, cur, per, my_begin, my_count, t, lane, wave);
 			cur ^= 1;
 			// the copy that is first in the order now uses the edge exactly when no copy does not (:454-462)
 			first_is_ref = first_is_ref && 0u != zeros;
