@@ -29,6 +29,10 @@ hg = HostGraph.from_arrays(g, src.cpu().numpy().view(np.uint64), hp, ep, ds.samp
 hg.set_transposed_paths(dst.cpu().numpy().view(np.uint64), ep, hp)
 for rep in range(reps):
 	t = time.time()
+	if os.environ.get("FOUNDER_BENCH_SEARCH_ONLY"):      # the cut search alone (timing-only kernel variants give cut positions no matching could use)
+		res = hg.find_cut_positions_gpu(ctx, min_dist, threads=16)
+		print("run %d: cut search alone %.3f s; %s" % (rep, time.time() - t, "no solution" if res is None else "%d cuts, score %d" % (len(res[0]), res[1])), flush=True)
+		continue
 	cuts, assigned, score = hg.find_founders_gpu(ctx, founders, min_dist, keep_ref_edges=False, threads=16)
 	dt = time.time() - t
 	print("run %d: %.3f s; %d cuts, score %d, chunks (search GPU, host; matching GPU, host) = %s; crc32 cuts %08x matchings %08x" % (rep, dt, len(cuts), score, hg.gpu_chunks,

@@ -21,12 +21,12 @@
 
 namespace v2m {
 
-constexpr int kPbwtThreads = 1024;
+constexpr int kPbwtThreads = 1024;                    // (512 / 256 threads with twice / four times the copies each: 40.5 + 22.0 ms / 71.7 + 39.9 ms at config 4 against 30.5 + 17.3)
 constexpr int kPbwtWaves = kPbwtThreads / 64;
 constexpr int kPbwtMaxCopies = 8192;                  // chromosome copies a workgroup can walk (LDS-resident state)
 constexpr int kPbwtPerThread = kPbwtMaxCopies / kPbwtThreads;
 constexpr int kPbwtHashSlots = 4096;                  // distinct candidate bins per candidate node: far fewer in practice
-constexpr int kPbwtMaxBins = 1024;                    // more distinct bins than this at one candidate: the chunk is left to the host
+constexpr int kPbwtMaxBins = kPbwtThreads;            // more distinct bins than this at one candidate (a thread per bin): the chunk is left to the host
 
 // __syncthreads() with the LDS wait spelled out: on loop back edges hipcc (ROCm 7.2) has emitted the barrier without the
 // s_waitcnt lgkmcnt(0) that __syncthreads() implies (kernels.hpp, ring transpose; tests/test_kernel_isa.py checks every
@@ -358,27 +358,15 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 				bin[k] = binned ? (c < next + 1u ? c : next + 1u) : 0xFFFFFFFFu;
 			}
 		}
+		// About a hundred bins per candidate at config 4, a dozen of which hold most of the 5008 copies.  Measured there, against this
+		// plain loop (30.5 ms for the kernel): counting a wave's most frequent bins with ballots first and adding them once, 34.5 ms
+		// with one such round, 36.6 with two, 43.9 with four; a plain read of the key before the compare-and-swap, 31.9; all of a
+		// thread's lookups issued together, 33.3; without any insertion the kernel takes 17.9 ms, its pBWT steps alone 11.5
+		// (profiles/r04/founder_kernels_what_bounds_them.txt).
 #pragma unroll
 		for (int k = 0; k < kPbwtPerThread; ++k) {
 			if ((uint32_t) k < per) {
-				// Thousands of copies share a few dozen bins, and LDS atomics of one wave on one address run one after the other: the
-				// wave's two most frequent bins of this round (as seen from its first lanes) are counted with a ballot and added once.
-				bool active = 0xFFFFFFFFu != bin[k];
-				uint32_t count = 1u;
-				bool merged = false;
-#pragma unroll
-				for (int round = 0; round < 2; ++round) {
-					unsigned long long const open = __ballot(active && !merged);
-					if (0ull == open) break;                                  // (wave-uniform)
-					int const leader = __ffsll((long long) open) - 1;
-					uint32_t const lead_bin = (uint32_t) __builtin_amdgcn_readlane((int) bin[k], leader);
-					unsigned long long const same = __ballot(active && !merged && bin[k] == lead_bin);
-					if (active && !merged && bin[k] == lead_bin) {
-						if (lane == leader) { count = (uint32_t) __popcll(same); merged = true; }
-						else active = false;
-					}
-				}
-				if (active) pbwt_bin_add(hash_key, hash_count, bin_slot, &n_bins_s, &failed_s, bin[k], count);
+				if (0xFFFFFFFFu != bin[k]) pbwt_bin_add(hash_key, hash_count, bin_slot, &n_bins_s, &failed_s, bin[k], 1u);
 			}
 		}
 		my_cnt = wave_inclusive_add(my_cnt);
@@ -399,6 +387,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		// phase D: the table's entries into dense arrays (bin_key / bin_packed: copies | emits << 16), the table left empty
 		uint32_t my_key = 0, my_packed = 0;
 		bool const have = (uint32_t) t < n_bins;
+
 		if (have) {
 			uint32_t const slot = bin_slot[t];
 			my_key = hash_key[slot] - 1u;
@@ -421,7 +410,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		{
 			uint32_t n_pad = 64u;
 			while (n_pad < n_bins) n_pad <<= 1;                                 // 64 .. 1024: a wave's lanes share their slice (LDS broadcasts)
-			uint32_t const parts = (uint32_t) kPbwtThreads / n_pad;
+			uint32_t const parts = (uint32_t) kPbwtThreads / n_pad;          // (n_bins <= kPbwtMaxBins = the threads: at least one)
 			uint32_t const i = (uint32_t) t & (n_pad - 1u), part = (uint32_t) t / n_pad;
 			uint32_t const groups = (n_bins + 3u) / 4u, per_part = (groups + parts - 1u) / parts;
 			uint32_t const g0 = part * per_part, g1 = g0 + per_part < groups ? g0 + per_part : groups;
