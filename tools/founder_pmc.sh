@@ -32,3 +32,11 @@ for kernel in ("pbwt_cut_trials_kernel", "pbwt_cut_records_kernel"):
 	for c in sorted(tot): print("   %-28s %16.0f per launch (%d launches)" % (c, tot[c] / n[c], n[c]))
 PY
 rm -rf $OUT/pmc_[0-9]
+# which sources these figures belong to: git blob hashes of everything libv2m_hip.so is compiled from (as profiles/pmc_traffic.json carries them)
+python3 - <<'PY'
+import json, sys
+sys.path.insert(0, ".")
+import bench
+json.dump({"_note": "kernel sources (git blob hashes) of the library that tools/founder_pmc.sh measured: kernel_stats.csv and summary.txt next to this file", "kernel_sources": bench.kernel_source_stamp()},
+	open("gpurun_out/founder_pmc/provenance.json", "w"), indent=1)
+PY
