@@ -709,6 +709,20 @@ def main():
 			ctx.profile_enable(False)
 			u_count, u_splice, u_resolve = u_count / reps, u_splice / reps, u_resolve / reps
 			bases_u = int(lengths.sum())
+			# like for like: the ALIGNED kernel on the very same rows, buffer and pitch (what a launch reaches depends on the address range it
+			# covers and on the buffer's backing -- DESIGN.md section 4, profiles/r04/unaligned_footprint_4_buffers.txt -- so the full-footprint
+			# aligned launches of the timed region are the wrong yardstick for a 256-row launch)
+			a_same = None
+			if upitch >= (L + 15) // 16 * 16:
+				ctx.splice_rows_device(ub, out_ptr, upitch)
+				ctx.synchronize()
+				ctx.profile_enable(True)
+				ctx.profile_reset()
+				for _ in range(reps):
+					ctx.splice_rows_device(ub, out_ptr, upitch)
+				n_a, ms_a = ctx.profile_get(N.KERNEL_SPLICE_ALIGNED)
+				ctx.profile_enable(False)
+				a_same = ms_a / max(1, n_a)
 			# pass 2 (splice_unaligned_kernel): row bytes out + the rows' bit columns + the shared inputs + one tile offset per (row, tile);
 			# pass 1 (count + scan): the shared inputs + bit columns in, the tile counts out and in and out again (scan in place)
 			alg_u = bases_u + n_u * Ep // 8 + shared_bytes + 4 * n_u * n_tiles
@@ -728,6 +742,9 @@ def main():
 				"roofline": {"bound": "hbm", "kernel": "splice_unaligned_kernel", "algorithmic_bytes_per_launch": int(alg_u), "achieved": round(alg_u / u_splice / 1e6, 1), "peak": HBM_PEAK_GBS,
 					"unit": "GB/s", "frac": round(alg_u / u_splice / 1e6 / HBM_PEAK_GBS, 4)},
 				"time_per_base_vs_aligned_kernel": round(ms_per_base / aligned_ms_per_base, 3) if aligned_ms_per_base > 0 else None,
+				"aligned_kernel_same_rows_ms": round(a_same, 3) if a_same else None,
+				"time_per_base_vs_aligned_kernel_same_rows": round(ms_per_base / (a_same / (n_u * L)), 3) if a_same else None,
+				"yardsticks": "time_per_base_vs_aligned_kernel: against the timed region's aligned launches (the output buffer's whole footprint); ..._same_rows: against the aligned kernel on these very rows, this buffer and this pitch",
 				"roofline_count_pass": {"bound": "hbm", "kernel": "count_unaligned_kernel+scan_tile_counts_kernel", "algorithmic_bytes_per_launch": int(alg_c), "achieved": round(alg_c / u_count / 1e6, 1),
 					"unit": "GB/s", "note": "reads the shared inputs and the rows' effective-edge bits, writes 4 bytes per (row, 16-KiB tile); builds no row"},
 				"parity": {"rows_checked": len(usample), "bit_exact": u_ok, "method": "row lengths and device checksums against the CPU oracle's unaligned rows"},

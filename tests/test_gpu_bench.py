@@ -48,6 +48,7 @@ def test_bench_line_has_the_contract_fields():
 		assert leg["value"] > 0 and leg["parity"]["bit_exact"] is True and leg["roofline"]["kernel"] == "splice_unaligned_kernel"
 		assert set(leg["kernels_ms"]) == {"resolve_effective_edges_kernel", "count_unaligned_kernel+scan_tile_counts_kernel", "splice_unaligned_kernel"}
 		assert leg["time_per_base_vs_aligned_kernel"] > 0 and leg["footprint_GB"] > 0
+		assert leg["aligned_kernel_same_rows_ms"] > 0 and leg["time_per_base_vs_aligned_kernel_same_rows"] > 0   # like for like: same rows, buffer and pitch
 	assert un["rows"] >= un["first_rows_only"]["rows"] and "tuning" in un
 	assert d["config"]["per_rank"] == [{"rank": 0, "rows": d["config"]["rows_total"], "batches": d["parity"]["batches_covered"], "ms_per_step": d["ms_per_step"],
 		"launches": roof["launches"], "avg_launch_ms": roof["avg_launch_ms"]}]
