@@ -42,7 +42,7 @@ struct options {
 	char const *output_sequences_a2m{}, *dst_chromosome{}, *output_overlaps{};
 	char const *include_samples{}, *exclude_samples{};
 	char const *input_graph{}, *output_graph{};
-	char const *pipe{}, *input_cut_positions{}, *output_cut_positions{}, *output_graphviz{};
+	char const *pipe{}, *input_cut_positions{}, *output_cut_positions{};
 	bool output_sequences_separate{}, separate_plain{}, omit_reference{}, unaligned{}, verbose{}, graph_statistics{};
 	bool ref_mismatch_error{};
 	std::vector<int> devices{0};
@@ -79,42 +79,11 @@ void usage()
 		"  -p, --input-cut-positions=file     Cut position input\n"
 		"  -t, --output-cut-positions=file    Output the cut positions\n"
 		"      --pipe=command                 Instead of writing sequences to files, pipe them to `command <name>`\n"
-		"  -v, --output-graphviz=filename     Output the variant graph in Graphviz format\n";
+		"  (--output-graphviz and --output-memory-breakdown are outside this build's scope: SURVEY.md section 2)\n";
 }
 
 typedef std::set<std::tuple<std::string, std::string, unsigned>> sample_set;
 
-
-// --output-graphviz (main.cc:53-120): nodes as records "node | reference position | aligned position", the reference
-// edges between consecutive nodes (bold) and the ALT edges, each labelled with its sequence; sequences longer than
-// 20 characters are shown as their first and last 10 around an ellipsis, with the length.
-void write_graphviz_label(std::ostream &os, std::string_view label)
-{
-	if (label.size() <= 20) os << label;
-	else os << label.substr(0, 10) << "\xE2\x80\xA6" << label.substr(label.size() - 10) << " (" << label.size() << ')';
-}
-
-void write_graphviz(vh::sequence_type const &ref_seq, vh::variant_graph const &graph, std::ostream &os)
-{
-	std::string_view const ref(ref_seq.data(), ref_seq.size());
-	os << "digraph variants {\n\trankdir = LR;\n\trank = same;\n";
-	for (vh::u64 n(0); n < graph.node_count(); ++n)
-		os << '\t' << n << " [shape = Mrecord, label = \"" << n << " | " << graph.reference_positions[n] << " | " << graph.aligned_positions[n] << "\"];\n";
-	os << '\n';
-	for (vh::u64 n(0); n + 1 < graph.node_count(); ++n) {
-		os << '\t' << n << " -> " << (n + 1) << " [label = \"";
-		write_graphviz_label(os, ref.substr(graph.reference_positions[n], graph.reference_positions[n + 1] - graph.reference_positions[n]));
-		os << "\", penwidth = 2.0];\n";
-	}
-	os << '\n';
-	for (vh::u64 n(0); n + 1 < graph.alt_edge_count_csum.size(); ++n)
-		for (vh::u64 e(graph.alt_edge_count_csum[n]); e < graph.alt_edge_count_csum[n + 1]; ++e) {
-			os << '\t' << n << " -> " << graph.alt_edge_targets[e] << " [label = \"";
-			write_graphviz_label(os, graph.label(e));
-			os << "\"];\n";
-		}
-	os << "}\n";
-}
 
 // main.cc:42-120 (sample filter lists): TSV rows (chrom, sample, copy_idx)
 sample_set read_sample_list(char const *path, char const *chromosome)
@@ -209,12 +178,12 @@ int main(int argc, char **argv)
 		{"ref-mismatch-handling", required_argument, nullptr, o_mismatch}, {"include-samples", required_argument, nullptr, o_include},
 		{"exclude-samples", required_argument, nullptr, 'x'}, {"device", required_argument, nullptr, o_device}, {"verbose", no_argument, nullptr, o_verbose},
 		{"input-graph", required_argument, nullptr, 'g'}, {"output-graph", required_argument, nullptr, 'f'},
-		{"output-graphviz", required_argument, nullptr, 'v'}, {"output-memory-breakdown", required_argument, nullptr, o_unsupported}, {"pipe", required_argument, nullptr, o_pipe},
+		{"output-graphviz", required_argument, nullptr, o_unsupported}, {"output-memory-breakdown", required_argument, nullptr, o_unsupported}, {"pipe", required_argument, nullptr, o_pipe},
 		{"minimum-distance", required_argument, nullptr, 'd'}, {"input-cut-positions", required_argument, nullptr, 'p'},
 		{"output-cut-positions", required_argument, nullptr, 't'}, {"keep-ref-edges", no_argument, nullptr, o_keep_ref},
 		{"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
 	int c;
-	while (-1 != (c = getopt_long(argc, argv, "HF:d:p:t:r:e:a:c:s:m:x:g:f:v:h", longopts, nullptr))) {
+	while (-1 != (c = getopt_long(argc, argv, "HF:d:p:t:r:e:a:c:s:m:x:g:f:h", longopts, nullptr))) {
 		switch (c) {
 			case 'H': opt.haplotypes = true; break;
 			case 'F': opt.founder_mode = true; opt.founder_sequences = std::atol(optarg); break;
@@ -254,7 +223,6 @@ int main(int argc, char **argv)
 			case o_pipe: opt.pipe = optarg; break;
 			case 'p': opt.input_cut_positions = optarg; break;
 			case 't': opt.output_cut_positions = optarg; break;
-			case 'v': opt.output_graphviz = optarg; break;
 			case 'h': usage(); return EXIT_SUCCESS;
 			case o_unsupported: std::cerr << "ERROR: option " << argv[optind - 1] << " is not supported by this build.\n"; return EXIT_FAILURE;
 			default: usage(); return EXIT_FAILURE;
@@ -330,16 +298,6 @@ int main(int argc, char **argv)
 		if (opt.output_graph) {                                 // main.cc:418-426
 			std::cerr << "Outputting the variant graph..." << std::flush;
 			vh::write_graph(graph, opt.output_graph);
-			std::cerr << " Done.\n";
-		}
-
-		if (opt.output_graphviz) {                              // main.cc:449-455
-			std::cerr << "Outputting the variant graph in Graphviz format..." << std::flush;
-			std::ofstream os(opt.output_graphviz, std::ios::binary | std::ios::trunc);
-			if (!os) throw std::runtime_error(std::string("unable to open ") + opt.output_graphviz + " for writing");
-			write_graphviz(ref_seq, graph, os);
-			os.flush();
-			if (!os) throw std::runtime_error(std::string("error while writing ") + opt.output_graphviz);
 			std::cerr << " Done.\n";
 		}
 
