@@ -694,6 +694,20 @@ def main():
 
 		def unaligned_leg(n_u, reps=3):
 			ub = v2m.RowBatch(rows[:n_u])
+			# like for like: the ALIGNED kernel on the very same rows, buffer and pitch (what a launch reaches depends on the address range it
+			# covers and on the buffer's backing -- DESIGN.md section 4, profiles/r04/unaligned_footprint_4_buffers.txt -- so the full-footprint
+			# aligned launches of the timed region are the wrong yardstick for a 256-row launch)
+			a_same = None
+			if upitch >= (L + 15) // 16 * 16:
+				ctx.splice_rows_device(ub, out_ptr, upitch)
+				ctx.synchronize()
+				ctx.profile_enable(True)
+				ctx.profile_reset()
+				for _ in range(reps):
+					ctx.splice_rows_device(ub, out_ptr, upitch)
+				n_a, ms_a = ctx.profile_get(N.KERNEL_SPLICE_ALIGNED)
+				ctx.profile_enable(False)
+				a_same = ms_a / max(1, n_a)
 			ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True)      # warm-up (builds the second template; first >= 1-GiB launch: calibrates the store flavour)
 			ctx.synchronize()
 			ctx.profile_enable(True)
@@ -709,20 +723,6 @@ def main():
 			ctx.profile_enable(False)
 			u_count, u_splice, u_resolve = u_count / reps, u_splice / reps, u_resolve / reps
 			bases_u = int(lengths.sum())
-			# like for like: the ALIGNED kernel on the very same rows, buffer and pitch (what a launch reaches depends on the address range it
-			# covers and on the buffer's backing -- DESIGN.md section 4, profiles/r04/unaligned_footprint_4_buffers.txt -- so the full-footprint
-			# aligned launches of the timed region are the wrong yardstick for a 256-row launch)
-			a_same = None
-			if upitch >= (L + 15) // 16 * 16:
-				ctx.splice_rows_device(ub, out_ptr, upitch)
-				ctx.synchronize()
-				ctx.profile_enable(True)
-				ctx.profile_reset()
-				for _ in range(reps):
-					ctx.splice_rows_device(ub, out_ptr, upitch)
-				n_a, ms_a = ctx.profile_get(N.KERNEL_SPLICE_ALIGNED)
-				ctx.profile_enable(False)
-				a_same = ms_a / max(1, n_a)
 			# pass 2 (splice_unaligned_kernel): row bytes out + the rows' bit columns + the shared inputs + one tile offset per (row, tile);
 			# pass 1 (count + scan): the shared inputs + bit columns in, the tile counts out and in and out again (scan in place)
 			alg_u = bases_u + n_u * Ep // 8 + shared_bytes + 4 * n_u * n_tiles

@@ -75,6 +75,26 @@ def test_separate_files_and_sample_filter(tmp_path):
 	assert g.total_chromosome_copies == 8 and go.total_chromosome_copies == 6
 
 
+def test_every_chromosome_copy_excluded(tmp_path):
+	"""A haploid one-sample VCF with that sample's only copy excluded: no chromosome copy is left, the path matrix has no rows, and
+	the A2M holds the REF row alone -- aligned (gaps where the excluded copy's insertion would go) and unaligned.  (Round 3's reader
+	refused this input; the graph and its edges are still built: variant_graph.cc:215-283.)"""
+	import numpy as np
+	records = [(2, b"G", [b"T"], np.array([[1]])), (5, b"CG", [b"C"], np.array([[1]])), (9, b"C", [b"G", b"CAA"], np.array([[2]]))]
+	fa, vcf = synth.write_inputs(str(tmp_path), b"ACGTACGTACGTACGT", records, 1)
+	excl = tmp_path / "excl.tsv"
+	excl.write_text("1\tS0\t0\n")
+	go = oracle.build_variant_graph(fa, vcf, "1", exclude_sample="S0", exclude_copy=0)
+	assert go.total_chromosome_copies == 0 and go.edge_count == 4
+	out = tmp_path / "out.a2m"
+	for extra, unaligned in (([], False), (["--unaligned"], True)):
+		r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-s", str(out), "-x", str(excl), "--output-graph-statistics"] + extra)
+		assert r.returncode == 0, r.stderr.decode()
+		assert out.read_bytes() == b">REF\n" + go.output_sequence(go.ref, unaligned=unaligned) + b"\n"
+		assert b"Total ploidy: 0" in r.stdout
+	assert b"-" in go.output_sequence(go.ref) and b"-" not in go.output_sequence(go.ref, unaligned=True)
+
+
 def test_one_megabase_end_to_end(tmp_path):
 	g = synth.build_case(tmp_path, 62, 1000000, 12000, 40, long_every=500)
 	fa, vcf = str(tmp_path / "synth.fa"), str(tmp_path / "synth.vcf")
