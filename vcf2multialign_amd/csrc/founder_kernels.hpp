@@ -65,7 +65,12 @@ __device__ __forceinline__ pbwt_scan_item scan_combine(pbwt_scan_item const &a, 
 // v_mov_b32_dpp with zeros where a lane has no source (or its row is masked out): the identity of every scan below, so a
 // round of a scan is "fetch, combine" with no per-lane select.  No LDS round trip, unlike __shfl_up (ds_bpermute_b32).
 template <int kCtrl, int kRowMask>
-__device__ __forceinline__ uint32_t pbwt_dpp(uint32_t v) { return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, kCtrl, kRowMask, 0xf, false); }
+__device__ __forceinline__ uint32_t pbwt_dpp(uint32_t v)
+{
+	// all rows enabled: bound_ctrl shifts zeros in, and the instruction needs no `old` operand set up beforehand; with rows masked out
+	// (the two broadcasts) those rows must come out as 0, which is what `old` = 0 gives them
+	return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, kCtrl, kRowMask, 0xf, 0xf == kRowMask);
+}
 
 constexpr int kDppRowShr1 = 0x111, kDppRowShr2 = 0x112, kDppRowShr4 = 0x114, kDppRowShr8 = 0x118, kDppBcast15 = 0x142, kDppBcast31 = 0x143, kDppWaveShr1 = 0x138;
 
@@ -177,31 +182,38 @@ __device__ __forceinline__ uint32_t pbwt_step(
 	unsigned short const *const ord = order[cur];
 	uint32_t const *const dv = divergence[cur];
 	uint64_t const *const col = column[cols.buf];
+	// A slot past the thread's last copy (only the last threads have any) counts as a copy of class 1 with divergence 0: it adds no zero,
+	// leaves p as it is, and what it does to q only reaches threads that hold no copy at all.  So nothing below selects on validity but the
+	// two stores of pass 2.
+	uint32_t const *const col32 = reinterpret_cast<uint32_t const *>(col);
 	uint32_t copy[kPbwtPerThread], d[kPbwtPerThread];
-	uint32_t flags = 0;
-	pbwt_scan_item mine{0u, 0u, 0u};
 #pragma unroll
 	for (int k = 0; k < kPbwtPerThread; ++k) {
 		if ((uint32_t) k < per) {                                           // (uniform)
-			bool const valid = (uint32_t) k < my_count;
-			copy[k] = valid ? (uint32_t) ord[my_begin + k] : 0u;             // (my_begin + k < 1024 * per <= kPbwtMaxCopies: inside the array either way)
+			copy[k] = ord[my_begin + k];                                     // (my_begin + k < 1024 * per <= kPbwtMaxCopies: inside the array either way)
 			d[k] = dv[my_begin + k];
 		}
 	}
+	uint32_t flags = 0;
+	uint32_t chain_p = 0u, chain_q = 0u;
 #pragma unroll
 	for (int k = 0; k < kPbwtPerThread; ++k) {
 		if ((uint32_t) k < per) {
 			bool const valid = (uint32_t) k < my_count;
-			uint32_t const f = (uint32_t) (col[copy[k] >> 6] >> (copy[k] & 63u)) & 1u;
+			uint32_t const c = valid ? copy[k] : 0u;
+			uint32_t const bit = (col32[c >> 5] >> (c & 31u)) & 1u;
+			uint32_t const f = valid ? bit : 1u;
+			d[k] = valid ? d[k] : 0u;
 			flags |= f << k;
-			// a copy of class 0 takes p and leaves biased 0 (= 1) behind; one of class 1 does that to q
-			uint32_t const one_p = f ? d[k] : (kChainConst | 1u), one_q = f ? (kChainConst | 1u) : d[k];
-			uint32_t const np = chain_then(mine.p, one_p), nq = chain_then(mine.q, one_q);
-			mine.zeros += valid ? 1u - f : 0u;
-			mine.p = valid ? np : mine.p;
-			mine.q = valid ? nq : mine.q;
+			// a copy of class 1 folds its value into p and leaves biased 0 (= 1) behind in q; one of class 0 the other way round
+			uint32_t const acc = f ? chain_p : chain_q;
+			uint32_t const keep = (acc & kChainConst) | d[k];
+			uint32_t const grown = acc > keep ? acc : keep;                   // chain_then(acc, d): d is never a constant
+			chain_p = f ? grown : (kChainConst | 1u);
+			chain_q = f ? (kChainConst | 1u) : grown;
 		}
 	}
+	pbwt_scan_item const mine{per - (uint32_t) __builtin_popcount(flags), chain_p, chain_q};
 	pbwt_scan_item const incl = wave_inclusive_scan(mine);
 	if (lane == 63) wave_items[wave] = uint4{incl.zeros, incl.p, incl.q, 0u};
 	pbwt_block_sync();
@@ -229,17 +241,17 @@ __device__ __forceinline__ uint32_t pbwt_step(
 #pragma unroll
 	for (int k = 0; k < kPbwtPerThread; ++k) {
 		if ((uint32_t) k < per) {
-			bool const valid = (uint32_t) k < my_count;
-			bool const f = 0u != ((flags >> k) & 1u);
+			uint32_t const fk = (flags >> k) & 1u;
+			bool const f = 0u != fk;
 			p = p > d[k] ? p : d[k];
 			q = q > d[k] ? q : d[k];
 			uint32_t const at = f ? one_at : zero_at;
 			uint32_t const value = f ? q : p;
-			if (valid) { out_ord[at] = (unsigned short) copy[k]; out_dv[at] = value; }
-			zero_at += (valid && !f) ? 1u : 0u;
-			one_at += (valid && f) ? 1u : 0u;
-			p = (valid && !f) ? 1u : p;
-			q = (valid && f) ? 1u : q;
+			if ((uint32_t) k < my_count) { out_ord[at] = (unsigned short) copy[k]; out_dv[at] = value; }
+			one_at += fk;
+			zero_at += fk ^ 1u;
+			p = f ? p : 1u;
+			q = f ? 1u : q;
 		}
 	}
 	// the next edge's column into the other buffer (nobody reads that one during this step), the one after it on its way
