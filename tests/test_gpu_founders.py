@@ -245,3 +245,25 @@ def test_edge_major_copy_is_kept_between_the_two_searches_and_dropped_with_the_b
 		assert ctx.profile_get(N.KERNEL_TRANSPOSE)[0] == 2
 		# no copy follows any ALT edge now: one path class from the first node to the last (the stale copy would give `want` again)
 		assert got0 != want and got0[0] == [0, len(hg0.reference_positions) - 1] and got0[2] == 1
+
+
+@pytest.mark.parametrize("n_samples", [1100, 1600, 2100, 2600, 3100, 4096], ids=lambda n: "%d_copies" % (2 * n))
+def test_every_copies_per_thread_instantiation(v2m, HostGraph, tmp_path, n_samples):
+	"""The founder kernels are instantiated per copies-per-thread count (ceil(copies / 1024) = 1 .. 8; the other tests use 1, 2 and 5):
+	2200 .. 8192 copies -- the last one the most a workgroup's LDS holds -- through both searches on the GPU against the host's sequential loops."""
+	rng = np.random.default_rng(4000 + n_samples)
+	ref = synth.random_reference(rng, 4000)
+	recs = synth.random_records(rng, ref, 160, n_samples, mix=(0.8, 0.1, 0.1), density=0.08)
+	fa, vcf = synth.write_inputs(str(tmp_path), ref, recs, n_samples)
+	og = oracle.build_variant_graph(fa, vcf, "1")
+	assert og.total_chromosome_copies == 2 * n_samples
+	hg = HostGraph(fa, vcf, "1")
+	hg.set_transposed_paths(og.paths_by_chrom_copy_and_edge, og.path_rows, og.path_cols)
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(v2m.VariantGraph.from_object(og), og.ref)
+		for founders, min_distance in ((3, 0), (25, 20)):
+			want = hg.find_founders(founders, min_distance, threads=1)
+			got = hg.find_founders_gpu(ctx, founders, min_distance, threads=4)
+			assert got == want, (founders, min_distance)
+			if want is not None and len(want[0]) > 2:
+				assert hg.gpu_chunks[1] == 0 and hg.gpu_chunks[3] == 0 and hg.gpu_chunks[0] >= 1 and hg.gpu_chunks[2] >= 1, hg.gpu_chunks

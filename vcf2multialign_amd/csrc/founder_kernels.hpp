@@ -164,8 +164,8 @@ __device__ __forceinline__ pbwt_column_stream pbwt_prime_columns(uint64_t const 
 }
 
 // One step of Durbin's algorithm 2 for edge `edge` (pbwt.hh:77-134) by the whole workgroup: state order[cur] / divergence[cur]
-// -> order[cur ^ 1] / divergence[cur ^ 1].  Thread t owns `my_count` <= per <= kPbwtPerThread consecutive copies of the order from
-// my_begin on (per is workgroup-uniform).  Returns how many copies do NOT use the edge (workgroup-uniform).  TWO barriers; the
+// -> order[cur ^ 1] / divergence[cur ^ 1].  Thread t owns `my_count` <= kPer <= kPbwtPerThread consecutive copies of the order from
+// my_begin on (kPer = ceil(copies / 1024) is a template parameter of the kernels: the per-copy loops unroll without a branch or a dead slot).  Returns how many copies do NOT use the edge (workgroup-uniform).  TWO barriers; the
 // caller flips `cur`.
 //   pass 1  the thread's copies, their divergence values and their bits of the edge into registers; what the run does to the zero
 //           count and to the two running maxima, folded locally; an inclusive scan of that over the wave (DPP)      -- barrier --
@@ -174,11 +174,13 @@ __device__ __forceinline__ pbwt_column_stream pbwt_prime_columns(uint64_t const 
 //           stashed                                                                                                  -- barrier --
 // Round 3's form of this step took 5 us at config 4 (three barriers, ds_bpermute scans over five registers, the 16 wave totals
 // combined serially by all 1024 threads, every copy read twice).
+template <int kPer>
 __device__ __forceinline__ uint32_t pbwt_step(
 	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge, uint32_t edge_limit, pbwt_column_stream &cols,
 	unsigned short (*order)[kPbwtMaxCopies], uint32_t (*divergence)[kPbwtMaxCopies], uint64_t (*column)[kPbwtMaxCopies / 64], uint4 *wave_items,
-	int cur, uint32_t per, uint32_t my_begin, uint32_t my_count, int t, int lane, int wave)
+	int cur, uint32_t my_begin, uint32_t my_count, int t, int lane, int wave)
 {
+	constexpr uint32_t per = kPer;
 	unsigned short const *const ord = order[cur];
 	uint32_t const *const dv = divergence[cur];
 	uint64_t const *const col = column[cols.buf];
@@ -186,9 +188,9 @@ __device__ __forceinline__ uint32_t pbwt_step(
 	// leaves p as it is, and what it does to q only reaches threads that hold no copy at all.  So nothing below selects on validity but the
 	// two stores of pass 2.
 	uint32_t const *const col32 = reinterpret_cast<uint32_t const *>(col);
-	uint32_t copy[kPbwtPerThread], d[kPbwtPerThread];
+	uint32_t copy[kPer], d[kPer];
 #pragma unroll
-	for (int k = 0; k < kPbwtPerThread; ++k) {
+	for (int k = 0; k < kPer; ++k) {
 		if ((uint32_t) k < per) {                                           // (uniform)
 			copy[k] = ord[my_begin + k];                                     // (my_begin + k < 1024 * per <= kPbwtMaxCopies: inside the array either way)
 			d[k] = dv[my_begin + k];
@@ -197,7 +199,7 @@ __device__ __forceinline__ uint32_t pbwt_step(
 	uint32_t flags = 0;
 	uint32_t chain_p = 0u, chain_q = 0u;
 #pragma unroll
-	for (int k = 0; k < kPbwtPerThread; ++k) {
+	for (int k = 0; k < kPer; ++k) {
 		if ((uint32_t) k < per) {
 			bool const valid = (uint32_t) k < my_count;
 			uint32_t const c = valid ? copy[k] : 0u;
@@ -239,7 +241,7 @@ __device__ __forceinline__ uint32_t pbwt_step(
 	unsigned short *const out_ord = order[cur ^ 1];
 	uint32_t *const out_dv = divergence[cur ^ 1];
 #pragma unroll
-	for (int k = 0; k < kPbwtPerThread; ++k) {
+	for (int k = 0; k < kPer; ++k) {
 		if ((uint32_t) k < per) {
 			uint32_t const fk = (flags >> k) & 1u;
 			bool const f = 0u != fk;
@@ -283,7 +285,8 @@ __device__ __forceinline__ void pbwt_bin_add(uint32_t *hash_key, uint32_t *hash_
 	else *failed_s = 1u;
 }
 
-// One workgroup per chunk.  See v2m_pbwt_cut_trials() in include/v2m_hip.h for the arguments.
+// One workgroup per chunk.  See v2m_pbwt_cut_trials() in include/v2m_hip.h for the arguments.  kPer = ceil(n_copies / kPbwtThreads).
+template <int kPer>
 __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 	uint64_t const *__restrict__ paths_by_edge,          // edge-major bits: column e = words [e * words_per_edge, +words_per_edge), bit c = copy c
 	uint32_t words_per_edge, uint32_t n_copies, uint32_t n_edges,
@@ -309,7 +312,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 	int const t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	uint32_t const chunk = blockIdx.x;
 	uint64_t const cand_begin = chunk_first[chunk], cand_end = chunk_first[chunk + 1];
-	uint32_t const per = (n_copies + kPbwtThreads - 1) / kPbwtThreads;          // <= kPbwtPerThread
+	constexpr uint32_t per = kPer;                                              // ceil(n_copies / kPbwtThreads) <= kPbwtPerThread (the host picks the instantiation)
 	uint32_t const my_begin = (uint32_t) t * per < n_copies ? (uint32_t) t * per : n_copies;
 	uint32_t const my_end = my_begin + per < n_copies ? my_begin + per : n_copies;
 	uint32_t const my_count = my_end - my_begin;
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		// ---- the edges before this candidate's node (find_cut_positions.cc:170-176 over pbwt.hh:77-134) -----------------
 		uint32_t const upto = cand_edge[cand];
 		for (; edge < upto; ++edge) {
-			pbwt_step(paths_by_edge, words_per_edge, edge, n_edges, cols, order, divergence, column, wave_items, cur, per, my_begin, my_count, t, lane, wave);
+			pbwt_step<kPer>(paths_by_edge, words_per_edge, edge, n_edges, cols, order, divergence, column, wave_items, cur, my_begin, my_count, t, lane, wave);
 			cur ^= 1;
 		}
 
@@ -341,10 +344,10 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		uint32_t const next = (uint32_t) cand;
 		uint32_t const *const dv = divergence[cur];
 		// the largest divergence value and how many copies hold it
-		uint32_t d[kPbwtPerThread];
+		uint32_t d[kPer];
 		uint32_t my_max = 0;
 #pragma unroll
-		for (int k = 0; k < kPbwtPerThread; ++k) {
+		for (int k = 0; k < kPer; ++k) {
 			if ((uint32_t) k < per) {
 				d[k] = (uint32_t) k < my_count ? dv[my_begin + k] : 0u;
 				my_max = umax(my_max, d[k]);
@@ -358,9 +361,9 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		// biased 0 ("no match yet") is the SMALLEST value: the walk reaches it last, it points to no candidate, and the only
 		// count that includes it is the final one (all copies): it takes no part in the bins
 		uint32_t my_cnt = 0;
-		uint32_t bin[kPbwtPerThread];
+		uint32_t bin[kPer];
 #pragma unroll
-		for (int k = 0; k < kPbwtPerThread; ++k) {
+		for (int k = 0; k < kPer; ++k) {
 			if ((uint32_t) k < per) {
 				bool const valid = (uint32_t) k < my_count;
 				bool const binned = valid && 0u != d[k] && d[k] != d_max;
@@ -376,7 +379,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		// thread's lookups issued together, 33.3; without any insertion the kernel takes 17.9 ms, its pBWT steps alone 11.5
 		// (profiles/r04/founder_kernels_what_bounds_them.txt).
 #pragma unroll
-		for (int k = 0; k < kPbwtPerThread; ++k) {
+		for (int k = 0; k < kPer; ++k) {
 			if ((uint32_t) k < per) {
 				if (0xFFFFFFFFu != bin[k]) pbwt_bin_add(hash_key, hash_count, bin_slot, &n_bins_s, &failed_s, bin[k], 1u);
 			}
@@ -518,6 +521,7 @@ __device__ __forceinline__ class_scan_item class_wave_scan(class_scan_item x)
 // "threshold < unbiased(d)" with d biased: 0 is the reference's DIVERGENCE_MAX ("no match yet": starts a class)
 __device__ __forceinline__ bool past_edge(uint32_t d, uint32_t threshold) { return 0u == d || d - 1u > threshold; }
 
+template <int kPer>
 __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t n_copies, uint32_t n_edge_columns /* columns of paths_by_edge (>= every edge visited + 1 is not required: fetches are clamped) */,
 	uint32_t const *__restrict__ cut_edge,                // [n_cuts]: edges before each cut node
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	uint32_t const chunk = blockIdx.x;
 	uint64_t const cut_begin = chunk_first_cut[chunk], cut_end = chunk_first_cut[chunk + 1];
 	if (cut_begin >= cut_end) { if (t == 0) chunk_status[chunk] = 0u; return; }
-	uint32_t const per = (n_copies + kPbwtThreads - 1) / kPbwtThreads;
+	constexpr uint32_t per = kPer;
 	uint32_t const my_begin = (uint32_t) t * per < n_copies ? (uint32_t) t * per : n_copies;
 	uint32_t const my_end = my_begin + per < n_copies ? my_begin + per : n_copies;
 	uint32_t const my_count = my_end - my_begin;
@@ -560,7 +564,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	// up to the cut before the chunk's first one; the classes it left behind (founder.cc:scan_cut_chunk)
 	uint64_t const start_cut = cut_begin - 1;
 	for (uint32_t const upto = cut_edge[start_cut]; edge < upto; ++edge) {
-		pbwt_step(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, cur, per, my_begin, my_count, t, lane, wave);
+		pbwt_step<kPer>(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, cur, my_begin, my_count, t, lane, wave);
 		cur ^= 1;
 	}
 
@@ -573,10 +577,10 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	auto const classes_at_cut = [&](uint32_t block_threshold, bool with_span, uint32_t span_threshold, uint32_t &distinct_out) -> bool {
 		unsigned short const *const ord = order[cur];
 		uint32_t const *const dv = divergence[cur];
-		uint32_t copy[kPbwtPerThread], d[kPbwtPerThread];
+		uint32_t copy[kPer], d[kPer];
 		class_scan_item mine{0u, 0u, 0u};
 #pragma unroll
-		for (int k = 0; k < kPbwtPerThread; ++k) {
+		for (int k = 0; k < kPer; ++k) {
 			if ((uint32_t) k < per) {                                       // (uniform)
 				bool const valid = (uint32_t) k < my_count;
 				copy[k] = ord[my_begin + k];
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 		unsigned short const *const lhs_class = copy_class[rhs];       // (the previous cut's classes: read)
 		unsigned short *const rhs_class = copy_class[rhs ^ 1];         // (this cut's: written; the arrays swap roles below)
 #pragma unroll
-		for (int k = 0; k < kPbwtPerThread; ++k) {
+		for (int k = 0; k < kPer; ++k) {
 			if ((uint32_t) k < per) {
 				bool const valid = (uint32_t) k < my_count;
 				if (valid) {
@@ -643,7 +647,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	bool first_is_ref = true;
 	for (uint64_t cut = cut_begin; cut < cut_end; ++cut) {
 		for (uint32_t const upto = cut_edge[cut]; edge < upto; ++edge) {
-			uint32_t const zeros = pbwt_step(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, cur, per, my_begin, my_count, t, lane, wave);
+			uint32_t const zeros = pbwt_step<kPer>(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, cur, my_begin, my_count, t, lane, wave);
 			cur ^= 1;
 			// the copy that is first in the order now uses the edge exactly when no copy does not (:454-462)
 			first_is_ref = first_is_ref && 0u != zeros;

@@ -19,6 +19,8 @@
 #include <utility>
 #include <vector>
 
+#include <type_traits>
+
 #include "../../include/v2m_hip.h"
 #include "kernels.hpp"
 #include "founder_kernels.hpp"
@@ -881,6 +883,28 @@ int check_batch(v2m_ctx *ctx, v2m_row_batch const *rows, u32 flags)
 
 
 // =============================================================================================
+namespace {
+
+// Calls launch(std::integral_constant<int, ceil(n_copies / kPbwtThreads)>): the founder kernels' instantiation for this many copies per thread.
+template <typename t_launch>
+void pbwt_dispatch_per_thread(u64 n_copies, t_launch &&launch)
+{
+	static_assert(8 == v2m::kPbwtPerThread, "one case per copies-per-thread count");
+	switch ((n_copies + v2m::kPbwtThreads - 1) / v2m::kPbwtThreads) {
+		case 1: launch(std::integral_constant<int, 1>{}); break;
+		case 2: launch(std::integral_constant<int, 2>{}); break;
+		case 3: launch(std::integral_constant<int, 3>{}); break;
+		case 4: launch(std::integral_constant<int, 4>{}); break;
+		case 5: launch(std::integral_constant<int, 5>{}); break;
+		case 6: launch(std::integral_constant<int, 6>{}); break;
+		case 7: launch(std::integral_constant<int, 7>{}); break;
+		default: launch(std::integral_constant<int, 8>{}); break;   // (n_copies <= kPbwtMaxCopies was checked)
+	}
+}
+
+} // namespace
+
+
 extern "C" {
 
 uint32_t v2m_abi_version(void) { return V2M_ABI_VERSION; }
@@ -1389,9 +1413,13 @@ int pbwt_cut_trials_impl(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	V2M_HIP_TRY(ctx, hipMemsetAsync(d_status.p, 0xFF, n_chunks * sizeof(u32), ctx->stream));
 	hipLaunchKernelGGL(v2m::pbwt_first_candidate_kernel, dim3(unsigned((u64(n_edges) + 1 + 255) / 256)), dim3(256), 0, ctx->stream,
 		d_cand_edge.as<u32>(), u32(n_candidates), n_edges, d_first.as<u32>());
-	hipLaunchKernelGGL(v2m::pbwt_cut_trials_kernel, dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
-		d_by_edge, u32(cols / 64), u32(n_copies), n_edges, d_first.as<u32>(), d_cand_edge.as<u32>(), d_cand_aln.as<u64>(), min_distance,
-		d_chunk_first.as<u64>(), d_order.as<u32>(), d_div.as<u32>(), trial_capacity, d_pred.as<u32>(), d_class.as<u32>(), d_end.as<u64>(), d_status.as<u32>());
+	// (the kernel is instantiated per copies-per-thread count, 1 .. 8, so that its per-copy loops unroll without branches)
+	auto const launch_trials([&](auto per_tag) {
+		hipLaunchKernelGGL((v2m::pbwt_cut_trials_kernel<decltype(per_tag)::value>), dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
+			d_by_edge, u32(cols / 64), u32(n_copies), n_edges, d_first.as<u32>(), d_cand_edge.as<u32>(), d_cand_aln.as<u64>(), min_distance,
+			d_chunk_first.as<u64>(), d_order.as<u32>(), d_div.as<u32>(), trial_capacity, d_pred.as<u32>(), d_class.as<u32>(), d_end.as<u64>(), d_status.as<u32>());
+	});
+	pbwt_dispatch_per_thread(n_copies, launch_trials);
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
 	// (only the candidates of this call's chunks: a caller may be consuming an earlier call's part of the same array meanwhile)
@@ -1528,9 +1556,12 @@ int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const
 	V2M_HIP_TRY(ctx, d_ref.ensure(n_cuts * sizeof(u32)));
 	V2M_HIP_TRY(ctx, d_status.ensure(n_chunks * sizeof(u32)));
 	V2M_HIP_TRY(ctx, hipMemsetAsync(d_status.p, 0xFF, n_chunks * sizeof(u32), ctx->stream));
-	hipLaunchKernelGGL(v2m::pbwt_cut_records_kernel, dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
-		d_by_edge, u32(cols / 64), u32(n_copies), u32(rows), d_cut_edge.as<u32>(), d_chunk_first.as<u64>(), d_start_edge.as<u32>(), d_order.as<u32>(), d_div.as<u32>(),
-		pool_capacity, d_lhs.as<u32>(), d_rhs.as<u32>(), d_size.as<u32>(), d_end.as<u64>(), d_distinct.as<u32>(), d_first.as<u32>(), d_ref.as<u32>(), d_status.as<u32>());
+	auto const launch_records([&](auto per_tag) {
+		hipLaunchKernelGGL((v2m::pbwt_cut_records_kernel<decltype(per_tag)::value>), dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
+			d_by_edge, u32(cols / 64), u32(n_copies), u32(rows), d_cut_edge.as<u32>(), d_chunk_first.as<u64>(), d_start_edge.as<u32>(), d_order.as<u32>(), d_div.as<u32>(),
+			pool_capacity, d_lhs.as<u32>(), d_rhs.as<u32>(), d_size.as<u32>(), d_end.as<u64>(), d_distinct.as<u32>(), d_first.as<u32>(), d_ref.as<u32>(), d_status.as<u32>());
+	});
+	pbwt_dispatch_per_thread(n_copies, launch_records);
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
 	u64 const cut_lo(chunk_first_cut[0]), cut_hi(chunk_first_cut[n_chunks]);   // only the cuts of this call's chunks
