@@ -124,3 +124,24 @@ def test_bench_two_ranks_under_torch_distributed_run():
 	d = json.loads(lines[0])
 	_check_two_rank_line(d)
 	assert "torch.distributed (gloo)" in d["config"]["ranks_coordinated_by"]
+
+
+def test_bench_four_ranks_as_typed_uneven_shards():
+	"""Four ranks on one GPU (mini3: 200 copies -> blocks of 8 dealt 48 / 48 / 48 / 56, REF on rank 0): every rank binds only its own slice,
+	passes the same barriers (timed region, three end-to-end passes) and contributes its figures; the line adds up."""
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--force-device", "0", "--config", "mini3",
+		"--steps", "2", "--warmup", "1", "--output-candidates", "1", "--batch-rows", "20", "--cpu-baseline-rows", "8", "--e2e-threads", "4"],
+		stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT, env=env)
+	assert r.returncode == 0, r.stderr.decode()[-3000:]
+	lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+	assert len(lines) == 1
+	d = json.loads(lines[0])
+	per_rank = d["config"]["per_rank"]
+	assert d["n_gpus"] == 4 and [p["rank"] for p in per_rank] == [0, 1, 2, 3]
+	assert [p["rows"] for p in per_rank] == [49, 48, 48, 56] and sum(p["rows"] for p in per_rank) == d["config"]["rows_total"] == 201
+	assert d["parity"]["bit_exact"] is True and d["parity"]["batches_covered"] == sum(p["batches"] for p in per_rank)
+	assert abs(d["ms_per_step"] - max(p["ms_per_step"] for p in per_rank)) <= 1e-3
+	e = d["end_to_end"]
+	assert e["rows"] == 201 and len(e["per_rank_GBs"]) == 4 and e["parity"]["bit_exact"] is True and e["parity"]["rows_checked"] == 201
+	assert d["cpu_baseline"]["value"] > 0 and d["roofline_transpose"]["cpu_baseline"]["bit_exact_vs_gpu_dense_form"] is True
