@@ -774,7 +774,7 @@ def main():
 		same = bool(np.array_equal(cpu_dst, gpu_dense))
 		gpu_ms = result["roofline_transpose"]["avg_launch_ms"]
 		result["roofline_transpose"]["cpu_baseline"] = {
-			"seconds": round(secs_c, 3), "value": round(tr_bytes / secs_c / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+			"seconds": round(secs_c, 6), "value": round(tr_bytes / secs_c / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
 			"sample": "the whole %d x %d-bit matrix of rank 0 in this run (%.3f GB read + written), one call of the oracle's v2mo_transpose_matrix (the 8x8-block traversal of transpose_matrix.cc:41-109), including its zero-fill of the destination; host has %d logical CPUs"
 				% (hp_local, Ep, tr_bytes / 1e9, os.cpu_count()),
 			"bit_exact_vs_gpu_dense_form": same, "gpu_over_cpu": round(secs_c * 1e3 / gpu_ms, 1) if gpu_ms > 0 else None,
