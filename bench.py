@@ -268,7 +268,7 @@ def main():
 	ap.add_argument("--cpu-transpose", type=int, default=1, help="after timing (rank 0, every N): time the CPU oracle's transpose_matrix on rank 0's matrix and compare it bit for bit with the GPU's dense-form result (config 3: ~5 s); 0 disables")
 	ap.add_argument("--transpose-extras", type=int, default=1, help="after timing, also measure the inverse transpose and a 1024-bit-padded matrix (rank 0); 0 disables")
 	ap.add_argument("--e2e-gb", type=float, default=64.0, help="the end-to-end leg (every rank, after the main timing): this many GB of the rank's rows through v2m_splice_rows -- device slots, D2H copies on the copy stream, pinned slots -- into a C sink that checksums every row on the host; 0 disables")
-	ap.add_argument("--e2e-threads", type=int, default=16, help="host threads of the end-to-end leg's checksumming sink (a GPU box gives 16 cores per GPU)")
+	ap.add_argument("--e2e-threads", type=int, default=4, help="host threads of the end-to-end leg's checksumming sink.  A GPU box gives a job 16 cores' worth of CPU time (a cgroup quota: what goes beyond it gets the whole process throttled -- with 16 threads of the scalar loop the leg ran at 39 instead of 55 GB/s in one run out of three), so the sink must leave room for the process's other threads: with the AVX-512 loop (41 GB/s per thread on the boxes' Zen 5 cores, profiles/r04/cpu_quota_and_sink_rates.txt) four threads are twice what the link delivers; the scalar loop (7 GB/s per thread) needs --e2e-threads 12")
 	ap.add_argument("--hub-selftest", action="store_true", help="no GPU work: the ranks only exercise the barrier / gather plumbing of their launch form and rank 0 prints what it gathered (CPU test suite)")
 	args = ap.parse_args()
 
@@ -477,10 +477,14 @@ def main():
 		for name in ("checksums", "lengths"):
 			getattr(sl, "v2ms_checksum_sink_" + name).restype = C.POINTER(C.c_uint64)
 			getattr(sl, "v2ms_checksum_sink_" + name).argtypes = [C.c_void_p]
+		sl.v2ms_checksum_sink_flavour.restype = C.c_char_p
+		sl.v2ms_checksum_sink_flavour.argtypes = [C.c_void_p]
 		sink_fn = C.cast(sl.v2ms_checksum_sink_fn, N.SINK_FN)
+		sink_flavour = [None]
 
 		def through_the_sink(batch):
 			state = sl.v2ms_checksum_sink_create(max(1, batch.n_rows), max(1, args.e2e_threads))
+			sink_flavour[0] = sl.v2ms_checksum_sink_flavour(state).decode()
 			try:
 				t_s = time.perf_counter()
 				rc = ctx._lib.v2m_splice_rows(ctx._h, C.byref(batch.struct), 0, sink_fn, state)
@@ -520,7 +524,7 @@ def main():
 			e_secs = sorted(passes)[len(passes) // 2]
 			log("[bench] rank %d end to end: %d rows = %.1f GB through the sink in %s s (median %.1f GB/s); every row against the oracle (%.1f s on %d threads): %s"
 				% (rank, e_n, e_bytes / 1e9, " / ".join("%.3f" % p for p in passes), e_bytes / e_secs / 1e9, time.time() - t_o, host_threads, "bit-exact" if e_ok else "MISMATCH"))
-			mine["e2e"] = {"rows": e_n, "bytes": e_bytes, "seconds": e_secs, "passes_s": [round(p, 4) for p in passes], "bit_exact": e_ok}
+			mine["e2e"] = {"rows": e_n, "bytes": e_bytes, "seconds": e_secs, "passes_s": [round(p, 4) for p in passes], "bit_exact": e_ok, "sink": "%d threads, %s loop" % (args.e2e_threads, sink_flavour[0])}
 
 	everyone = hub.gather(mine)
 
@@ -609,7 +613,7 @@ def main():
 		result["end_to_end"] = {
 			"metric": "aligned A2M Gbases/sec delivered to a host sink (PCIe-inclusive)", "value": round(e_bytes / e_secs / 1e9, 3), "unit": "Gbases/s", "GBs": round(e_bytes / e_secs / 1e9, 3),
 			"rows": sum(l["rows"] for l in legs), "bytes": e_bytes, "seconds": round(e_secs, 4),
-			"path": "v2m_splice_rows: slices of the batch spliced into two device slots, D2H on the copy stream under the next slice's kernels, rows handed to a C sink from the library's pinned slots (what output::output_a2m does, output.cc:47-76); the sink reads every byte (checksum on %d host threads) and keeps nothing; all ranks at once, one link each" % args.e2e_threads,
+			"path": "v2m_splice_rows: slices of the batch spliced into two device slots, D2H on the copy stream under the next slice's kernels, rows handed to a C sink from the library's pinned slots (what output::output_a2m does, output.cc:47-76); the sink reads every byte (checksum on %s) and keeps nothing; all ranks at once, one link each" % legs[0]["sink"],
 			"roofline": {"bound": "pcie", "achieved": round(slow["bytes"] / slow["seconds"] / 1e9, 2), "peak": PCIE_PEAK_GBS, "unit": "GB/s", "frac": round(slow["bytes"] / slow["seconds"] / 1e9 / PCIE_PEAK_GBS, 4),
 				"note": "per GPU (the slowest rank's link): PCIe Gen5 x16, 63 GB/s spec per direction; a row byte crosses the link exactly once"},
 			"per_rank_GBs": [round(l["bytes"] / l["seconds"] / 1e9, 2) for l in legs],

@@ -312,11 +312,18 @@ def test_checksum_sink_of_the_end_to_end_leg(v2m):
 	sl.v2ms_checksum_sink_rows.restype = C.c_uint64
 	sl.v2ms_checksum_sink_rows.argtypes = [C.c_void_p]
 	sl.v2ms_checksum_sink_destroy.argtypes = [C.c_void_p]
+	sl.v2ms_checksum_sink_flavour.restype = C.c_char_p
+	sl.v2ms_checksum_sink_flavour.argtypes = [C.c_void_p]
+	sl.v2ms_checksum_sink_force_scalar.argtypes = [C.c_void_p]
 	rng = np.random.default_rng(7)
-	rows = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (0, 1, 7, 8, 9, 63, 64, 1000, 100003, 3_000_001)]
+	rows = [rng.integers(0, 256, n, dtype=np.uint8).tobytes() for n in (0, 1, 7, 8, 9, 63, 64, 65, 71, 1000, 100003, 3_000_001)]
 	want = v2m.checksum_rows_host(rows).tolist()
-	for threads in (1, 2, 5, 16):
+	for threads, scalar in ((1, False), (2, False), (5, True), (16, False), (3, True)):      # the CPU's widest loop (AVX-512DQ where there is one) and the scalar one
 		s = sl.v2ms_checksum_sink_create(len(rows), threads)
+		assert sl.v2ms_checksum_sink_flavour(s) in (b"scalar", b"avx512dq")
+		if scalar:
+			sl.v2ms_checksum_sink_force_scalar(s)
+			assert sl.v2ms_checksum_sink_flavour(s) == b"scalar"
 		for rep in range(3):            # the pool is reused row after row
 			for i, body in enumerate(rows):
 				assert sl.v2ms_checksum_sink_fn(s, i, body, len(body)) == 0

@@ -50,7 +50,7 @@ TUNING_LIB_PATH = os.path.join(PKG_DIR, "libv2m_hip_tuning.so")
 
 # synthetic-input generator (bench + scale tests): host generator + the HIP kernel filling genotype bits
 SYNTH_LIB_PATH = os.path.join(PKG_DIR, "libv2m_synth.so")
-SYNTH_SOURCES = [os.path.join(CSRC, "synth", "synth_capi.hip"), os.path.join(CSRC, "synth", "synth.cc"), os.path.join(CSRC, "host", "graph_builder.cc")]
+SYNTH_SOURCES = [os.path.join(CSRC, "synth", "synth_capi.hip"), os.path.join(CSRC, "synth", "synth.cc"), os.path.join(CSRC, "synth", "sink.cc"), os.path.join(CSRC, "host", "graph_builder.cc")]
 SYNTH_DEPS = include_closure(SYNTH_SOURCES)
 
 
