@@ -267,7 +267,7 @@ def main():
 	ap.add_argument("--unaligned-rows", type=int, default=256, help="the separately timed --unaligned leg (rank 0, after the main timing) runs on as many rows as the output buffer holds and, beside it, on the first this-many rows; 0 disables")
 	ap.add_argument("--cpu-transpose", type=int, default=1, help="after timing (rank 0, every N): time the CPU oracle's transpose_matrix on rank 0's matrix and compare it bit for bit with the GPU's dense-form result (config 3: ~5 s); 0 disables")
 	ap.add_argument("--transpose-extras", type=int, default=1, help="after timing, also measure the inverse transpose and a 1024-bit-padded matrix (rank 0); 0 disables")
-	ap.add_argument("--e2e-gb", type=float, default=64.0, help="the end-to-end leg (every rank, after the main timing): this many GB of the rank's rows through v2m_splice_rows -- device slots, D2H copies on the copy stream, pinned slots -- into a C sink that checksums every row on the host; 0 disables")
+	ap.add_argument("--e2e-gb", type=float, default=64.0, help="the end-to-end leg (every rank, last: after the main timing and rank 0's other legs, by which time the driver has finished wiping the output-buffer candidates that v2m_alloc_output freed): this many GB of the rank's rows through v2m_splice_rows -- device slots, D2H copies on the copy stream, pinned slots -- into a C sink that checksums every row on the host; 0 disables")
 	ap.add_argument("--e2e-threads", type=int, default=4, help="host threads of the end-to-end leg's checksumming sink.  A GPU box gives a job 16 cores' worth of CPU time (a cgroup quota: what goes beyond it gets the whole process throttled -- with 16 threads of the scalar loop the leg ran at 39 instead of 55 GB/s in one run out of three), so the sink must leave room for the process's other threads: with the AVX-512 loop (41 GB/s per thread on the boxes' Zen 5 cores, profiles/r04/cpu_quota_and_sink_rates.txt) four threads are twice what the link delivers; the scalar loop (7 GB/s per thread) needs --e2e-threads 12")
 	ap.add_argument("--hub-selftest", action="store_true", help="no GPU work: the ranks only exercise the barrier / gather plumbing of their launch form and rank 0 prints what it gathered (CPU test suite)")
 	args = ap.parse_args()
@@ -458,6 +458,190 @@ def main():
 		log("[bench] rank %d parity: %d rows of %d batches against the oracle in %.1f s: %s" % (rank, len(picks), len(batches), time.time() - t_o, "bit-exact" if ok else "MISMATCH"))
 		del og
 
+	# ================= rank 0, before the end-to-end leg: the legs that only it runs =========================================
+	# (They come first on purpose: v2m_alloc_output has just written four 63-GB candidates and freed three, the driver wipes freed VRAM that was
+	# written in the background for about nine seconds, and while it does every D2H copy of the process runs at 40 instead of 56 GB/s
+	# (profiles/r04/e2e_slow_after_alloc_output.txt).  That wipe is an artefact of choosing the output buffer by measurement, not something a
+	# caller of output_a2m pays -- the command-line driver never calls v2m_alloc_output -- so the end-to-end leg must not be timed inside it.
+	# The other ranks wait at the leg's first barrier meanwhile.)
+	extras = {}
+	if rank == 0:
+		# ---- the transpose, at the reference's padding: algorithmic 2 * Hp * Ep / 8 bytes per call -----------------------
+		tr_bytes = 2 * hp_local * Ep // 8
+		if transpose_launches:
+			t_ms = transpose_ms / transpose_launches
+			extras["roofline_transpose"] = {
+				"bound": "hbm", "kernel": "transpose_bits (v2m_bind_path_matrix_device: source in the reference's layout and padding, destination the library's own line-aligned copy; the kernel is chosen per matrix shape by measurement, see config.tuning)",
+				"rank": 0, "matrix_bits": [hp_local, Ep], "algorithmic_bytes": tr_bytes, "launches": transpose_launches,
+				"avg_launch_ms": round(t_ms, 4), "achieved": round(tr_bytes / t_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+				"frac": round(tr_bytes / t_ms / 1e6 / HBM_PEAK_GBS, 4),
+			}
+
+		def time_transpose(src_ptr, n_r, n_c, dst_ptr, reps=5):
+			ctx.transpose_bits_device(src_ptr, n_r, n_c, dst_ptr)   # first call of a shape: the library times its candidates
+			ctx.synchronize()
+			ctx.profile_enable(True)
+			ctx.profile_reset()
+			for _ in range(reps):
+				ctx.transpose_bits_device(src_ptr, n_r, n_c, dst_ptr)
+			n, ms = ctx.profile_get(N.KERNEL_TRANSPOSE)
+			ctx.profile_enable(False)
+			return ms / max(1, n)
+
+		if args.transpose_extras and hp_local:
+			# the ABI's dense form (v2m_transpose_bits_device: caller-visible destination, so both sides at the reference's padding)
+			fwd_ms = time_transpose(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())
+			back = torch.empty_like(paths_src)
+			inv_ms = time_transpose(paths_dst.data_ptr(), Ep, hp_local, back.data_ptr())
+			involution = bool(torch.equal(back, paths_src))
+			del back
+			pad1024 = lambda n: (n + 1023) // 1024 * 1024
+			hp_p, ep_p = pad1024(hp_local), pad1024(Ep)
+			p_src, p_dst = make_paths(hp_p, ep_p, c0, c1)
+			fwd_p = time_transpose(p_src.data_ptr(), hp_p, ep_p, p_dst.data_ptr())
+			inv_p = time_transpose(p_dst.data_ptr(), ep_p, hp_p, p_src.data_ptr())
+			del p_src, p_dst
+			gbs = lambda nbytes, ms: round(nbytes / ms / 1e6, 1)
+			extras.setdefault("roofline_transpose", {})["after_timing"] = {
+				"dense_forward_ms": round(fwd_ms, 4), "dense_forward_GBs": gbs(tr_bytes, fwd_ms), "dense_forward_frac": round(tr_bytes / fwd_ms / 1e6 / HBM_PEAK_GBS, 4),
+				"inverse_ms": round(inv_ms, 4), "inverse_GBs": gbs(tr_bytes, inv_ms), "inverse_frac": round(tr_bytes / inv_ms / 1e6 / HBM_PEAK_GBS, 4), "involution_bit_exact": involution,
+				"note": "dense_forward / inverse: v2m_transpose_bits_device with a caller-visible destination (both sides at the reference's 64-bit padding); padded_1024: the same with both dimensions padded to 1024 bits",
+				"padded_1024": {"matrix_bits": [hp_p, ep_p], "forward_ms": round(fwd_p, 4), "forward_GBs": gbs(2 * hp_p * ep_p // 8, fwd_p), "inverse_ms": round(inv_p, 4), "inverse_GBs": gbs(2 * hp_p * ep_p // 8, inv_p)},
+				"kernels": "; ".join(note for note in ctx.info.split("; ") if note.startswith("transpose ")),   # which kernel the library measured fastest for each of these shapes
+			}
+			if not involution:
+				log("[bench] PARITY FAILURE: transpose(transpose(m)) != m")
+				extras["parity_failed"] = True
+			ctx.bind_path_matrix_device(paths_src.data_ptr(), hp_local, Ep)
+
+		# Context for the roofline number: what a plain device memset of the very same output buffer reaches in this
+		# process (the achievable write rate varies by +-10 % between processes / boxes).
+		ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+		fills = []
+		for _ in range(3):
+			ev0.record()
+			_hip_memset(torch, out_ptr, out_bytes)
+			ev1.record()
+			torch.cuda.synchronize()
+			fills.append(ev0.elapsed_time(ev1))
+		extras["memset_same_buffer_GBs"] = round(out_bytes / (min(fills) * 1e-3) / 1e9, 1)
+		extras["memset_same_buffer_rank"] = 0
+
+		# ---- second leg, timed on its own: --unaligned (sequence_writer.cc:80: no '-' padding) -----------------------------
+		# Measured on the SAME address footprint as the aligned leg (as many rows as the ~63-GB output buffer holds at the unaligned
+		# pitch: the store pattern only reaches its full rate when a launch spans several tens of GB), and, for
+		# continuity with rounds 1-2, on the first --unaligned-rows (256) rows as well.
+		if args.unaligned_rows and n_rows > 1:
+			import oracle
+			upitch = (ctx.max_unaligned_length + 255) // 256 * 256
+			n_tiles = -(-L // 16384)
+			aligned_ms_per_base = (splice_ms / max(1, launches)) / max(1, batch_rows * L)
+
+			def unaligned_leg(n_u, reps=3):
+				ub = v2m.RowBatch(rows[:n_u])
+				# like for like: the ALIGNED kernel on the very same rows, buffer and pitch (what a launch reaches depends on the address range it
+				# covers and on the buffer's backing -- DESIGN.md section 4, profiles/r04/unaligned_footprint_4_buffers.txt -- so the full-footprint
+				# aligned launches of the timed region are the wrong yardstick for a 256-row launch)
+				a_same = None
+				if upitch >= (L + 15) // 16 * 16:
+					ctx.splice_rows_device(ub, out_ptr, upitch)
+					ctx.synchronize()
+					ctx.profile_enable(True)
+					ctx.profile_reset()
+					for _ in range(reps):
+						ctx.splice_rows_device(ub, out_ptr, upitch)
+					n_a, ms_a = ctx.profile_get(N.KERNEL_SPLICE_ALIGNED)
+					ctx.profile_enable(False)
+					a_same = ms_a / max(1, n_a)
+				ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True)      # warm-up (builds the second template; first >= 1-GiB launch: calibrates the store flavour)
+				ctx.synchronize()
+				ctx.profile_enable(True)
+				ctx.profile_reset()
+				t_u = time.perf_counter()
+				for _ in range(reps):
+					lengths = ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True, want_lengths=True)
+				ctx.synchronize()
+				wall_u = (time.perf_counter() - t_u) / reps
+				_, u_count = ctx.profile_get(N.KERNEL_UNALIGNED_COUNT)
+				_, u_splice = ctx.profile_get(N.KERNEL_SPLICE_UNALIGNED)
+				_, u_resolve = ctx.profile_get(N.KERNEL_RESOLVE)
+				ctx.profile_enable(False)
+				u_count, u_splice, u_resolve = u_count / reps, u_splice / reps, u_resolve / reps
+				bases_u = int(lengths.sum())
+				# pass 2 (splice_unaligned_kernel): row bytes out + the rows' bit columns + the shared inputs + one tile offset per (row, tile);
+				# pass 1 (count + scan): the shared inputs + bit columns in, the tile counts out and in and out again (scan in place)
+				alg_u = bases_u + n_u * Ep // 8 + shared_bytes + 4 * n_u * n_tiles
+				alg_c = n_u * Ep // 8 + shared_bytes + 3 * 4 * n_u * n_tiles
+				usample = sorted({0, 1, n_u // 2, n_u - 1})
+				ucopies = [c0 + rows[i] for i in usample if rows[i] != v2m.PLOIDY_MAX]
+				uog = oracle_graph(ucopies)
+				ucol = {c: i for i, c in enumerate(ucopies)}
+				uwant, ulen = uog.row_checksums(ds.reference, [oracle.PLOIDY_MAX if rows[i] == v2m.PLOIDY_MAX else ucol[c0 + rows[i]] for i in usample], unaligned=True, threads=len(usample))
+				ugot = np.array([ctx.checksum_rows_device(out_ptr + i * upitch, upitch, 1, length=int(lengths[i]))[0] for i in usample], dtype=np.uint64)
+				u_ok = bool(np.array_equal(ulen, lengths[usample])) and bool(np.array_equal(ugot, uwant))
+				ms_per_base = u_splice / max(1, bases_u)
+				return {
+					"rows": n_u, "bases": bases_u, "footprint_GB": round(n_u * upitch / 1e9, 2),
+					"value": round(bases_u / (u_resolve + u_count + u_splice) / 1e6, 1), "unit": "Gbases/s", "wall_ms_per_batch": round(1e3 * wall_u, 3),
+					"kernels_ms": {"resolve_effective_edges_kernel": round(u_resolve, 3), "count_unaligned_kernel+scan_tile_counts_kernel": round(u_count, 3), "splice_unaligned_kernel": round(u_splice, 3)},
+					"roofline": {"bound": "hbm", "kernel": "splice_unaligned_kernel", "algorithmic_bytes_per_launch": int(alg_u), "achieved": round(alg_u / u_splice / 1e6, 1), "peak": HBM_PEAK_GBS,
+						"unit": "GB/s", "frac": round(alg_u / u_splice / 1e6 / HBM_PEAK_GBS, 4)},
+					"time_per_base_vs_aligned_kernel": round(ms_per_base / aligned_ms_per_base, 3) if aligned_ms_per_base > 0 else None,
+					"aligned_kernel_same_rows_ms": round(a_same, 3) if a_same else None,
+					"time_per_base_vs_aligned_kernel_same_rows": round(ms_per_base / (a_same / (n_u * L)), 3) if a_same else None,
+					"yardsticks": "time_per_base_vs_aligned_kernel: against the timed region's aligned launches (the output buffer's whole footprint); ..._same_rows: against the aligned kernel on these very rows, this buffer and this pitch",
+					"roofline_count_pass": {"bound": "hbm", "kernel": "count_unaligned_kernel+scan_tile_counts_kernel", "algorithmic_bytes_per_launch": int(alg_c), "achieved": round(alg_c / u_count / 1e6, 1),
+						"unit": "GB/s", "note": "reads the shared inputs and the rows' effective-edge bits, writes 4 bytes per (row, 16-KiB tile); builds no row"},
+					"parity": {"rows_checked": len(usample), "bit_exact": u_ok, "method": "row lengths and device checksums against the CPU oracle's unaligned rows"},
+				}
+
+			n_full = max(1, min(out_bytes // upitch, n_rows))
+			n_small = max(1, min(args.unaligned_rows, n_full))
+			small = unaligned_leg(n_small)
+			full = unaligned_leg(n_full) if n_full != n_small else small
+			extras["unaligned"] = dict(full, metric="unaligned (--unaligned) Gbases/sec, one batch on the aligned leg's output buffer (same ~%.0f-GB address footprint), kernels only, rank 0" % (out_bytes / 1e9),
+				first_rows_only=small, tuning=ctx.info)
+			for leg in (small, full):
+				if not leg["parity"]["bit_exact"]:
+					log("[bench] PARITY FAILURE (unaligned leg, %d rows) against the CPU oracle" % leg["rows"])
+					extras["parity_failed"] = True
+
+		# ---- the CPU path beside the GPU transpose ("time the whole matrix on CPU, one call per run") ---------
+		if args.cpu_transpose and hp_local and "roofline_transpose" in extras:
+			import oracle
+			host_src = np.frombuffer(_device_bytes(paths_src.data_ptr(), tr_bytes // 2), dtype=np.uint64)      # copied to the host once, after all GPU timing
+			ctx.transpose_bits_device(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())                # the ABI's dense form: caller-visible destination
+			ctx.synchronize()
+			gpu_dense = np.frombuffer(_device_bytes(paths_dst.data_ptr(), tr_bytes // 2), dtype=np.uint64)
+			t_c = time.perf_counter()
+			cpu_dst = oracle.transpose_matrix(host_src, hp_local, Ep)          # transpose_matrix.cc:41-109's traversal, one thread, -O2
+			secs_c = time.perf_counter() - t_c
+			same = bool(np.array_equal(cpu_dst, gpu_dense))
+			gpu_ms = extras["roofline_transpose"]["avg_launch_ms"]
+			extras["roofline_transpose"]["cpu_baseline"] = {
+				"seconds": round(secs_c, 6), "value": round(tr_bytes / secs_c / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+				"sample": "the whole %d x %d-bit matrix of rank 0 in this run (%.3f GB read + written), one call of the oracle's v2mo_transpose_matrix (the 8x8-block traversal of transpose_matrix.cc:41-109), including its zero-fill of the destination; host has %d logical CPUs"
+					% (hp_local, Ep, tr_bytes / 1e9, os.cpu_count()),
+				"bit_exact_vs_gpu_dense_form": same, "gpu_over_cpu": round(secs_c * 1e3 / gpu_ms, 1) if gpu_ms > 0 else None,
+			}
+			if not same:
+				log("[bench] PARITY FAILURE: the GPU's dense-form transpose differs from the CPU oracle's")
+				extras["parity_failed"] = True
+			del host_src, gpu_dense, cpu_dst
+
+		# ---- the CPU path beside the GPU splice: same run, same host, at every N (the other ranks have finished or wait) -------
+		if args.cpu_baseline_rows:
+			nb = min(args.cpu_baseline_rows, H)
+			og = oracle_graph(list(range(nb)))
+			nbytes, secs = og.haplotype_output_a2m(ds.reference, None, first_copy=0, n_copies=nb)
+			bases = (nb + 1) * L
+			extras["cpu_baseline"] = {
+				"value": round(bases / secs / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
+				"sample": "REF + first %d haplotypes of %s (%.2f Gbases) through the oracle's output_sequence/haplotype_output_a2m (sequence_writer.cc:22-85 driven by haplotype_output.cc:38-82) into a discarding std::ostream, %.1f s, on rank 0's host cores after the timed region; rows are independent, so the rate carries to the full %d rows; host has %d logical CPUs"
+					% (nb, args.config, bases / 1e9, secs, total_rows, os.cpu_count()),
+			}
+
+
 	# ---- end to end: what a caller of output::output_a2m gets (output.cc:47-76) -- every row crosses the link ------------
 	# v2m_splice_rows (the sink form the command-line driver uses): the batch is spliced slice by slice into two device slots,
 	# each slice's D2H copy runs on the copy stream under the next slice's kernels, and every finished row is handed to the sink
@@ -605,6 +789,9 @@ def main():
 		if not ok:
 			log("[bench] PARITY FAILURE against the CPU oracle")
 
+	result["roofline"].update({k: extras.pop(k) for k in ("memset_same_buffer_GBs", "memset_same_buffer_rank") if k in extras})
+	if extras.pop("parity_failed", False):
+		result.setdefault("parity", {})["bit_exact"] = False
 	legs = [f["e2e"] for f in everyone if f.get("e2e")]
 	if legs:
 		e_bytes, e_secs = sum(l["bytes"] for l in legs), max(l["seconds"] for l in legs)
@@ -624,181 +811,7 @@ def main():
 			log("[bench] PARITY FAILURE (end-to-end leg) against the CPU oracle")
 			result.setdefault("parity", {})["bit_exact"] = False
 
-	# ---- the transpose, at the reference's padding: algorithmic 2 * Hp * Ep / 8 bytes per call -----------------------
-	tr_bytes = 2 * hp_local * Ep // 8
-	if transpose_launches:
-		t_ms = transpose_ms / transpose_launches
-		result["roofline_transpose"] = {
-			"bound": "hbm", "kernel": "transpose_bits (v2m_bind_path_matrix_device: source in the reference's layout and padding, destination the library's own line-aligned copy; the kernel is chosen per matrix shape by measurement, see config.tuning)",
-			"rank": 0, "matrix_bits": [hp_local, Ep], "algorithmic_bytes": tr_bytes, "launches": transpose_launches,
-			"avg_launch_ms": round(t_ms, 4), "achieved": round(tr_bytes / t_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-			"frac": round(tr_bytes / t_ms / 1e6 / HBM_PEAK_GBS, 4),
-		}
-
-	def time_transpose(src_ptr, n_r, n_c, dst_ptr, reps=5):
-		ctx.transpose_bits_device(src_ptr, n_r, n_c, dst_ptr)   # first call of a shape: the library times its candidates
-		ctx.synchronize()
-		ctx.profile_enable(True)
-		ctx.profile_reset()
-		for _ in range(reps):
-			ctx.transpose_bits_device(src_ptr, n_r, n_c, dst_ptr)
-		n, ms = ctx.profile_get(N.KERNEL_TRANSPOSE)
-		ctx.profile_enable(False)
-		return ms / max(1, n)
-
-	if args.transpose_extras and hp_local:
-		# the ABI's dense form (v2m_transpose_bits_device: caller-visible destination, so both sides at the reference's padding)
-		fwd_ms = time_transpose(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())
-		back = torch.empty_like(paths_src)
-		inv_ms = time_transpose(paths_dst.data_ptr(), Ep, hp_local, back.data_ptr())
-		involution = bool(torch.equal(back, paths_src))
-		del back
-		pad1024 = lambda n: (n + 1023) // 1024 * 1024
-		hp_p, ep_p = pad1024(hp_local), pad1024(Ep)
-		p_src, p_dst = make_paths(hp_p, ep_p, c0, c1)
-		fwd_p = time_transpose(p_src.data_ptr(), hp_p, ep_p, p_dst.data_ptr())
-		inv_p = time_transpose(p_dst.data_ptr(), ep_p, hp_p, p_src.data_ptr())
-		del p_src, p_dst
-		gbs = lambda nbytes, ms: round(nbytes / ms / 1e6, 1)
-		result.setdefault("roofline_transpose", {})["after_timing"] = {
-			"dense_forward_ms": round(fwd_ms, 4), "dense_forward_GBs": gbs(tr_bytes, fwd_ms), "dense_forward_frac": round(tr_bytes / fwd_ms / 1e6 / HBM_PEAK_GBS, 4),
-			"inverse_ms": round(inv_ms, 4), "inverse_GBs": gbs(tr_bytes, inv_ms), "inverse_frac": round(tr_bytes / inv_ms / 1e6 / HBM_PEAK_GBS, 4), "involution_bit_exact": involution,
-			"note": "dense_forward / inverse: v2m_transpose_bits_device with a caller-visible destination (both sides at the reference's 64-bit padding); padded_1024: the same with both dimensions padded to 1024 bits",
-			"padded_1024": {"matrix_bits": [hp_p, ep_p], "forward_ms": round(fwd_p, 4), "forward_GBs": gbs(2 * hp_p * ep_p // 8, fwd_p), "inverse_ms": round(inv_p, 4), "inverse_GBs": gbs(2 * hp_p * ep_p // 8, inv_p)},
-			"kernels": "; ".join(note for note in ctx.info.split("; ") if note.startswith("transpose ")),   # which kernel the library measured fastest for each of these shapes
-		}
-		if not involution:
-			log("[bench] PARITY FAILURE: transpose(transpose(m)) != m")
-			result.setdefault("parity", {})["bit_exact"] = False
-		ctx.bind_path_matrix_device(paths_src.data_ptr(), hp_local, Ep)
-
-	# Context for the roofline number: what a plain device memset of the very same output buffer reaches in this
-	# process (the achievable write rate varies by +-10 % between processes / boxes).
-	ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-	fills = []
-	for _ in range(3):
-		ev0.record()
-		_hip_memset(torch, out_ptr, out_bytes)
-		ev1.record()
-		torch.cuda.synchronize()
-		fills.append(ev0.elapsed_time(ev1))
-	result["roofline"]["memset_same_buffer_GBs"] = round(out_bytes / (min(fills) * 1e-3) / 1e9, 1)
-	result["roofline"]["memset_same_buffer_rank"] = 0
-
-	# ---- second leg, timed on its own: --unaligned (sequence_writer.cc:80: no '-' padding) -----------------------------
-	# Measured on the SAME address footprint as the aligned leg (as many rows as the ~63-GB output buffer holds at the unaligned
-	# pitch: the store pattern only reaches its full rate when a launch spans several tens of GB), and, for
-	# continuity with rounds 1-2, on the first --unaligned-rows (256) rows as well.
-	if args.unaligned_rows and n_rows > 1:
-		import oracle
-		upitch = (ctx.max_unaligned_length + 255) // 256 * 256
-		n_tiles = -(-L // 16384)
-		f0 = everyone[0]
-		aligned_ms_per_base = avg_ms(f0) / max(1, batch_rows * L)
-
-		def unaligned_leg(n_u, reps=3):
-			ub = v2m.RowBatch(rows[:n_u])
-			# like for like: the ALIGNED kernel on the very same rows, buffer and pitch (what a launch reaches depends on the address range it
-			# covers and on the buffer's backing -- DESIGN.md section 4, profiles/r04/unaligned_footprint_4_buffers.txt -- so the full-footprint
-			# aligned launches of the timed region are the wrong yardstick for a 256-row launch)
-			a_same = None
-			if upitch >= (L + 15) // 16 * 16:
-				ctx.splice_rows_device(ub, out_ptr, upitch)
-				ctx.synchronize()
-				ctx.profile_enable(True)
-				ctx.profile_reset()
-				for _ in range(reps):
-					ctx.splice_rows_device(ub, out_ptr, upitch)
-				n_a, ms_a = ctx.profile_get(N.KERNEL_SPLICE_ALIGNED)
-				ctx.profile_enable(False)
-				a_same = ms_a / max(1, n_a)
-			ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True)      # warm-up (builds the second template; first >= 1-GiB launch: calibrates the store flavour)
-			ctx.synchronize()
-			ctx.profile_enable(True)
-			ctx.profile_reset()
-			t_u = time.perf_counter()
-			for _ in range(reps):
-				lengths = ctx.splice_rows_device(ub, out_ptr, upitch, unaligned=True, want_lengths=True)
-			ctx.synchronize()
-			wall_u = (time.perf_counter() - t_u) / reps
-			_, u_count = ctx.profile_get(N.KERNEL_UNALIGNED_COUNT)
-			_, u_splice = ctx.profile_get(N.KERNEL_SPLICE_UNALIGNED)
-			_, u_resolve = ctx.profile_get(N.KERNEL_RESOLVE)
-			ctx.profile_enable(False)
-			u_count, u_splice, u_resolve = u_count / reps, u_splice / reps, u_resolve / reps
-			bases_u = int(lengths.sum())
-			# pass 2 (splice_unaligned_kernel): row bytes out + the rows' bit columns + the shared inputs + one tile offset per (row, tile);
-			# pass 1 (count + scan): the shared inputs + bit columns in, the tile counts out and in and out again (scan in place)
-			alg_u = bases_u + n_u * Ep // 8 + shared_bytes + 4 * n_u * n_tiles
-			alg_c = n_u * Ep // 8 + shared_bytes + 3 * 4 * n_u * n_tiles
-			usample = sorted({0, 1, n_u // 2, n_u - 1})
-			ucopies = [c0 + rows[i] for i in usample if rows[i] != v2m.PLOIDY_MAX]
-			uog = oracle_graph(ucopies)
-			ucol = {c: i for i, c in enumerate(ucopies)}
-			uwant, ulen = uog.row_checksums(ds.reference, [oracle.PLOIDY_MAX if rows[i] == v2m.PLOIDY_MAX else ucol[c0 + rows[i]] for i in usample], unaligned=True, threads=len(usample))
-			ugot = np.array([ctx.checksum_rows_device(out_ptr + i * upitch, upitch, 1, length=int(lengths[i]))[0] for i in usample], dtype=np.uint64)
-			u_ok = bool(np.array_equal(ulen, lengths[usample])) and bool(np.array_equal(ugot, uwant))
-			ms_per_base = u_splice / max(1, bases_u)
-			return {
-				"rows": n_u, "bases": bases_u, "footprint_GB": round(n_u * upitch / 1e9, 2),
-				"value": round(bases_u / (u_resolve + u_count + u_splice) / 1e6, 1), "unit": "Gbases/s", "wall_ms_per_batch": round(1e3 * wall_u, 3),
-				"kernels_ms": {"resolve_effective_edges_kernel": round(u_resolve, 3), "count_unaligned_kernel+scan_tile_counts_kernel": round(u_count, 3), "splice_unaligned_kernel": round(u_splice, 3)},
-				"roofline": {"bound": "hbm", "kernel": "splice_unaligned_kernel", "algorithmic_bytes_per_launch": int(alg_u), "achieved": round(alg_u / u_splice / 1e6, 1), "peak": HBM_PEAK_GBS,
-					"unit": "GB/s", "frac": round(alg_u / u_splice / 1e6 / HBM_PEAK_GBS, 4)},
-				"time_per_base_vs_aligned_kernel": round(ms_per_base / aligned_ms_per_base, 3) if aligned_ms_per_base > 0 else None,
-				"aligned_kernel_same_rows_ms": round(a_same, 3) if a_same else None,
-				"time_per_base_vs_aligned_kernel_same_rows": round(ms_per_base / (a_same / (n_u * L)), 3) if a_same else None,
-				"yardsticks": "time_per_base_vs_aligned_kernel: against the timed region's aligned launches (the output buffer's whole footprint); ..._same_rows: against the aligned kernel on these very rows, this buffer and this pitch",
-				"roofline_count_pass": {"bound": "hbm", "kernel": "count_unaligned_kernel+scan_tile_counts_kernel", "algorithmic_bytes_per_launch": int(alg_c), "achieved": round(alg_c / u_count / 1e6, 1),
-					"unit": "GB/s", "note": "reads the shared inputs and the rows' effective-edge bits, writes 4 bytes per (row, 16-KiB tile); builds no row"},
-				"parity": {"rows_checked": len(usample), "bit_exact": u_ok, "method": "row lengths and device checksums against the CPU oracle's unaligned rows"},
-			}
-
-		n_full = max(1, min(out_bytes // upitch, n_rows))
-		n_small = max(1, min(args.unaligned_rows, n_full))
-		small = unaligned_leg(n_small)
-		full = unaligned_leg(n_full) if n_full != n_small else small
-		result["unaligned"] = dict(full, metric="unaligned (--unaligned) Gbases/sec, one batch on the aligned leg's output buffer (same ~%.0f-GB address footprint), kernels only, rank 0" % (out_bytes / 1e9),
-			first_rows_only=small, tuning=ctx.info)
-		for leg in (small, full):
-			if not leg["parity"]["bit_exact"]:
-				log("[bench] PARITY FAILURE (unaligned leg, %d rows) against the CPU oracle" % leg["rows"])
-				result.setdefault("parity", {})["bit_exact"] = False
-
-	# ---- the CPU path beside the GPU transpose ("time the whole matrix on CPU, one call per run") ---------
-	if args.cpu_transpose and hp_local and "roofline_transpose" in result:
-		import oracle
-		host_src = np.frombuffer(_device_bytes(paths_src.data_ptr(), tr_bytes // 2), dtype=np.uint64)      # copied to the host once, after all GPU timing
-		ctx.transpose_bits_device(paths_src.data_ptr(), hp_local, Ep, paths_dst.data_ptr())                # the ABI's dense form: caller-visible destination
-		ctx.synchronize()
-		gpu_dense = np.frombuffer(_device_bytes(paths_dst.data_ptr(), tr_bytes // 2), dtype=np.uint64)
-		t_c = time.perf_counter()
-		cpu_dst = oracle.transpose_matrix(host_src, hp_local, Ep)          # transpose_matrix.cc:41-109's traversal, one thread, -O2
-		secs_c = time.perf_counter() - t_c
-		same = bool(np.array_equal(cpu_dst, gpu_dense))
-		gpu_ms = result["roofline_transpose"]["avg_launch_ms"]
-		result["roofline_transpose"]["cpu_baseline"] = {
-			"seconds": round(secs_c, 6), "value": round(tr_bytes / secs_c / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-			"sample": "the whole %d x %d-bit matrix of rank 0 in this run (%.3f GB read + written), one call of the oracle's v2mo_transpose_matrix (the 8x8-block traversal of transpose_matrix.cc:41-109), including its zero-fill of the destination; host has %d logical CPUs"
-				% (hp_local, Ep, tr_bytes / 1e9, os.cpu_count()),
-			"bit_exact_vs_gpu_dense_form": same, "gpu_over_cpu": round(secs_c * 1e3 / gpu_ms, 1) if gpu_ms > 0 else None,
-		}
-		if not same:
-			log("[bench] PARITY FAILURE: the GPU's dense-form transpose differs from the CPU oracle's")
-			result.setdefault("parity", {})["bit_exact"] = False
-		del host_src, gpu_dense, cpu_dst
-
-	# ---- the CPU path beside the GPU splice: same run, same host, at every N (the other ranks have finished or wait) -------
-	if args.cpu_baseline_rows:
-		nb = min(args.cpu_baseline_rows, H)
-		og = oracle_graph(list(range(nb)))
-		nbytes, secs = og.haplotype_output_a2m(ds.reference, None, first_copy=0, n_copies=nb)
-		bases = (nb + 1) * L
-		result["cpu_baseline"] = {
-			"value": round(bases / secs / 1e9, 4), "unit": "Gbases/s", "cores": 1, "kind": "port",
-			"sample": "REF + first %d haplotypes of %s (%.2f Gbases) through the oracle's output_sequence/haplotype_output_a2m (sequence_writer.cc:22-85 driven by haplotype_output.cc:38-82) into a discarding std::ostream, %.1f s, on rank 0's host cores after the timed region; rows are independent, so the rate carries to the full %d rows; host has %d logical CPUs"
-				% (nb, args.config, bases / 1e9, secs, total_rows, os.cpu_count()),
-		}
+	result.update(extras)          # roofline_transpose, unaligned, cpu_baseline: measured before the end-to-end leg (above)
 
 	result_out.write(json.dumps(result) + "\n")
 	result_out.flush()

@@ -231,7 +231,11 @@ int v2m_splice_rows_device(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t fla
  * their physical backing is, which a caller cannot see from a pointer.  Allocates up to `candidates` buffers of
  * `bytes` (fewer if HBM runs out -- all of them are held until the choice is made), times the store pattern on each,
  * keeps the fastest and frees the others; v2m_ctx_info() reports the rates.  candidates <= 1 (or a buffer too small to
- * probe) is a plain allocation.  Free with v2m_free_output().  Synchronous. */
+ * probe) is a plain allocation.  Free with v2m_free_output().  Synchronous.
+ * A side effect to know about: the driver wipes freed device memory that has been written, in the background, and while it
+ * does (about 3 s per freed 63-GB candidate, measured) the process's device-to-host copies run at ~70 % of the link's rate
+ * (profiles/r04/e2e_slow_after_alloc_output.txt).  A caller that is about to stream rows to the host (v2m_splice_rows) and
+ * cares about those first seconds asks for one candidate. */
 int v2m_alloc_output(v2m_ctx *ctx, uint64_t bytes, int candidates, void **d_out);
 int v2m_free_output(v2m_ctx *ctx, void *d_ptr);
 

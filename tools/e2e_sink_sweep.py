@@ -10,6 +10,10 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--config", default="config3")
 ap.add_argument("--rows", type=int, default=640)
 ap.add_argument("--threads", default="4,8,16,32,64")
+ap.add_argument("--candidates", type=int, default=0, help="before the sink path's first use: v2m_alloc_output of a 63-GB buffer chosen among this many candidates (what bench.py does first)")
+ap.add_argument("--churn", default="", help="before the sink path's first use: hipMalloc this many 63-GB buffers; 'N' frees them again at once, 'N:hold' keeps them, 'N:touch' writes them (hipMemset) before freeing")
+ap.add_argument("--recovery", type=int, default=0, help="after the setup: this many extra passes of 96 rows (9.6 GB) through the counting sink, each with the time since the setup ended -- how long does a slow link stay slow?")
+ap.add_argument("--slots-first", action="store_true", help="with --candidates: run the sink path once BEFORE the candidates are allocated, so that its device and pinned slots exist already")
 args = ap.parse_args()
 
 import torch
@@ -56,6 +60,41 @@ def run(sink, state):
 	return dt
 
 
+if args.churn:
+	from vcf2multialign_amd import _native
+	rt = _native.hip_runtime()
+	rt.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+	rt.hipFree.argtypes = [C.c_void_p]
+	rt.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+	n, _, how = args.churn.partition(":")
+	ptrs = []
+	for i in range(int(n)):
+		p = C.c_void_p()
+		assert rt.hipMalloc(C.byref(p), 627 * ctx.min_row_pitch) == 0
+		ptrs.append(p)
+	if how == "touch":
+		for p in ptrs:
+			assert rt.hipMemset(p, 1, 627 * ctx.min_row_pitch) == 0
+		torch.cuda.synchronize()
+	if how != "hold":
+		for p in ptrs:
+			assert rt.hipFree(p) == 0
+	print("churn: %s x 63 GB hipMalloc'ed%s" % (n, {"hold": ", kept", "touch": ", written, freed"}.get(how, ", freed")), flush=True)
+if args.candidates:
+	if args.slots_first:
+		st = State(-1, 0, 0)
+		run(count_sink, C.byref(st))
+	out = ctx.alloc_output(627 * ctx.min_row_pitch, args.candidates)
+	print("output buffer of %.1f GB among %d candidates%s: %s" % (627 * ctx.min_row_pitch / 1e9, args.candidates, " (sink slots set up first)" if args.slots_first else "", ctx.info), flush=True)
+if args.recovery:
+	t_setup = time.perf_counter()
+	small = v2m.RowBatch([v2m.PLOIDY_MAX] + list(range(95)))
+	for i in range(args.recovery):
+		st = State(-1, 0, 0)
+		t0 = time.perf_counter()
+		rc = ctx._lib.v2m_splice_rows(ctx._h, C.byref(small.struct), 0, count_sink, C.byref(st))
+		dt = time.perf_counter() - t0
+		print("  %5.1f s after the setup: 96 rows through the counting sink at %.1f GB/s" % (t0 - t_setup, st.bytes / dt / 1e9), flush=True)
 st = State(-1, 0, 0)
 run(count_sink, C.byref(st))
 for rep in range(2):
