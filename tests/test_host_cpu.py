@@ -281,18 +281,20 @@ def test_bench_hub_over_pipes(n):
 	assert "import torch" not in hub and "dist." not in hub.replace("torch.distributed.", "") and "init_process_group" not in hub
 
 
-def test_bench_hub_under_torch_distributed_run():
-	"""The driver's launch form, world size 2 on CPU: the same barrier / gather through a gloo group."""
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_hub_under_torch_distributed_run(n):
+	"""The driver's launch form (python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N), world sizes 2 and 8 on CPU: the
+	same barrier / gather through a gloo group -- what the 8-GPU scaling run will use to line its ranks up."""
 	import json
 	import subprocess
 	import sys
-	r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-		os.path.join(ROOT, "bench.py"), "--gpus", "2", "--hub-selftest"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, env=_clean_env())
+	r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+		os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--hub-selftest"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, env=_clean_env())
 	assert r.returncode == 0, r.stderr.decode()[-2000:]
 	lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
 	assert len(lines) == 1
 	d = json.loads(lines[0])
-	assert [f["rank"] for f in d["hub_selftest"]] == [0, 1] and "torch.distributed (gloo)" in d["ranks_coordinated_by"]
+	assert [f["rank"] for f in d["hub_selftest"]] == list(range(n)) and "torch.distributed (gloo)" in d["ranks_coordinated_by"]
 
 
 def test_checksum_sink_of_the_end_to_end_leg(v2m):

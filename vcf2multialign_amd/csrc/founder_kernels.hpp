@@ -11,7 +11,8 @@
 //               both are prefix scans, of a count and of functions "p -> max(p, a)" / "p -> c" composed left to right
 //   candidate   class_count(v) = #{copies with divergence > v} only changes between candidates' edge ranges, so the walk
 //               over distinct values collapses to: bin the copies by the candidate their divergence value points to (an LDS
-//               hash), sort the few dozen distinct bins, prefix-sum their counts
+//               hash; about a hundred bins at config 4), then for every bin the copies and the emitting bins among the bins
+//               with a larger key -- one sum over the pairs of bins, spread over the whole workgroup; no sort, no scan
 //
 // Divergence values are BIASED by one as on the host (0 = "no match yet", founder.cc), so everything is plain u32 order.
 #pragma once

@@ -1345,6 +1345,8 @@ int pbwt_check_state(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_chunks, const u
 	if (n_copies > ctx->path_cols) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the bound path matrix has %llu copies, %llu asked for", (unsigned long long) ctx->path_cols, (unsigned long long) n_copies);
 	// (the kernels stage a whole edge column -- path_cols / 64 words -- in an LDS array sized for kPbwtMaxCopies)
 	if (ctx->path_cols > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk reads edge columns of at most %d copies; the bound path matrix has %llu columns", v2m::kPbwtMaxCopies, (unsigned long long) ctx->path_cols);
+	// (biased divergence values are edge indices + 2, and the kernels keep bit 31 of a running maximum for "constant")
+	if (ctx->n_edges >= 0x7FFFFFF0ull) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk keeps edge indices in 31 bits (the graph has %llu edges)", (unsigned long long) ctx->n_edges);
 	// the start order indexes the workgroup's state arrays in LDS
 	for (u64 i(0), n(n_chunks * n_copies); i < n; ++i)
 		if (start_order[i] >= n_copies) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "start_order[%llu] = %u is not a chromosome copy (%llu copies)", (unsigned long long) i, start_order[i], (unsigned long long) n_copies);
