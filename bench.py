@@ -231,6 +231,9 @@ class TorchHub(SoloHub):
 	def __init__(self, backend, rank, dev):
 		import torch.distributed as dist
 		os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+		# one node by contract: the group's own sockets go over loopback, whatever the host's name resolves to (or does not)
+		os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+		os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
 		if backend == "nccl":
 			dist.init_process_group("nccl", device_id=dev)
 		else:
