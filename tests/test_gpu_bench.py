@@ -34,6 +34,8 @@ def test_bench_line_has_the_contract_fields():
 	assert abs(roof["achieved"] - roof["algorithmic_bytes_per_launch"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) <= 0.01 * roof["achieved"]
 	cpu = d["cpu_baseline"]
 	assert cpu["value"] > 0 and cpu["unit"] == "Gbases/s" and cpu["cores"] == 1 and cpu["kind"] == "port" and cpu["sample"]
+	many = cpu["rows_dealt_to_threads"]             # context for the end-to-end figure; labelled as not the reference's behaviour
+	assert many["value"] > 0 and many["cores"] >= 1 and "not the reference's behaviour" in many["note"]
 	assert d["parity"]["bit_exact"] is True and d["parity"]["rows_checked"] > 0
 	assert d["parity"]["batches_covered"] >= 1
 	tr = d["roofline_transpose"]                    # the transpose at the reference's own 64-bit padding
