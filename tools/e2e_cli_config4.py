@@ -40,7 +40,7 @@ print("prepared %s: graph file %.0f MB, FASTA %.0f MB in %.1f s" % (cfg, os.path
 
 t = time.time()
 wrap = os.environ.get("E2E_WRAP", "").split()   # e.g. "rocprofv3 --hip-trace --stats -d DIR -o t --": the driver under a profiler
-p = subprocess.Popen(wrap + [build.CLI_PATH] + (["-F", "25", "-d", "50"] if mode == "founders" else ["-H", "--unaligned"] if mode == "unaligned" else ["-H"]) + ["-r", fa, "-g", gf, "-c", "1", "-s", "/dev/null", "--output-graph-statistics"] + (["--device=" + devices, "--verbose"] if devices else []),
+p = subprocess.Popen(wrap + [build.CLI_PATH] + (["-F", "25", "-d", "50"] if mode == "founders" else ["-H", "--unaligned"] if mode == "unaligned" else ["-H"]) + ["-r", fa, "-g", gf, "-c", "1", "-s", os.environ.get("E2E_DEST", "/dev/null"), "--output-graph-statistics"] + (["--device=" + devices, "--verbose"] if devices else []),
 	stderr=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
 marks = []
 for line in p.stderr:
@@ -54,4 +54,6 @@ print(p.stdout.read().strip())
 rows = 26 if mode == "founders" else ds.n_copies + 1
 print("exit %d; total %.2f s (%d rows x %d bases = %.1f Gbases -> %.1f Gbases/s end to end)" % (p.returncode, total, rows, g.aligned_length, rows * g.aligned_length / 1e9, rows * g.aligned_length / 1e9 / total))
 os.remove(gf); os.remove(fa)
+if os.environ.get("E2E_DEST", "/dev/null") != "/dev/null":
+	print("output file: %.2f GB" % (os.path.getsize(os.environ["E2E_DEST"]) / 1e9)); os.remove(os.environ["E2E_DEST"])
 sys.exit(p.returncode)
