@@ -271,7 +271,7 @@ def main():
 	ap.add_argument("--cpu-transpose", type=int, default=1, help="after timing (rank 0, every N): time the CPU oracle's transpose_matrix on rank 0's matrix and compare it bit for bit with the GPU's dense-form result (config 3: ~5 s); 0 disables")
 	ap.add_argument("--transpose-extras", type=int, default=1, help="after timing, also measure the inverse transpose and a 1024-bit-padded matrix (rank 0); 0 disables")
 	ap.add_argument("--e2e-gb", type=float, default=64.0, help="the end-to-end leg (every rank, last: after the main timing and rank 0's other legs, by which time the driver has finished wiping the output-buffer candidates that v2m_alloc_output freed): this many GB of the rank's rows through v2m_splice_rows -- device slots, D2H copies on the copy stream, pinned slots -- into a C sink that checksums every row on the host; 0 disables")
-	ap.add_argument("--e2e-threads", type=int, default=4, help="host threads of the end-to-end leg's checksumming sink.  A GPU box gives a job 16 cores' worth of CPU time (a cgroup quota: what goes beyond it gets the whole process throttled -- with 16 threads of the scalar loop the leg ran at 39 instead of 55 GB/s in one run out of three), so the sink must leave room for the process's other threads: with the AVX-512 loop (41 GB/s per thread on the boxes' Zen 5 cores, profiles/r04/cpu_quota_and_sink_rates.txt) four threads are twice what the link delivers; the scalar loop (7 GB/s per thread) needs --e2e-threads 12")
+	ap.add_argument("--e2e-threads", type=int, default=0, help="host threads of the end-to-end leg's checksumming sink; 0 = by the CPU: 4 where the sink has its AVX-512DQ loop (41 GB/s per thread on the boxes' Zen 5 cores, profiles/r04/cpu_quota_and_sink_rates.txt: twice what the link delivers), 12 with the scalar loop (7 GB/s per thread).  A GPU box gives a job 16 cores' worth of CPU time (a cgroup quota: what goes beyond it gets the whole process throttled), so the sink must leave room for the process's other threads")
 	ap.add_argument("--hub-selftest", action="store_true", help="no GPU work: the ranks only exercise the barrier / gather plumbing of their launch form and rank 0 prints what it gathered (CPU test suite)")
 	args = ap.parse_args()
 
@@ -689,6 +689,10 @@ def main():
 		sl.v2ms_checksum_sink_flavour.argtypes = [C.c_void_p]
 		sink_fn = C.cast(sl.v2ms_checksum_sink_fn, N.SINK_FN)
 		sink_flavour = [None]
+		if args.e2e_threads <= 0:
+			probe = sl.v2ms_checksum_sink_create(1, 1)
+			args.e2e_threads = 4 if sl.v2ms_checksum_sink_flavour(probe) == b"avx512dq" else 12
+			sl.v2ms_checksum_sink_destroy(probe)
 
 		def through_the_sink(batch):
 			state = sl.v2ms_checksum_sink_create(max(1, batch.n_rows), max(1, args.e2e_threads))
