@@ -179,12 +179,21 @@ namespace {
 		std::vector<std::uint64_t> const *global_row;   // of each row of this context's batch
 		v2m_sink_fn sink;
 		void *user;
+		bool ordered;                                   // false: the sink may be called for any row at any time, from every context's thread
 	};
 
 	int turn_sink(void *user, uint64_t row, char const *bytes, uint64_t length)
 	{
 		auto &st(*static_cast<turn_state *>(user));
 		std::uint64_t const global((*st.global_row)[row]);
+		if (!st.ordered) {
+			// rows that do not depend on each other's place (a file per sequence): every context writes its own as they come -- writers on
+			// different files do not wait for each other the way writers on one file do (profiles/r04/e2e_config2_file_destinations.txt)
+			{ std::lock_guard<std::mutex> const lock(st.gate->mutex); if (st.gate->failed) return 1; }
+			int const rc(st.sink(st.user, global, bytes, length));
+			if (rc) { std::lock_guard<std::mutex> const lock(st.gate->mutex); st.gate->failed = true; }
+			return rc;
+		}
 		std::unique_lock<std::mutex> lock(st.gate->mutex);
 		st.gate->turn.wait(lock, [&] { return st.gate->failed || st.gate->next_row == global; });
 		if (st.gate->failed) return 1;
@@ -199,7 +208,7 @@ namespace {
 
 // splice() over several contexts that hold the chromosome copies dealt round-robin (set_copy_interleave): the sink sees the
 // rows in the batch's order, exactly as from one context.
-void output::splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user)
+void output::splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user, bool ordered)
 {
 	if (rows.any_cuts) throw std::runtime_error("rows that switch copies need the whole path matrix on their GPU");
 	std::vector<gpu_context *> gpus{&m_gpu};
@@ -225,7 +234,7 @@ void output::splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user)
 				v2m_row_batch batch{};
 				batch.n_rows = local_copy[k].size();
 				batch.copy_index = local_copy[k].data();
-				turn_state st{&gate, &global_row[k], sink, user};
+				turn_state st{&gate, &global_row[k], sink, user, ordered};
 				gpus[k]->check(v2m_splice_rows(gpus[k]->get(), &batch, m_should_output_unaligned ? V2M_SPLICE_UNALIGNED : 0u, turn_sink, &st));
 			} catch (...) {
 				errors[k] = std::current_exception();
@@ -245,9 +254,9 @@ void output::splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user)
 }
 
 
-void output::splice(row_set const &rows, v2m_sink_fn sink, void *user)
+void output::splice(row_set const &rows, v2m_sink_fn sink, void *user, bool ordered)
 {
-	if (m_interleaved && !m_more_gpus.empty()) { splice_in_turns(rows, sink, user); return; }
+	if (m_interleaved && !m_more_gpus.empty()) { splice_in_turns(rows, sink, user, ordered); return; }
 	v2m_row_batch batch{};
 	batch.n_rows = rows.copy_index.size();
 	batch.copy_index = rows.copy_index.data();
@@ -344,7 +353,9 @@ void output::write_separate(row_set const &rows)
 {
 	separate_state st{&rows.ids, m_pipe_cmd, nullptr};
 	try {
-		splice(rows, separate_sink, &st);
+		// Files of their own need no order among themselves: with several GPU contexts each one's thread writes its sequences as they
+		// arrive.  Subprocesses (--pipe) are still started one after the other, as the reference starts them (output.cc:26-38).
+		splice(rows, separate_sink, &st, nullptr != m_pipe_cmd);
 	} catch (...) {
 		if (st.error) std::rethrow_exception(st.error);                     // what went wrong with the subprocess, not "sink failed"
 		throw;

@@ -67,8 +67,9 @@ protected:
 		std::vector<std::uint32_t> cut_copies;
 		bool any_cuts{};
 	};
-	void splice(row_set const &rows, v2m_sink_fn sink, void *user);
-	void splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user);
+	// ordered = false: the sink takes any row at any time and from several threads (one per GPU context)
+	void splice(row_set const &rows, v2m_sink_fn sink, void *user, bool ordered = true);
+	void splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user, bool ordered);
 	static std::vector<std::uint32_t> rebased_copies(row_set const &rows, std::uint64_t first, std::uint64_t last, copy_shard shard);
 	void write_a2m(row_set const &rows, std::ostream &stream);
 	void write_a2m_sharded(row_set const &rows, char const *dst_name);
