@@ -100,6 +100,40 @@ def _device_bytes(ptr, nbytes):
 	return buf.raw
 
 
+def device_binding(dev_index):
+	"""Where this rank landed: the HIP device the runtime reports as current (after torch.cuda.set_device), its name and PCI bus id,
+	the NUMA node that slot hangs off (sysfs) and the CPUs this process may run on -- logged by every rank and carried in
+	config.per_rank, so that a rank bound to the wrong GPU, or to a GPU across the socket, is visible in the record."""
+	import ctypes
+	out = {"hip_device": None, "name": None, "pci_bus_id": None, "numa_node": None, "cpus_allowed": None}
+	try:
+		rt = _hip_runtime()
+		cur = ctypes.c_int(-1)
+		if rt.hipGetDevice(ctypes.byref(cur)) == 0:
+			out["hip_device"] = cur.value
+		buf = ctypes.create_string_buffer(64)
+		if rt.hipDeviceGetPCIBusId(buf, 64, ctypes.c_int(dev_index)) == 0:
+			out["pci_bus_id"] = buf.value.decode().lower()
+		import torch
+		out["name"] = torch.cuda.get_device_name(dev_index)
+	except Exception as e:   # a record, not a requirement
+		out["error"] = repr(e)
+	if out["pci_bus_id"]:
+		try:
+			with open("/sys/bus/pci/devices/%s/numa_node" % out["pci_bus_id"]) as f:
+				out["numa_node"] = int(f.read().strip())
+		except (OSError, ValueError):
+			pass
+	try:
+		with open("/proc/self/status") as f:
+			for line in f:
+				if line.startswith("Cpus_allowed_list:"):
+					out["cpus_allowed"] = line.split(":", 1)[1].strip()
+	except OSError:
+		pass
+	return out
+
+
 HUB_ENV = "V2M_BENCH_HUB"   # set for the children of `python bench.py --gpus N`: the parent serves barrier / gather over their pipes
 
 
@@ -260,18 +294,20 @@ def main():
 	ap.add_argument("--steps", type=int, default=3)
 	ap.add_argument("--warmup", type=int, default=1)
 	ap.add_argument("--config", default="config3", help="synthetic workload (vcf2multialign_amd/synth.py CONFIGS)")
+	ap.add_argument("--samples", type=int, default=0, help="override the config's number of diploid samples (tests: so few copies that some ranks own no row at all)")
 	ap.add_argument("--batch-rows", type=int, default=0, help="rows per splice launch (one device output buffer of this many rows is reused); 0 = as many as fit --batch-gb")
 	ap.add_argument("--batch-gb", type=float, default=64.0, help="size of the reused device output buffer when --batch-rows is 0: launches that write a ~64-GB address range reach the full HBM write rate (DESIGN.md section 4)")
 	ap.add_argument("--dist-backend", default="gloo", help="under torch.distributed.run only: the torch.distributed backend of the barrier / gather of figures (gloo: CPU objects; nccl = RCCL).  The data path has no collective; `python bench.py --gpus N` as typed uses neither")
 	ap.add_argument("--force-device", type=int, default=None, help="rehearsal only: put every rank on this HIP device")
 	ap.add_argument("--output-candidates", type=int, default=4, help="device buffers v2m_alloc_output may hold at once to choose the output buffer from (as many as fit are tried; 1 = plain allocation)")
 	ap.add_argument("--cpu-baseline-rows", type=int, default=320, help="haplotypes (plus REF) the CPU oracle is timed on, on rank 0 after the timed region at every N (320 rows of config 3 = 32 Gbases, about 11 s on one core); 0 disables")
-	ap.add_argument("--verify-rows", type=int, default=1, help="after timing: rows per batch (every batch) checked against the CPU oracle, plus REF and the last batch's ragged final group; 0 disables")
+	ap.add_argument("--verify-rows", type=int, default=-1, help="after timing, every rank re-runs every batch of its step and checks rows against the CPU oracle by device checksum: -1 (default) = EVERY row of every batch (config 3: all 5009 rows, ~25 s of oracle time on the job's 16 quota cores, dealt over the ranks at N > 1); k > 0 = k rows per batch plus REF and the last batch's ragged final group; 0 disables")
 	ap.add_argument("--unaligned-rows", type=int, default=256, help="the separately timed --unaligned leg (rank 0, after the main timing) runs on as many rows as the output buffer holds and, beside it, on the first this-many rows; 0 disables")
 	ap.add_argument("--cpu-transpose", type=int, default=1, help="after timing (rank 0, every N): time the CPU oracle's transpose_matrix on rank 0's matrix and compare it bit for bit with the GPU's dense-form result (config 3: ~5 s); 0 disables")
 	ap.add_argument("--transpose-extras", type=int, default=1, help="after timing, also measure the inverse transpose and a 1024-bit-padded matrix (rank 0); 0 disables")
 	ap.add_argument("--e2e-gb", type=float, default=64.0, help="the end-to-end leg (every rank, last: after the main timing and rank 0's other legs, by which time the driver has finished wiping the output-buffer candidates that v2m_alloc_output freed): this many GB of the rank's rows through v2m_splice_rows -- device slots, D2H copies on the copy stream, pinned slots -- into a C sink that checksums every row on the host; 0 disables")
-	ap.add_argument("--e2e-threads", type=int, default=0, help="host threads of the end-to-end leg's checksumming sink; 0 = by the CPU: 4 where the sink has its AVX-512DQ loop (41 GB/s per thread on the boxes' Zen 5 cores, profiles/r04/cpu_quota_and_sink_rates.txt: twice what the link delivers), 12 with the scalar loop (7 GB/s per thread).  A GPU box gives a job 16 cores' worth of CPU time (a cgroup quota: what goes beyond it gets the whole process throttled), so the sink must leave room for the process's other threads")
+	ap.add_argument("--e2e-threads", type=int, default=0, help="host threads of the end-to-end leg's checksumming sink, PER RANK; 0 = by the CPU and the job's quota: 4 where the sink has its AVX-512DQ loop (41 GB/s per thread on the boxes' Zen 5 cores, profiles/r04/cpu_quota_and_sink_rates.txt: twice what the link delivers), 12 with the scalar loop (7 GB/s per thread), and never more than this rank's share of the job's CPU quota (cgroup cpu.max / affinity mask, divided by LOCAL_WORLD_SIZE, one core left for the rank's main thread): what goes beyond the quota gets the whole job throttled")
+	ap.add_argument("--host-threads", type=int, default=0, help="threads per rank for the CPU oracle's row checks after timing; 0 = this rank's share of the job's CPU quota (sharding.host_threads_per_rank), at most 16")
 	ap.add_argument("--hub-selftest", action="store_true", help="no GPU work: the ranks only exercise the barrier / gather plumbing of their launch form and rank 0 prints what it gathered (CPU test suite)")
 	args = ap.parse_args()
 
@@ -289,6 +325,7 @@ def main():
 	os.dup2(2, 1)
 
 	under_parent = os.environ.get(HUB_ENV) == "1"
+	local_world = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
 	if args.hub_selftest:
 		hub = SoloHub() if world == 1 else PipeHub(rank, result_out) if under_parent else TorchHub(args.dist_backend, rank, None)
 		hub.barrier()
@@ -316,16 +353,26 @@ def main():
 	from vcf2multialign_amd import build as _build
 	if not under_parent:            # (the parent of `python bench.py --gpus N` has built before it started the ranks)
 		if local_rank == 0:
-			_build.build_native()   # no-op when the in-tree libraries are newer than their sources (hipcc cross-compiles gfx950)
+			try:
+				_build.build_native()   # no-op when the in-tree libraries are newer than their sources (hipcc cross-compiles gfx950)
+			except _build.StaleUnderProfiler as e:   # never a compiler launcher under a profiler's preload: build first, then profile
+				sys.exit("[bench] " + str(e))
 		hub.barrier()               # nobody loads the libraries before the (possible) rebuild is over
 	import vcf2multialign_amd as v2m
 	from vcf2multialign_amd import _native as N
 	from vcf2multialign_amd import synth
-	from vcf2multialign_amd.sharding import shard_copies
+	from vcf2multialign_amd.sharding import cpu_quota, host_threads_per_rank, shard_copies
+
+	# ---- the host side of this rank: sized from the JOB's quota, divided among the node's ranks ------------------------------
+	quota_cores, quota_source = cpu_quota()
+	host_threads = args.host_threads if args.host_threads > 0 else host_threads_per_rank(local_world, cap=16)
+	where = device_binding(dev_index)
+	log("[bench] rank %d/%d (local %d/%d, pid %d): HIP device %s = %s, PCI %s, NUMA node %s; CPUs allowed %s; job quota %d cores (%s) -> %d host threads for this rank"
+		% (rank, world, local_rank, local_world, os.getpid(), where["hip_device"], where["name"], where["pci_bus_id"], where["numa_node"], where["cpus_allowed"], quota_cores, quota_source, host_threads))
 
 	# ---- workload: generated on every rank (deterministic), resident in HBM before timing ----------
 	t0 = time.time()
-	ds = synth.dataset(args.config)
+	ds = synth.dataset(args.config, **({"samples": args.samples} if args.samples > 0 else {}))
 	g = ds.graph
 	L, R, NN, E = g.aligned_length, len(ds.reference), g.node_count, g.edge_count
 	H = ds.n_copies
@@ -409,6 +456,7 @@ def main():
 		"rank": rank, "rows": n_rows, "batches": len(batches), "elapsed_s": elapsed,
 		"launches": launches, "splice_ms": splice_ms, "algorithmic_bytes_per_launch": alg_bytes_per_launch,
 		"resolve_ms": resolve_ms, "transpose_launches": transpose_launches, "transpose_ms": transpose_ms,
+		"binding": where, "host_threads": host_threads,
 	}
 
 	# ---- CPU oracle: every rank checks rows of every batch of its own shard ----------------------------
@@ -421,9 +469,45 @@ def main():
 			g.label_offsets, g.label_bytes, np.concatenate(cols) if Ep else np.zeros(0, np.uint64), Ep, n_cols,
 			["S%d" % i for i in range(n_cols // ds.ploidy)], np.arange(n_cols // ds.ploidy + 1, dtype=np.uint32) * ds.ploidy)
 
-	host_threads = max(1, min(16, os.cpu_count() or 1))
-	mine["parity_ok"], mine["parity_checked"] = True, 0
-	if args.verify_rows and batches:
+	mine["parity_ok"], mine["parity_checked"], mine["parity_all_rows"] = True, 0, args.verify_rows < 0   # (a rank that owns no row has checked all of them)
+	oracle_sums = {}     # local row index -> the oracle's checksum of that (aligned) row, kept for the end-to-end leg's check
+	local_of = lambda bi, r: rows[bi * batch_rows + r]
+
+	def oracle_rows_of(local_rows_):
+		"""(oracle graph over the copies these local rows name, the oracle's row arguments for them)."""
+		import oracle
+		copies = sorted({c0 + lr for lr in local_rows_ if lr != v2m.PLOIDY_MAX})
+		col_of = {c: i for i, c in enumerate(copies)}
+		return oracle_graph(copies), [oracle.PLOIDY_MAX if lr == v2m.PLOIDY_MAX else col_of[c0 + lr] for lr in local_rows_]
+
+	if args.verify_rows < 0 and batches:
+		# EVERY row of every batch of this rank's step: the batch is re-run, every row reduced to its 64-bit checksum on the device, and the
+		# oracle walks the same rows on this rank's host threads (the columns of one batch resident at a time).  "bit-exact vs CPU" is total.
+		import oracle
+		t_o, ok, n_checked, full_compare = time.time(), True, 0, None
+		for bi, b in enumerate(batches):
+			ctx.splice_rows_device(b, out_ptr, pitch)
+			got = ctx.checksum_rows_device(out_ptr, pitch, b.n_rows, length=L)
+			part = [local_of(bi, r) for r in range(b.n_rows)]
+			og, want_rows = oracle_rows_of(part)
+			want_sums, want_len = og.row_checksums(ds.reference, want_rows, threads=min(host_threads, len(want_rows)))
+			bad = np.nonzero((got != want_sums) | (want_len != L))[0]
+			if len(bad):
+				ok = False
+				log("[bench] rank %d PARITY: batch %d, %d rows differ from the oracle's (first: row %d of the batch)" % (rank, bi, len(bad), int(bad[0])))
+			for r in range(b.n_rows):
+				oracle_sums[bi * batch_rows + r] = int(want_sums[r])
+			n_checked += b.n_rows
+			if bi == len(batches) - 1:            # one row byte for byte: the very last row of the rank's step
+				r = b.n_rows - 1
+				body = og.output_sequence(ds.reference, copy_index=want_rows[r]) if want_rows[r] != oracle.PLOIDY_MAX else og.output_sequence(ds.reference)
+				full_compare = _device_bytes(out_ptr + r * pitch, L) == body
+			del og
+		ok = ok and full_compare is not False
+		mine["parity_ok"], mine["parity_checked"], mine["parity_all_rows"] = ok, n_checked, True
+		mine["parity_oracle_s"] = round(time.time() - t_o, 2)
+		log("[bench] rank %d parity: ALL %d rows of %d batches against the oracle in %.1f s on %d threads: %s" % (rank, n_checked, len(batches), time.time() - t_o, host_threads, "bit-exact" if ok else "MISMATCH"))
+	elif args.verify_rows and batches:
 		import oracle
 		# which rows: per batch `verify_rows` rows spread over the batch (the first batch's includes row 0: REF on rank 0), and
 		# every row of the last batch's final, ragged 16-row group (the rows a wrong grid or tile bound would lose first)
@@ -435,11 +519,7 @@ def main():
 		tail = last.n_rows % 16 or min(16, last.n_rows)
 		picks += [(len(batches) - 1, r) for r in range(last.n_rows - min(tail, 4), last.n_rows)]
 		picks = sorted(set(picks))
-		local_of = lambda bi, r: rows[bi * batch_rows + r]
-		copies = sorted({c0 + local_of(bi, r) for bi, r in picks if local_of(bi, r) != v2m.PLOIDY_MAX})
-		og = oracle_graph(copies)
-		col_of = {c: i for i, c in enumerate(copies)}
-		want_rows = [oracle.PLOIDY_MAX if local_of(bi, r) == v2m.PLOIDY_MAX else col_of[c0 + local_of(bi, r)] for bi, r in picks]
+		og, want_rows = oracle_rows_of([local_of(bi, r) for bi, r in picks])
 		t_o = time.time()
 		want_sums, want_len = og.row_checksums(ds.reference, want_rows, threads=min(host_threads, len(want_rows)))
 		ok = bool((want_len == L).all())
@@ -457,7 +537,7 @@ def main():
 				body = og.output_sequence(ds.reference, copy_index=want_rows[i]) if want_rows[i] != oracle.PLOIDY_MAX else og.output_sequence(ds.reference)
 				full_compare = _device_bytes(out_ptr + picks[i][1] * pitch, L) == body
 		ok = ok and bool(np.array_equal(got_sums, want_sums)) and full_compare is not False
-		mine["parity_ok"], mine["parity_checked"] = ok, len(picks)
+		mine["parity_ok"], mine["parity_checked"], mine["parity_all_rows"] = ok, len(picks), False
 		log("[bench] rank %d parity: %d rows of %d batches against the oracle in %.1f s: %s" % (rank, len(picks), len(batches), time.time() - t_o, "bit-exact" if ok else "MISMATCH"))
 		del og
 
@@ -647,13 +727,7 @@ def main():
 			# the same rows dealt to as many threads as the job's CPU quota allows (16 on a GPU box), each walking its rows into its own
 			# discarding stream.  It is what the end-to-end figure, not `value`, should be read against.
 			from concurrent.futures import ThreadPoolExecutor
-			quota = host_threads
-			try:
-				limit, period = open("/sys/fs/cgroup/cpu.max").read().split()
-				if limit != "max":
-					quota = max(1, min(quota, int(limit) // int(period)))
-			except (OSError, ValueError):
-				pass
+			quota = max(1, min(16, quota_cores))   # the whole job's quota: the other ranks wait at a barrier meanwhile
 			share = -(-nb // quota)
 			parts = [(c, min(share, nb - c)) for c in range(0, nb, share)]
 			t_all = time.perf_counter()
@@ -691,8 +765,13 @@ def main():
 		sink_flavour = [None]
 		if args.e2e_threads <= 0:
 			probe = sl.v2ms_checksum_sink_create(1, 1)
-			args.e2e_threads = 4 if sl.v2ms_checksum_sink_flavour(probe) == b"avx512dq" else 12
+			by_cpu = 4 if sl.v2ms_checksum_sink_flavour(probe) == b"avx512dq" else 12
 			sl.v2ms_checksum_sink_destroy(probe)
+			# never more than this rank's share of the job's quota, with one core per rank left for the rank's own thread (it drives the
+			# copies and hands the rows over).  A 16-core quota gives 4 sink threads at N = 1 and 1 at N = 8 (one AVX-512DQ thread reads
+			# 41 GB/s, below a link's 57: the line then shows it in end_to_end.sink); a quota of 16 cores per GPU gives 4 at every N.
+			# DESIGN.md section 7 has the budget of the leg at 8 links.
+			args.e2e_threads = max(1, min(by_cpu, host_threads_per_rank(local_world, cap=by_cpu, reserve=local_world)))
 
 		def through_the_sink(batch):
 			state = sl.v2ms_checksum_sink_create(max(1, batch.n_rows), max(1, args.e2e_threads))
@@ -726,16 +805,19 @@ def main():
 		if e2e_rows:
 			import oracle
 			t_o = time.time()
-			ecopies = [c0 + r for r in rows[:e2e_rows] if r != v2m.PLOIDY_MAX]
-			eog = oracle_graph(ecopies)
-			ecol = {c: i for i, c in enumerate(ecopies)}
-			ewant, ewant_len = eog.row_checksums(ds.reference, [oracle.PLOIDY_MAX if r == v2m.PLOIDY_MAX else ecol[c0 + r] for r in rows[:e2e_rows]], threads=host_threads)
+			if all(i in oracle_sums for i in range(e2e_rows)):
+				# the parity leg above has walked these very rows on the CPU already (every row of the rank): the same oracle checksums
+				ewant, ewant_len, how = np.array([oracle_sums[i] for i in range(e2e_rows)], dtype=np.uint64), np.full(e2e_rows, L, dtype=np.uint64), "the parity leg's oracle checksums of the same rows"
+			else:
+				eog, ewant_rows = oracle_rows_of(rows[:e2e_rows])
+				ewant, ewant_len = eog.row_checksums(ds.reference, ewant_rows, threads=host_threads)
+				how = "%.1f s on %d threads" % (time.time() - t_o, host_threads)
+				del eog
 			# (the checksums kept are the last pass's: every pass delivers the same rows)
 			e_ok = e_n == e2e_rows and e_bytes == e2e_rows * L and bool(np.array_equal(e_lens, ewant_len)) and bool(np.array_equal(e_sums, ewant))
-			del eog
 			e_secs = sorted(passes)[len(passes) // 2]
-			log("[bench] rank %d end to end: %d rows = %.1f GB through the sink in %s s (median %.1f GB/s); every row against the oracle (%.1f s on %d threads): %s"
-				% (rank, e_n, e_bytes / 1e9, " / ".join("%.3f" % p for p in passes), e_bytes / e_secs / 1e9, time.time() - t_o, host_threads, "bit-exact" if e_ok else "MISMATCH"))
+			log("[bench] rank %d end to end: %d rows = %.1f GB through the sink in %s s (median %.1f GB/s); every row against the oracle (%s): %s"
+				% (rank, e_n, e_bytes / 1e9, " / ".join("%.3f" % p for p in passes), e_bytes / e_secs / 1e9, how, "bit-exact" if e_ok else "MISMATCH"))
 			mine["e2e"] = {"rows": e_n, "bytes": e_bytes, "seconds": e_secs, "passes_s": [round(p, 4) for p in passes], "bit_exact": e_ok, "sink": "%d threads, %s loop" % (args.e2e_threads, sink_flavour[0])}
 
 	everyone = hub.gather(mine)
@@ -753,6 +835,8 @@ def main():
 	avg_ms = lambda f: f["splice_ms"] / max(1, f["launches"])
 	per_rank = [{"rank": f["rank"], "rows": f["rows"], "batches": f["batches"], "ms_per_step": round(1e3 * f["elapsed_s"] / args.steps, 3),
 		"launches": f["launches"], "avg_launch_ms": round(avg_ms(f), 4)} for f in everyone]
+	# where every rank ran (HIP device as the runtime reports it, PCI bus id, the slot's NUMA node, allowed CPUs) and what its host side was given
+	placement = [dict(f["binding"], rank=f["rank"], host_threads=f["host_threads"], sink=(f.get("e2e") or {}).get("sink")) for f in everyone]
 	# the roofline is the SLOWEST rank's kernel average over that rank's own launches (its rows per launch may differ by a few)
 	roof_rank = max(everyone, key=avg_ms)
 	avg_launch_s = avg_ms(roof_rank) / 1e3
@@ -797,6 +881,9 @@ def main():
 			"sharding": "contiguous chromosome copies per rank (multiples of 8), graph + reference replicated, no collective",
 			"ranks_coordinated_by": hub.kind,
 			"per_rank": per_rank,
+			"placement": placement,
+			"host": {"cpu_quota_cores": quota_cores, "cpu_quota_source": quota_source, "logical_cpus": os.cpu_count(), "local_world_size": local_world,
+				"note": "host threads per rank (oracle checks, sink) are the job's quota divided by the node's ranks, not os.cpu_count()"},
 			"tuning": ctx.info,
 		},
 		"roofline": {
@@ -812,8 +899,11 @@ def main():
 	checked = sum(f["parity_checked"] for f in everyone)
 	if checked:
 		ok = all(f["parity_ok"] for f in everyone)
-		result["parity"] = {"rows_checked": checked, "batches_covered": sum(f["batches"] for f in everyone), "bit_exact": ok,
-			"method": "per rank, after timing: every batch of the step re-run; device checksums (v2m_checksum_rows_device) of %d row(s) per batch, REF and the last batch's final ragged group against the CPU oracle's rows, plus the last row of the last batch byte for byte" % args.verify_rows}
+		all_rows = all(f.get("parity_all_rows") for f in everyone)
+		result["parity"] = {"rows_checked": checked, "rows_total": total_rows, "all_rows": all_rows and checked == total_rows, "batches_covered": sum(f["batches"] for f in everyone), "bit_exact": ok,
+			"oracle_seconds_per_rank": [f.get("parity_oracle_s") for f in everyone],
+			"method": ("per rank, after timing: every batch of the step re-run and EVERY row's device checksum (v2m_checksum_rows_device) compared with the CPU oracle's checksum of its own walk of that row (sequence_writer.cc:22-85), plus the last row of each rank byte for byte" if all_rows else
+				"per rank, after timing: every batch of the step re-run; device checksums (v2m_checksum_rows_device) of %d row(s) per batch, REF and the last batch's final ragged group against the CPU oracle's rows, plus the last row of the last batch byte for byte" % args.verify_rows)}
 		if not ok:
 			log("[bench] PARITY FAILURE against the CPU oracle")
 

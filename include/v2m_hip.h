@@ -73,7 +73,11 @@ enum {
 #define V2M_PLOIDY_MAX UINT32_MAX
 
 /* flags of v2m_splice_rows* */
-#define V2M_SPLICE_UNALIGNED 0x1u /* should_output_unaligned (sequence_writer.cc:80): no '-' padding */
+#define V2M_SPLICE_UNALIGNED 0x1u /* should_output_unaligned (sequence_writer.cc:80): no '-' padding.  Bytes are opaque to the
+                                   * walk (sequence_writer.cc:73-74 streams whatever the FASTA / VCF held) and aligned mode keeps
+                                   * every byte value; the unaligned kernels use byte 0 as their padding marker, so a graph whose
+                                   * ref_seq or label pool holds a NUL byte is refused in this mode (V2M_ERR_UNSUPPORTED) rather
+                                   * than written without it. */
 
 typedef struct v2m_ctx v2m_ctx;
 

@@ -23,6 +23,9 @@ _u32p = C.POINTER(C.c_uint32)
 def build_oracle(force=False):
 	src = os.path.join(ORACLE_DIR, "v2m_oracle.cc")
 	if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+		# never start a compiler from a process that runs under a profiler's preload (vcf2multialign_amd/build.py:under_profiler)
+		if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCPROFILER_")) for k in os.environ):
+			raise RuntimeError("oracle/libv2m_oracle.so is missing or stale and this process runs under a profiler: run `make -C oracle` first, without the profiler")
 		subprocess.check_call(["make", "-C", ORACLE_DIR, "-B" if force else "-s"])
 	return _LIB_PATH
 

@@ -55,7 +55,22 @@ def test_bench_line_has_the_contract_fields():
 	assert d["config"]["per_rank"] == [{"rank": 0, "rows": d["config"]["rows_total"], "batches": d["parity"]["batches_covered"], "ms_per_step": d["ms_per_step"],
 		"launches": roof["launches"], "avg_launch_ms": roof["avg_launch_ms"]}]
 	assert d["residency"] == "hbm" and "end_to_end" in d["residency_note"]      # the line says which number `value` is
+	assert d["parity"]["all_rows"] is True and d["parity"]["rows_checked"] == d["parity"]["rows_total"] == d["config"]["rows_total"]   # every row, not a sample
+	_check_placement(d, 1)
 	_check_end_to_end(d, n_ranks=1)
+
+
+def _check_placement(d, n_ranks, forced_device=0):
+	"""Every rank says where it ran (the HIP device the runtime reports, its PCI bus id, the slot's NUMA node, the CPUs it may use) and how many
+	host threads it was given out of the job's quota: a mis-bound rank or an oversubscribed host is visible in the record."""
+	host = d["config"]["host"]
+	assert host["cpu_quota_cores"] >= 1 and host["cpu_quota_source"] and host["local_world_size"] == n_ranks
+	place = d["config"]["placement"]
+	assert [p["rank"] for p in place] == list(range(n_ranks))
+	for p in place:
+		assert p["hip_device"] == forced_device and p["pci_bus_id"] and p["name"] and p["cpus_allowed"]
+		assert 1 <= p["host_threads"] <= max(1, host["cpu_quota_cores"] // n_ranks)
+	assert sum(p["host_threads"] for p in place) <= max(n_ranks, host["cpu_quota_cores"])
 
 
 def _check_end_to_end(d, n_ranks):
@@ -105,6 +120,8 @@ def _check_two_rank_line(d):
 	assert cpu["value"] > 0 and cpu["unit"] == "Gbases/s" and cpu["cores"] == 1 and cpu["kind"] == "port" and "rank 0" in cpu["sample"]
 	tc = d["roofline_transpose"]["cpu_baseline"]
 	assert tc["kind"] == "port" and tc["cores"] == 1 and tc["value"] > 0 and tc["bit_exact_vs_gpu_dense_form"] is True
+	assert d["parity"]["all_rows"] is True and d["parity"]["rows_checked"] == d["config"]["rows_total"]
+	_check_placement(d, 2)
 	_check_end_to_end(d, n_ranks=2)
 
 
@@ -147,3 +164,65 @@ def test_bench_four_ranks_as_typed_uneven_shards():
 	e = d["end_to_end"]
 	assert e["rows"] == 201 and len(e["per_rank_GBs"]) == 4 and e["parity"]["bit_exact"] is True and e["parity"]["rows_checked"] == 201
 	assert d["cpu_baseline"]["value"] > 0 and d["roofline_transpose"]["cpu_baseline"]["bit_exact_vs_gpu_dense_form"] is True
+
+
+# A GPU box allows at most 6 processes on its card at once, and the pytest process is one of them: five ranks is the most a test
+# started from here may put on the device.  The 8-rank plumbing of both launch forms runs without GPU work in tests/test_host_cpu.py.
+FIVE = ["--gpus", "5", "--force-device", "0", "--config", "mini3", "--steps", "2", "--warmup", "1", "--output-candidates", "1", "--batch-rows", "8", "--cpu-baseline-rows", "8"]
+
+
+def _check_five_rank_line(d, rows, rank0_has_copies=True):
+	per_rank = d["config"]["per_rank"]
+	assert d["n_gpus"] == 5 and [p["rank"] for p in per_rank] == list(range(5)) and [p["rows"] for p in per_rank] == rows
+	assert sum(rows) == d["config"]["rows_total"] and d["value"] > 0
+	assert d["parity"]["bit_exact"] is True and d["parity"]["all_rows"] is True and d["parity"]["rows_checked"] == sum(rows)
+	assert d["parity"]["batches_covered"] == sum(p["batches"] for p in per_rank)
+	assert all(p["batches"] == -(-p["rows"] // 8) and p["launches"] == 2 * p["batches"] for p in per_rank)     # --batch-rows 8: several launches per rank and step
+	assert abs(d["ms_per_step"] - max(p["ms_per_step"] for p in per_rank)) <= 1e-3
+	roof = d["roofline"]
+	assert roof["avg_launch_ms"] == max(p["avg_launch_ms"] for p in per_rank) and per_rank[roof["rank"]]["rows"] > 0
+	_check_placement(d, 5)
+	e = d["end_to_end"]
+	with_rows = sum(1 for r in rows if r)
+	assert e["rows"] == sum(rows) and len(e["per_rank_GBs"]) == with_rows and e["parity"]["bit_exact"] is True and e["parity"]["rows_checked"] == sum(rows)
+	assert d["cpu_baseline"]["value"] > 0
+	if rank0_has_copies:    # (the transpose legs are rank 0's; a rank 0 that carries REF alone has no matrix to transpose)
+		assert d["roofline_transpose"]["cpu_baseline"]["bit_exact_vs_gpu_dense_form"] is True
+
+
+def test_bench_five_ranks_as_typed():
+	"""`python bench.py --gpus 5`, all on device 0: mini3's 200 copies in blocks of 8 -> 40 per rank, REF on rank 0, launches of 8 rows."""
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + FIVE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT, env=env)
+	assert r.returncode == 0, r.stderr.decode()[-3000:]
+	lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+	assert len(lines) == 1
+	_check_five_rank_line(json.loads(lines[0]), [41, 40, 40, 40, 40])
+	assert r.stderr.decode().count("HIP device 0") == 5        # every rank logged where it landed
+
+
+def test_bench_five_ranks_under_torch_distributed_run():
+	import socket
+	with socket.socket() as sock:
+		sock.bind(("127.0.0.1", 0))
+		port = sock.getsockname()[1]
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+	r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "5", "--master-addr", "127.0.0.1", "--master-port", str(port),
+		os.path.join(ROOT, "bench.py")] + FIVE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT, env=env)
+	assert r.returncode == 0, r.stderr.decode()[-3000:]
+	lines = [l for l in r.stdout.decode().splitlines() if l.strip().startswith("{")]
+	assert len(lines) == 1
+	d = json.loads(lines[0])
+	_check_five_rank_line(d, [41, 40, 40, 40, 40])
+	assert "torch.distributed (gloo)" in d["config"]["ranks_coordinated_by"]
+
+
+def test_bench_ranks_that_own_nothing():
+	"""12 samples = 24 copies = 3 blocks of 8 over 5 ranks: rank 0 carries REF alone, rank 1 owns no row at all, ranks 2-4 eight copies each.
+	The empty rank passes every barrier, contributes zeros, and the line still adds up."""
+	env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + FIVE + ["--samples", "12"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900, cwd=ROOT, env=env)
+	assert r.returncode == 0, r.stderr.decode()[-3000:]
+	lines = [l for l in r.stdout.decode().splitlines() if l.strip()]
+	assert len(lines) == 1
+	_check_five_rank_line(json.loads(lines[0]), [1, 0, 8, 8, 8], rank0_has_copies=False)

@@ -3,7 +3,9 @@ oracle on sampled rows (the oracle needs ~0.1 s per 10 MB row; the GPU writes 20
 
 config 2: synthetic 10 Mb reference, 100k SNV-only records, 1000 diploid samples -> all 2001 rows (20 GB).
 config 3: synthetic 100 Mb reference, 1M SNV+indel records, 2504 diploid samples -> the full 5056 x 1M path-matrix
-          transpose, and a 96-row window of the splice (9.6 GB).
+          transpose; a 96-row window of the splice (9.6 GB) with padding copies; and EVERY one of the 5009 rows, aligned and
+          --unaligned, in the bench's own 64-GB batches, by device checksum against the oracle's streamed checksum of the
+          same row (502 GB per mode; ~25 s each on the box's 16 quota cores).
 config 4: the config-3 input with --founder-sequences=25 --minimum-distance=50 -> host search on 1 and 16 threads, the
           26 rows (672 495 copy switches per founder row) against the oracle's walk with the same cuts.
 config 5: synthetic 250 Mb reference, 6M records incl. MNPs / multi-allelic sites, 10000 diploid samples -> the full
@@ -13,6 +15,7 @@ config 5: synthetic 250 Mb reference, 6M records incl. MNPs / multi-allelic site
 import numpy as np
 import pytest
 
+import full_parity
 import oracle
 
 pytestmark = pytest.mark.gpu
@@ -40,12 +43,7 @@ def _device_paths(torch, v2m, ds, ctx, copy_base=0, hp=None):
 	return src, dst
 
 
-def _oracle_for(ds, copies):
-	"""Oracle graph whose path matrix holds the CPU re-derivation of the given chromosome copies (as copies 0..k-1)."""
-	g = ds.graph
-	cols = np.concatenate([ds.copy_column(c) for c in copies] + [np.zeros(ds.path_rows // 64, np.uint64)] * ((-len(copies)) % 64))
-	return oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
-		g.label_offsets, g.label_bytes, cols, ds.path_rows, 64 * ((len(copies) + 63) // 64))
+_oracle_for = full_parity.oracle_for
 
 
 def _popcount(torch, t):
@@ -177,6 +175,62 @@ def test_config3_row_window(env):
 		assert lengths.tolist() == [len(e) for e in exp]
 		usums = ctx.checksum_rows_device(uout.data_ptr(), upitch, len(urows), lengths=lengths)
 		assert np.array_equal(usums, v2m.checksum_rows_host(exp))
+
+
+@pytest.mark.parametrize("unaligned", [False, True], ids=["aligned", "unaligned"])
+def test_config3_every_row_against_the_oracle(env, unaligned):
+	"""BASELINE's headline config, all of it: REF + 5008 haplotype rows of 100.3 Mbases, spliced in the bench's batches (627 rows
+	into one 64-GB buffer), every row's length and 64-bit checksum against the oracle's walk of the same row
+	(sequence_writer.cc:22-85; --unaligned: :80).  "Bit-exact vs CPU" on the configuration the metric is quoted on is total."""
+	torch, v2m, synth = env
+	from vcf2multialign_amd.sharding import host_threads_per_rank
+	ds = synth.dataset("config3")
+	threads = host_threads_per_rank(1)
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(ds.graph, ds.reference)
+		src, dst = _device_paths(torch, v2m, ds, ctx)
+		del src
+		ctx.set_paths_device(dst.data_ptr(), ds.path_rows, ds.path_cols)
+		out_bytes = 627 * ctx.min_row_pitch
+		out_ptr = ctx.alloc_output(out_bytes, candidates=1)
+		try:
+			res = full_parity.check_all_rows(v2m, ctx, ds, out_ptr, out_bytes, unaligned=unaligned, threads=threads, say=print)
+		finally:
+			ctx.free_output(out_ptr)
+	print("config 3, %s: %d rows in %d batches of %d, GPU %.1f s, oracle %.1f s on %d threads, %d mismatches"
+		% ("--unaligned" if unaligned else "aligned", res["rows"], res["batches"], res["rows_per_batch"], res["gpu_s"], res["oracle_s"], threads, len(res["mismatches"])))
+	assert res["rows"] == 5009 and res["batches"] == (8 if not unaligned else res["batches"]) and res["rows_per_batch"] <= 627
+	assert res["mismatches"] == []
+	assert res["distinct_lengths"] == 1 if not unaligned else res["distinct_lengths"] > 1000      # unaligned rows differ in length
+
+
+def test_config5_every_row_against_the_oracle(env):
+	"""BASELINE config 5, all 20 001 rows of 252 Mbases (5.04 TB per mode) the same way.  About 5 min of oracle time per mode on 16
+	cores, so it runs only when asked for (V2M_FULL_CONFIG5=1; add "unaligned" to the value for that mode too); the builder runs it
+	once per round and records the output under profiles/rNN/."""
+	import os
+	mode = os.environ.get("V2M_FULL_CONFIG5", "")
+	if not mode:
+		pytest.skip("set V2M_FULL_CONFIG5=1 (or =unaligned, =both) to walk all 20 001 rows of config 5 on the CPU")
+	torch, v2m, synth = env
+	from vcf2multialign_amd.sharding import host_threads_per_rank
+	ds = synth.dataset("config5")
+	threads = host_threads_per_rank(1)
+	with v2m.Context(0) as ctx:
+		ctx.upload_graph(ds.graph, ds.reference)
+		src, dst = _device_paths(torch, v2m, ds, ctx)
+		del src
+		ctx.set_paths_device(dst.data_ptr(), ds.path_rows, ds.path_cols)
+		out_bytes = 253 * ctx.min_row_pitch
+		out_ptr = ctx.alloc_output(out_bytes, candidates=1)
+		try:
+			for unaligned in ([False] if mode == "1" else [True] if mode == "unaligned" else [False, True]):
+				res = full_parity.check_all_rows(v2m, ctx, ds, out_ptr, out_bytes, unaligned=unaligned, threads=threads, say=print)
+				print("config 5, %s: %d rows in %d batches of %d, GPU %.1f s, oracle %.1f s on %d threads, %d mismatches"
+					% ("--unaligned" if unaligned else "aligned", res["rows"], res["batches"], res["rows_per_batch"], res["gpu_s"], res["oracle_s"], threads, len(res["mismatches"])))
+				assert res["rows"] == 20001 and res["mismatches"] == []
+		finally:
+			ctx.free_output(out_ptr)
 
 
 @pytest.mark.parametrize("config", ["mini5", "mini3"])

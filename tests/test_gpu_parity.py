@@ -531,6 +531,42 @@ def test_precondition_errors(v2m, ctx, tmp_path):
 	assert ctx.splice_rows([0]) == _oracle_rows(g, [0])
 
 
+def test_nul_bytes_are_kept_in_aligned_mode_and_refused_in_unaligned_mode(v2m, ctx, tmp_path):
+	"""Bytes are opaque to the walk: the reference streams whatever the FASTA / the VCF's ALT column held (sequence_writer.cc:73-74).
+	Aligned mode keeps a NUL byte of the reference sequence or of a label; the unaligned kernels mark padding with byte 0, so that mode
+	refuses such a graph (V2M_ERR_UNSUPPORTED) instead of writing rows that lack the byte."""
+	g = synth.build_case(tmp_path, 43, 30000, 300, 3, mix=(0.5, 0.4, 0.1))
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies))
+	# (1) in the reference sequence
+	ref = bytearray(g.ref)
+	for p in (0, 1234, 16384, len(ref) - 1):
+		ref[p] = 0
+	ref = bytes(ref)
+	vg = v2m.VariantGraph.from_object(g)
+	ctx.upload_graph(vg, ref)
+	want = [g.output_sequence(ref, copy_index=r) for r in rows]
+	assert want[0].count(b"\0") == 4 and ctx.splice_rows(rows) == want
+	with pytest.raises(v2m.V2MError) as e:
+		ctx.splice_rows(rows, unaligned=True)
+	assert e.value.code == 3 and "NUL" in str(e.value)
+	# (2) in an ALT label (the first byte of every fifth label)
+	lb = bytearray(g.label_bytes)
+	for o in g.label_offsets[:-1][::5]:
+		if int(o) < len(lb):
+			lb[int(o)] = 0
+	g2 = oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
+		g.label_offsets, bytes(lb), g.paths_by_chrom_copy_and_edge, g.path_rows, g.path_cols, g.sample_names, g.ploidy_csum)
+	ctx.upload_graph(v2m.VariantGraph.from_object(g2), g.ref)
+	want = [g2.output_sequence(g.ref, copy_index=r) for r in rows]
+	assert b"\0" not in want[0] and any(b"\0" in w for w in want[1:]) and ctx.splice_rows(rows) == want
+	with pytest.raises(v2m.V2MError) as e:
+		ctx.splice_rows(rows, unaligned=True)
+	assert e.value.code == 3
+	# the same context takes a graph without such a byte in both modes afterwards
+	ctx.upload_graph(vg, g.ref)
+	assert ctx.splice_rows(rows, unaligned=True) == [g.output_sequence(g.ref, copy_index=r, unaligned=True) for r in rows]
+
+
 # ---- --unaligned: chunks with padding ------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("mode", ["", "plain"])

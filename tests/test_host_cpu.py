@@ -114,24 +114,24 @@ def _free_port():
 
 
 def _gloo_worker(rank, world, port, n_copies, q):
-	import torch.distributed as dist
-	from vcf2multialign_amd.sharding import local_rows, max_over_ranks
-	os.environ["MASTER_ADDR"] = "127.0.0.1"
-	os.environ["MASTER_PORT"] = str(port)
-	dist.init_process_group("gloo", rank=rank, world_size=world)
+	"""What a rank of bench.py does with the others under torch.distributed.run, through bench.py's own TorchHub: a barrier, one
+	gather of figures, the maximum taken on rank 0.  No row and no tensor travels."""
+	import sys
+	sys.path.insert(0, ROOT)
+	import bench
+	from vcf2multialign_amd.sharding import local_rows
+	os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+	hub = bench.TorchHub("gloo", rank, None)
 	rows = local_rows(n_copies, world, rank)
-	dist.barrier()
-	t = max_over_ranks(1.0 + rank, dist)     # the bench's max-over-ranks timing
-	gathered = [None] * world
-	dist.all_gather_object(gathered, [gi for gi, _ in rows])   # test-only: the data path itself has no collective
-	dist.barrier()
-	dist.destroy_process_group()
-	q.put((rank, t, gathered))
+	hub.barrier()
+	everyone = hub.gather({"rank": rank, "elapsed_s": 1.0 + rank, "rows": [gi for gi, _ in rows]})
+	hub.close()
+	q.put((rank, everyone))
 
 
 def test_two_rank_gloo_partition():
-	"""world_size-2 rehearsal of the N>1 path on CPU: both ranks derive disjoint, ordered shards and agree on the
-	max-over-ranks time."""
+	"""world_size-2 rehearsal of the N>1 path on CPU: both ranks derive disjoint, ordered shards, and rank 0 ends up with every
+	rank's figures (the max-over-ranks time is taken from them, as bench.py does)."""
 	import torch.multiprocessing as mp
 	ctx = mp.get_context("spawn")
 	q = ctx.Queue()
@@ -139,14 +139,27 @@ def test_two_rank_gloo_partition():
 	procs = [ctx.Process(target=_gloo_worker, args=(r, 2, port, 300, q)) for r in range(2)]
 	for p in procs:
 		p.start()
-	results = [q.get(timeout=120) for _ in procs]
+	results = dict(q.get(timeout=120) for _ in procs)
 	for p in procs:
 		p.join(timeout=60)
 		assert p.exitcode == 0
-	for rank, t, gathered in results:
-		assert t == 2.0
-		assert gathered[0] + gathered[1] == list(range(301))
-		assert gathered[0][-1] == 152 and gathered[1][0] == 153   # rank 0: REF + copies 0..151 (19 bytes of every column), rank 1: copies 152..299
+	assert results[1] is None                                     # only rank 0 holds the gathered figures
+	everyone = results[0]
+	assert [f["rank"] for f in everyone] == [0, 1] and max(f["elapsed_s"] for f in everyone) == 2.0
+	assert everyone[0]["rows"] + everyone[1]["rows"] == list(range(301))
+	assert everyone[0]["rows"][-1] == 152 and everyone[1]["rows"][0] == 153   # rank 0: REF + copies 0..151 (19 bytes of every column), rank 1: copies 152..299
+
+
+def test_cpu_quota_and_threads_per_rank(tmp_path, monkeypatch):
+	"""The host side of a rank is sized from the job's quota (affinity mask, cgroup cpu.max) divided by the node's ranks."""
+	from vcf2multialign_amd import sharding
+	cores, source = sharding.cpu_quota()
+	assert 1 <= cores <= (os.cpu_count() or 1) and source
+	assert sharding.host_threads_per_rank(1, cap=4) <= 4
+	assert sharding.host_threads_per_rank(10 ** 6) == 1
+	monkeypatch.setattr(sharding, "cpu_quota", lambda: (16, "test"))
+	assert [sharding.host_threads_per_rank(n) for n in (1, 2, 4, 8, 16, 32)] == [16, 8, 4, 2, 1, 1]
+	assert sharding.host_threads_per_rank(1, cap=12) == 12 and sharding.host_threads_per_rank(2, reserve=4) == 6
 
 
 def test_header_is_plain_c_and_the_c_example_links(tmp_path):
@@ -237,6 +250,43 @@ def test_every_quoted_include_is_a_build_dependency_and_a_stamped_kernel_source(
 		for fn in files:
 			if fn.endswith((".hpp", ".hh", ".h")):
 				assert os.path.join(dirpath, fn) in every, fn + " is included by nothing that is built"
+
+
+def test_nothing_is_compiled_under_a_profiler(tmp_path, monkeypatch):
+	"""A stale library in a process that runs under rocprofv3's preload is an error, not a compile: a compiler launcher started there
+	would exec with the GPU already initialised by the preload (the hop that takes a node of the pool down)."""
+	from vcf2multialign_amd import build
+	assert not build.under_profiler()
+	monkeypatch.setenv("LD_PRELOAD", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+	assert build.under_profiler()
+	with pytest.raises(build.StaleUnderProfiler):
+		build._build(str(tmp_path / "missing.so"), build.HIP_SOURCES, build.HIP_DEPS, False, False)     # missing target: would have to compile
+	build.build_native()                                                                                  # everything fresh: a no-op, no error
+	monkeypatch.delenv("LD_PRELOAD")
+	monkeypatch.setenv("ROCPROFILER_SOMETHING", "1")
+	assert build.under_profiler()
+	import oracle
+	monkeypatch.setattr(oracle, "_LIB_PATH", str(tmp_path / "no_such_oracle.so"))
+	with pytest.raises(RuntimeError):
+		oracle.build_oracle()
+
+
+def test_an_unresolved_include_makes_its_target_stale_and_nothing_else(tmp_path):
+	from vcf2multialign_amd import build
+	src = tmp_path / "a.cc"
+	src.write_text('#include "there.hh"\n#if 0\n#include "not_there.hh"\n#endif\n')
+	(tmp_path / "there.hh").write_text("// ok")
+	closure = build.include_closure([str(src)])
+	missing = [d for d in closure if isinstance(d, build.MissingInclude)]
+	assert len(closure) == 3 and len(missing) == 1 and missing[0].endswith("not_there.hh")
+	lib = tmp_path / "a.so"
+	lib.write_bytes(b"")
+	assert build._stale(str(lib), closure) and not build._stale(str(lib), [d for d in closure if d not in missing])
+	with pytest.raises(RuntimeError):
+		build.include_closure([str(src)], strict=True)
+	# the tree itself has none: every quoted include of every target resolves
+	for name, sources in build._SOURCES_OF.items():
+		assert build.include_closure(sources, strict=True) == getattr(build, name)
 
 
 def test_a_stale_library_is_noticed_through_any_header(tmp_path):

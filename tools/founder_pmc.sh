@@ -3,6 +3,10 @@
 # separate --pmc passes, the SQ counters that say what bounds them.  Output under gpurun_out/founder_pmc/ (summary: summary.txt).
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+# Build BEFORE the first profiler line, with no profiler around: under rocprofv3 (--pmc above all) the preload has initialised the GPU before
+# python starts, and a compiler launcher started from there would be the exec-after-GPU-init hop this pool forbids.  bench.py / build.py / the
+# oracle binding refuse to compile when they find themselves stale under a profiler, so a missed build ends in a message, not in a compile.
+python3 -c 'import __graft_entry__ as g; g.build()' > /dev/null
 OUT=gpurun_out/founder_pmc
 rm -rf $OUT; mkdir -p $OUT
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- python3 tools/founder_kernels_bench.py config3 2 > $OUT/run.txt 2> $OUT/run.err || { tail -5 $OUT/run.err; exit 1; }

@@ -10,6 +10,10 @@
 # Run on the GPU box from the repository root; copy the files into profiles/rNN/ (and pmc_traffic.json into profiles/) afterwards.
 set -e -o pipefail
 cd /tmp && export TMPDIR=/tmp && cd "${GRAFT_REPO_ROOT:-/root/repo}"
+# Build BEFORE the first profiler line, with no profiler around: under rocprofv3 (--pmc above all) the preload has initialised the GPU before
+# python starts, and a compiler launcher started from there would be the exec-after-GPU-init hop this pool forbids.  bench.py / build.py / the
+# oracle binding refuse to compile when they find themselves stale under a profiler, so a missed build ends in a message, not in a compile.
+python3 -c 'import __graft_entry__ as g; g.build()' > /dev/null
 OUT=gpurun_out/refresh
 mkdir -p $OUT
 # the counter passes run with the store flavour fixed, so that every splice launch they see is one of the step's own

@@ -88,6 +88,7 @@ struct v2m_ctx {
 	// graph
 	bool has_graph{};
 	u64 n_nodes{}, n_edges{}, ref_len{}, aligned_len{}, label_bytes{};
+	bool has_nul_byte{};                // ref_seq or a label holds a 0 byte: the unaligned kernels' padding marker (kernels.hpp), so --unaligned refuses
 	u32 n_tiles{};
 	std::vector<u32> h_csum;            // alt_edge_count_csum narrowed, [N + 1]
 	std::vector<u32> h_tgt_prefix_max;  // [E + 1]: max target over edges < e (cut validation)
@@ -876,6 +877,8 @@ int check_batch(v2m_ctx *ctx, v2m_row_batch const *rows, u32 flags)
 	if (rows->cut_offsets && rows->cut_offsets[rows->n_rows] && (!rows->cut_nodes || !rows->cut_copies))
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut arrays are NULL");
 	if (rows->n_rows >= 0xFFFFFFFFull) return fail(ctx, V2M_ERR_UNSUPPORTED, "too many rows in one batch");
+	if ((flags & V2M_SPLICE_UNALIGNED) && ctx->has_nul_byte)
+		return fail(ctx, V2M_ERR_UNSUPPORTED, "the reference sequence or an ALT label holds a NUL byte, which the unaligned kernels use as their padding marker; aligned mode keeps such bytes");
 	return V2M_OK;
 }
 
@@ -1180,6 +1183,9 @@ int v2m_upload_graph(v2m_ctx *ctx, const v2m_graph_view *g, const char *ref_seq,
 	V2M_HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 
 	ctx->n_nodes = N; ctx->n_edges = E; ctx->ref_len = ref_len; ctx->aligned_len = L; ctx->label_bytes = label_total;
+	// The reference streams whatever bytes the FASTA / VCF held (sequence_writer.cc:73-74).  Aligned mode does the same here; the
+	// unaligned kernels mark padding with byte 0, so a graph that holds one is refused there (check_batch) instead of losing it.
+	ctx->has_nul_byte = (ref_len && std::memchr(ref_seq, 0, ref_len)) || (label_total && std::memchr(g->alt_edge_label_bytes, 0, label_total));
 	ctx->n_tiles = n_tiles;
 	ctx->h_csum = std::move(csum);
 	ctx->h_tgt_prefix_max = std::move(tgt_prefix_max);

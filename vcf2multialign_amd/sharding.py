@@ -2,8 +2,14 @@
 bytes of the bit-packed path matrix (8 copies: a rank's slice of paths_by_edge_and_chrom_copy is then a strided 2-D
 byte copy, bytes [c0/8, c1/8) of every column, zero-padded to a multiple of 64 rows for the transpose), graph and
 reference are replicated, rows stay in file order when the ranks' outputs are concatenated.  No collective is needed on the data path
-(rows are independent, haplotype_output.cc:62-81); torch.distributed is used only for barriers and for the
-max-over-ranks of timings."""
+(rows are independent, haplotype_output.cc:62-81).  What ranks exchange is figures, never rows: bench.py's hub (its parent
+process over pipes, or a gloo group under torch.distributed.run) serves a barrier and one gather, and rank 0 takes the
+maximum of the gathered times.
+
+cpu_quota() / host_threads_per_rank(): the host side of a rank (sink threads, checker threads) is sized from what the job
+may use -- the cgroup's cpu.max and the affinity mask, not os.cpu_count() -- divided among the ranks of the node."""
+
+import os
 
 PLOIDY_MAX = 0xFFFFFFFF
 
@@ -35,11 +41,32 @@ def local_rows(n_copies, world, rank, include_reference=True):
 	return rows
 
 
-def max_over_ranks(value, dist=None, device=None):
-	"""MAX all-reduce of a python float (identity without an initialised process group)."""
-	if dist is None or not dist.is_available() or not dist.is_initialized():
-		return value
-	import torch
-	t = torch.tensor([value], dtype=torch.float64, device=device)
-	dist.all_reduce(t, op=dist.ReduceOp.MAX)
-	return float(t.item())
+def cpu_quota():
+	"""Cores' worth of CPU time this process may use: the smaller of its affinity mask and its cgroup's cpu.max quota
+	(v2: /sys/fs/cgroup/cpu.max "limit period"; v1: cpu.cfs_quota_us / cpu.cfs_period_us).  A GPU box of the pool gives a
+	1-GPU job 16 cores' worth on a 256-thread host, and a process that runs more busy threads than that is throttled as a
+	whole (profiles/r04/cpu_quota_and_sink_rates.txt).  Returns (cores, where the figure comes from)."""
+	try:
+		cores, source = len(os.sched_getaffinity(0)), "affinity mask"
+	except (AttributeError, OSError):
+		cores, source = os.cpu_count() or 1, "os.cpu_count()"
+	for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: t.split()),
+			("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+		try:
+			with open(path) as f:
+				limit, period = parse(f.read())
+			if limit not in ("max", "-1") and int(period) > 0:
+				q = max(1, int(limit) // int(period))
+				if q < cores:
+					cores, source = q, path
+			break
+		except (OSError, ValueError):
+			continue
+	return max(1, cores), source
+
+
+def host_threads_per_rank(local_world=1, cap=16, reserve=0):
+	"""Busy host threads one rank may run when `local_world` ranks share the node's quota: (quota - reserve) / local_world,
+	at least 1 and at most `cap`."""
+	cores, _ = cpu_quota()
+	return max(1, min(cap, (cores - reserve) // max(1, local_world)))
