@@ -466,7 +466,7 @@ def main():
 		n_cols = 64 * ((len(copies) + 63) // 64)
 		cols = [ds.copy_column(c) for c in copies] + [np.zeros(Ep // 64, np.uint64)] * (n_cols - len(copies))
 		return oracle.graph_from_arrays(g.reference_positions, g.aligned_positions, g.alt_edge_targets, g.alt_edge_count_csum,
-			g.label_offsets, g.label_bytes, np.concatenate(cols) if Ep else np.zeros(0, np.uint64), Ep, n_cols,
+			g.label_offsets, g.label_bytes, np.concatenate(cols) if (Ep and cols) else np.zeros(0, np.uint64), Ep, n_cols,
 			["S%d" % i for i in range(n_cols // ds.ploidy)], np.arange(n_cols // ds.ploidy + 1, dtype=np.uint32) * ds.ploidy)
 
 	mine["parity_ok"], mine["parity_checked"], mine["parity_all_rows"] = True, 0, args.verify_rows < 0   # (a rank that owns no row has checked all of them)

@@ -60,7 +60,12 @@ __attribute__((target("avx512f,avx512dq"))) uint64_t sum_words_avx512(char const
 		acc = _mm512_add_epi64(acc, z);
 		index_term = _mm512_add_epi64(index_term, step);
 	}
-	return (uint64_t) _mm512_reduce_add_epi64(acc) + sum_words_scalar(bytes, k, k1);
+	// (lanes added as unsigned words: _mm512_reduce_add_epi64 adds them as signed long long, which is an overflow UBSan reports)
+	alignas(64) uint64_t lanes[8];
+	_mm512_store_si512(lanes, acc);
+	uint64_t total(sum_words_scalar(bytes, k, k1));
+	for (uint64_t lane : lanes) total += lane;
+	return total;
 }
 
 sum_words_fn pick_sum_words()
