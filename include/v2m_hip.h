@@ -32,7 +32,8 @@
  *
  * V2M_ABI_VERSION: 1 = round 1 (transpose, graph, rows); 2 = + v2m_upload_path_slice, v2m_alloc_output / v2m_free_output,
  * v2m_profile_get_launches (v2m_bind_path_matrix_device followed without a step); 3 = + v2m_upload_path_blocks (and then
- * v2m_pbwt_cut_trials, v2m_pbwt_cut_records); 4 = + v2m_pbwt_cut_trials_streamed.  Entries have only ever been added.
+ * v2m_pbwt_cut_trials, v2m_pbwt_cut_records); 4 = + v2m_pbwt_cut_trials_streamed; 5 = + v2m_splice_rows_held / v2m_row_release (rows a
+ * sink may keep until it says so).  Entries have only ever been added.
  *
  * Conventions
  *   - Plain C: pointers + sizes, no exceptions, no C++/torch types.  Every function that can
@@ -55,7 +56,7 @@
 extern "C" {
 #endif
 
-#define V2M_ABI_VERSION 4
+#define V2M_ABI_VERSION 5
 
 enum {
 	V2M_OK = 0,
@@ -217,6 +218,21 @@ typedef int (*v2m_sink_fn)(void *user, uint64_t row_index, const char *bytes, ui
  * Works through the batch in device-sized slices, overlapping the D2H copy of one slice with
  * the kernels of the next.  Synchronous. */
 int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m_sink_fn sink, void *user);
+
+/* The same rows for a sink that does not finish with a row inside the call -- one that queues it for a pool of writer threads
+ * (output.cc:47-76 with more than one thread behind the file descriptor: a file per sequence, haplotype_output.cc:85-132, scales
+ * with writers where one writer on one stream does not).  `bytes` stays valid, in a pinned slot of the library's, until the sink
+ * calls v2m_row_release(hold) -- once per accepted row, from any thread, during or after the sink call.  Rows still arrive in batch
+ * order on the calling thread, and the call goes on launching slices and copies meanwhile; a slot is copied into again only when
+ * every row of it has been released.  n_slots (2 ... 64) pinned slots of the slice size v2m_splice_rows uses (512 MB for batches
+ * of 8 GB and more, else 128 MB) are allocated on first use and kept by the ctx: rows in writers' hands + rows crossing the link
+ * + rows being delivered all need a slot, so n_slots = writers' rows / rows per slot + 2 is the least that keeps the link busy.
+ * A sink that returns non-zero has NOT accepted that row (it must not release it) and ends the call with V2M_ERR_SINK.
+ * The call returns only when every accepted row has been released, also after an error.  Synchronous. */
+typedef struct v2m_row_hold v2m_row_hold;
+typedef int (*v2m_hold_sink_fn)(void *user, uint64_t row_index, const char *bytes, uint64_t length, v2m_row_hold *hold);
+int v2m_splice_rows_held(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, uint32_t n_slots, v2m_hold_sink_fn sink, void *user);
+void v2m_row_release(v2m_row_hold *hold);
 
 /* Device-resident form: row i is written to d_out + i * row_pitch and stays in HBM.
  * Aligned mode: every row has v2m_aligned_length() bytes; row_pitch a multiple of 16 and >= the aligned length

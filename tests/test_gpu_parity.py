@@ -732,3 +732,78 @@ def test_output_buffer_allocate_free_allocate(ctx, v2m, tmp_path):
 			assert rt.hipMemcpy(buf, out + r * pitch, L, 2) == 0
 			assert buf.raw == expected[rows[r]], r
 		ctx.free_output(out)
+
+
+# ---- v2m_splice_rows_held: rows a sink may keep (ABI 5) -----------------------------------------------------------------------------
+
+@pytest.mark.parametrize("unaligned", [False, True])
+def test_held_rows_stay_valid_until_released(ctx, v2m, tmp_path, monkeypatch, unaligned):
+	"""The sink returns at once and a pool of threads reads the rows later, releasing each when done: every row's bytes are still the
+	oracle's when its reader gets to it, although the call has gone on through many more slices meanwhile (small slots: a few rows
+	each, so slots are reused dozens of times)."""
+	import ctypes as C
+	import queue
+	import threading
+	import time
+	g = synth.build_case(tmp_path, 97, 40000, 500, 40, mix=(0.6, 0.25, 0.15))          # 80 copies
+	_upload(v2m, ctx, g)
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies))
+	want = _oracle_rows(g, rows, unaligned=unaligned)
+	monkeypatch.setenv("V2M_RING_SLOT_BYTES", str(3 * ((ctx.max_unaligned_length + 255) // 256 * 256) + 8))   # three rows per slot
+	for n_slots, n_readers in ((2, 1), (3, 4), (8, 3)):
+		got, todo = {}, queue.Queue()
+
+		def reader():
+			for row, ptr, length, hold in iter(todo.get, None):
+				time.sleep(0.0005 * (row % 3))                                            # let the pipeline run ahead of the readers
+				got[row] = C.string_at(ptr, length) if length else b""
+				ctx.release_row(hold)
+
+		readers = [threading.Thread(target=reader) for _ in range(n_readers)]
+		for t in readers:
+			t.start()
+		try:
+			ctx.splice_rows_held(rows, lambda row, ptr, length, hold: todo.put((row, ptr, length, hold)), n_slots=n_slots, unaligned=unaligned)
+		finally:
+			for _ in readers:
+				todo.put(None)
+			for t in readers:
+				t.join()
+		assert [got[r] for r in range(len(rows))] == want, (n_slots, n_readers)      # (the call returned: every row had been released)
+
+
+def test_held_rows_refusals_and_errors(ctx, v2m, tmp_path, monkeypatch):
+	g = synth.build_case(tmp_path, 98, 20000, 200, 10)
+	_upload(v2m, ctx, g)
+	rows = [v2m.PLOIDY_MAX] + list(range(g.total_chromosome_copies))
+	monkeypatch.setenv("V2M_RING_SLOT_BYTES", str(2 * ((ctx.aligned_length + 255) // 256 * 256) + 8))
+	seen = []
+
+	def refuse_the_seventh(row, ptr, length, hold):
+		if row == 7:
+			return True                                                                  # not accepted: must not be released
+		seen.append(row)
+		ctx.release_row(hold)
+
+	with pytest.raises(v2m.V2MError) as e:
+		ctx.splice_rows_held(rows, refuse_the_seventh, n_slots=3)
+	assert e.value.code == 7 and seen == list(range(7))
+	with pytest.raises(v2m.V2MError) as e:                                               # fewer than two slots cannot overlap anything
+		ctx.splice_rows_held(rows, lambda *a: None, n_slots=1)
+	assert e.value.code == 1
+	class Boom(Exception):
+		pass
+	def raises(row, ptr, length, hold):
+		raise Boom()
+	with pytest.raises(Boom):
+		ctx.splice_rows_held(rows, raises, n_slots=2)
+	# the context is still good for the plain form and for another held call
+	assert ctx.splice_rows(rows) == _oracle_rows(g, rows)
+	out = {}
+	def keep(row, ptr, length, hold):
+		import ctypes as C
+		out[row] = C.string_at(ptr, length)
+		ctx.release_row(hold)
+	ctx.splice_rows_held(rows, keep, n_slots=2)
+	assert [out[r] for r in range(len(rows))] == _oracle_rows(g, rows)
+	ctx.splice_rows_held([], keep, n_slots=2)                                            # no row: nothing happens

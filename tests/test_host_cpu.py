@@ -37,7 +37,7 @@ def test_library_exports_every_declared_symbol(v2m):
 	for name in declared:
 		assert hasattr(lib, name), name + " is declared in include/v2m_hip.h but not exported"
 	assert set(declared) == set(_native.SIGNATURES), "ctypes signatures and header disagree"
-	assert lib.v2m_abi_version() == 4
+	assert lib.v2m_abi_version() == 5
 
 
 def test_no_device_means_loud_failure(v2m):

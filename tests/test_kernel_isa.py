@@ -80,3 +80,16 @@ def test_no_scratch_and_no_mfma(isa):
 	assert len(sizes) >= 16 and len(sizes) == len(isa) - 1
 	assert [n for n, size in sizes if int(size) != 0] == []
 	assert "v_mfma" not in text
+
+
+def test_m0_is_touched_only_by_the_gather_of_the_unaligned_kernel(isa):
+	"""splice_unaligned_kernel moves short chunks' descriptors with v_writelane_b32 ..., m0 from inline assembly (clang has no builtin, and a
+	gfx9 VALU instruction may read one SGPR only); the compiler does not track M0 across that, so nothing else may depend on it."""
+	for name, lines in isa.items():
+		if name == "__text__":
+			continue
+		uses = [l.strip() for l in lines if re.search(r"\bm0\b", l.split(";")[0])]
+		if "splice_unaligned_kernel" in name:
+			assert uses and all(u.startswith(("s_mov_b32 m0,", "v_writelane_b32")) for u in uses), uses[:5]
+		else:
+			assert not uses, (name, uses[:3])

@@ -2,9 +2,9 @@
 // outputs, the unordered per-context writers of --output-sequences-separate, --pipe) and for the worker pool of the bench's
 // checksumming sink (csrc/synth/sink.cc).
 //
-// output.cc reaches the GPU through three entry points of include/v2m_hip.h -- v2m_splice_rows, v2m_aligned_length,
-// v2m_last_error (gpu_context::check) -- and through gpu_context's constructor / destructor.  This file is a CPU-only MOCK of
-// exactly those: a "context" synthesises its rows on the calling thread, a few rows per slice, in a heap buffer that is freed as
+// output.cc reaches the GPU through five entry points of include/v2m_hip.h -- v2m_splice_rows, v2m_splice_rows_held +
+// v2m_row_release (rows a pool of writers keeps for a while), v2m_aligned_length, v2m_last_error (gpu_context::check) -- and
+// through gpu_context's constructor / destructor.  This file is a CPU-only MOCK of exactly those: a "context" synthesises its rows on the calling thread, a few rows per slice, in a heap buffer that is freed as
 // soon as the slice's sink calls have returned (a sink that kept a pointer is a use-after-free under ASan, as it would be a stale
 // pinned slot in the library), with slice sizes that do not divide the contexts' blocks, so turns change in the middle of slices.
 // Nothing here is product code and nothing of it is linked into the product.
@@ -16,7 +16,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
 #include <sstream>
 #include <streambuf>
 #include <thread>
@@ -76,6 +78,66 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 		}
 	}
 	return V2M_OK;
+}
+}
+
+// The held form: n_slots heap "pinned slots" in a ring; a slot is freed (so that a writer still reading it is a use-after-free under ASan)
+// and refilled only when every accepted row of it has been released -- by whatever thread, which is what TSan watches.
+struct v2m_row_hold {
+	std::mutex *mutex; std::condition_variable *released;
+	u64 outstanding{};
+	char *bytes{};
+};
+
+extern "C" {
+void v2m_row_release(v2m_row_hold *hold)
+{
+	bool last;
+	{ std::lock_guard<std::mutex> const lock(*hold->mutex); last = 0 == --hold->outstanding; }
+	if (last) hold->released->notify_all();
+}
+
+int v2m_splice_rows_held(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, uint32_t n_slots, v2m_hold_sink_fn sink, void *user)
+{
+	bool const unaligned(flags & V2M_SPLICE_UNALIGNED);
+	u64 const pitch(ctx->aligned_len + 16);
+	std::mutex mutex;
+	std::condition_variable released;
+	std::vector<v2m_row_hold> slots(n_slots);
+	for (auto &s : slots) { s.mutex = &mutex; s.released = &released; }
+	auto const wait_free([&](v2m_row_hold &s) {
+		std::unique_lock<std::mutex> lock(mutex);
+		released.wait(lock, [&] { return 0 == s.outstanding; });
+		delete[] s.bytes;
+		s.bytes = nullptr;
+	});
+	int rc(V2M_OK);
+	for (u64 r0(0), slice(0); r0 < rows->n_rows && V2M_OK == rc; r0 += ctx->slice_rows, ++slice) {
+		u64 const n(std::min<u64>(ctx->slice_rows, rows->n_rows - r0));
+		auto &slot(slots[slice % n_slots]);
+		wait_free(slot);
+		slot.bytes = new char[n * pitch];
+		std::vector<u64> lengths(n);
+		for (u64 i(0); i < n; ++i) {
+			u32 const local(rows->copy_index[r0 + i]);
+			u32 const copy(V2M_PLOIDY_MAX == local ? local : ctx->to_global ? ctx->to_global(local) : local);
+			std::string const body(row_body(*ctx, copy, unaligned));
+			std::memcpy(slot.bytes + i * pitch, body.data(), body.size());
+			lengths[i] = body.size();
+		}
+		{ std::lock_guard<std::mutex> const lock(mutex); slot.outstanding = n; }
+		for (u64 i(0); i < n; ++i) {
+			bool const fail(ctx->fail_after_rows >= 0 && long(r0 + i) >= ctx->fail_after_rows);
+			if (ctx->delay_us) std::this_thread::sleep_for(std::chrono::microseconds(ctx->delay_us));
+			if (!fail && 0 == sink(user, r0 + i, slot.bytes + i * pitch, lengths[i], &slot)) continue;
+			{ std::lock_guard<std::mutex> const lock(mutex); slot.outstanding -= n - i; }
+			ctx->err = fail ? "mock: device lost" : "sink callback failed";
+			rc = fail ? V2M_ERR_HIP : V2M_ERR_SINK;
+			break;
+		}
+	}
+	for (auto &s : slots) wait_free(s);                              // no row in a writer's hands when the call returns
+	return rc;
 }
 }
 
@@ -279,12 +341,14 @@ int main(int argc, char **argv)
 		}
 	}
 
-	// (C) a file per sequence, every context's thread writing its own as they come (unordered)
-	{
-		rig r(3, L);
+	// (C) a file per sequence: the rows stay in the contexts' slots while a pool of writers (1, 3 and 8 threads) writes them out
+	for (unsigned writers : {1u, 3u, 8u}) for (std::size_t n_ctx : {1u, 3u}) {
+		::setenv("V2M_WRITER_THREADS", std::to_string(writers).c_str(), 1);
+		::setenv("V2M_HELD_SLOTS", writers == 3 ? "2" : "5", 1);
+		rig r(n_ctx, L);
 		haplotype_output out(*r.gpus[0], nullptr, nullptr, true, false, counted);
 		r.attach(out);
-		r.interleave(out);
+		if (n_ctx > 1) r.interleave(out);
 		std::string const sub(dir + "/separate");
 		::mkdir(sub.c_str(), 0755);
 		char cwd[4096];
@@ -297,7 +361,8 @@ int main(int argc, char **argv)
 				std::string const name("S" + std::to_string(s) + "." + std::to_string(1 + k) + ".a2m");
 				all = all && slurp(name) == ">" + name + "\n" + row_body(r.ctx[0], 2 * s + k, false);
 			}
-		expect(all, "separate: every sequence's file, written from three threads");
+		expect(all, "separate: every sequence's file, written by the pool");
+		for (u32 q(0); q < samples; ++q) for (u32 k(0); k < 2; ++k) ::unlink(("S" + std::to_string(q) + "." + std::to_string(1 + k) + ".a2m").c_str());
 		expect(0 == ::chdir(cwd), "chdir back");
 	}
 

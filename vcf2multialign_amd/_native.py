@@ -23,7 +23,7 @@ V2M_SPLICE_UNALIGNED = 0x1
 
 KERNEL_TRANSPOSE, KERNEL_RESOLVE, KERNEL_SPLICE_ALIGNED, KERNEL_SPLICE_UNALIGNED, KERNEL_TEMPLATE, KERNEL_UNALIGNED_COUNT = range(6)
 KERNEL_NAMES = ["transpose_bits_kernel", "resolve_effective_edges_kernel", "splice_aligned_kernel", "splice_unaligned_kernel", "expand_reference_row_kernel", "count_unaligned_kernel"]
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GraphView(C.Structure):
@@ -44,6 +44,7 @@ class RowBatchStruct(C.Structure):
 
 
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64)
+HOLD_SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p)   # v2m_hold_sink_fn
 TRIALS_SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64)   # v2m_trials_sink
 
 # every symbol include/v2m_hip.h declares: (restype, argtypes)
@@ -66,6 +67,8 @@ SIGNATURES = {
 	"v2m_min_row_pitch": (C.c_uint64, [C.c_void_p]),
 	"v2m_max_unaligned_length": (C.c_uint64, [C.c_void_p]),
 	"v2m_splice_rows": (C.c_int, [C.c_void_p, C.POINTER(RowBatchStruct), C.c_uint32, SINK_FN, C.c_void_p]),
+	"v2m_splice_rows_held": (C.c_int, [C.c_void_p, C.POINTER(RowBatchStruct), C.c_uint32, C.c_uint32, HOLD_SINK_FN, C.c_void_p]),
+	"v2m_row_release": (None, [C.c_void_p]),
 	"v2m_splice_rows_device": (C.c_int, [C.c_void_p, C.POINTER(RowBatchStruct), C.c_uint32, C.c_void_p, C.c_uint64, C.c_void_p]),
 	"v2m_pbwt_cut_trials": (C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p,
 		C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

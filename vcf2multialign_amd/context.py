@@ -183,6 +183,30 @@ class Context:
 		self._check(rc)
 		return collected if sink is None else None
 
+	def splice_rows_held(self, rows, on_row, n_slots=4, unaligned=False):
+		"""v2m_splice_rows_held: on_row(row_index, address, length, hold) is called per row in order on this thread and may return
+		before it is done with the row; the bytes at `address` stay valid until release_row(hold) is called (any thread, once per
+		accepted row).  A callback that raises, or returns a true value, refuses the row and ends the call."""
+		if not isinstance(rows, RowBatch):
+			rows = RowBatch(rows)
+		error = []
+
+		def _cb(_user, row_index, ptr, length, hold):
+			try:
+				return 1 if on_row(row_index, ptr, length, hold) else 0
+			except BaseException as e:
+				error.append(e)
+				return 1
+
+		cb = N.HOLD_SINK_FN(_cb)
+		rc = self._lib.v2m_splice_rows_held(self._h, C.byref(rows.struct), N.V2M_SPLICE_UNALIGNED if unaligned else 0, n_slots, cb, None)
+		if error:
+			raise error[0]
+		self._check(rc)
+
+	def release_row(self, hold):
+		self._lib.v2m_row_release(hold)
+
 	def splice_rows_device(self, rows, d_out, row_pitch, unaligned=False, want_lengths=False):
 		if not isinstance(rows, RowBatch):
 			rows = RowBatch(rows)

@@ -12,6 +12,7 @@
 #include <cerrno>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <exception>
 #include <mutex>
 #include <fstream>
@@ -179,21 +180,12 @@ namespace {
 		std::vector<std::uint64_t> const *global_row;   // of each row of this context's batch
 		v2m_sink_fn sink;
 		void *user;
-		bool ordered;                                   // false: the sink may be called for any row at any time, from every context's thread
 	};
 
 	int turn_sink(void *user, uint64_t row, char const *bytes, uint64_t length)
 	{
 		auto &st(*static_cast<turn_state *>(user));
 		std::uint64_t const global((*st.global_row)[row]);
-		if (!st.ordered) {
-			// rows that do not depend on each other's place (a file per sequence): every context writes its own as they come -- writers on
-			// different files do not wait for each other the way writers on one file do (profiles/r04/e2e_config2_file_destinations.txt)
-			{ std::lock_guard<std::mutex> const lock(st.gate->mutex); if (st.gate->failed) return 1; }
-			int const rc(st.sink(st.user, global, bytes, length));
-			if (rc) { std::lock_guard<std::mutex> const lock(st.gate->mutex); st.gate->failed = true; }
-			return rc;
-		}
 		std::unique_lock<std::mutex> lock(st.gate->mutex);
 		st.gate->turn.wait(lock, [&] { return st.gate->failed || st.gate->next_row == global; });
 		if (st.gate->failed) return 1;
@@ -208,7 +200,7 @@ namespace {
 
 // splice() over several contexts that hold the chromosome copies dealt round-robin (set_copy_interleave): the sink sees the
 // rows in the batch's order, exactly as from one context.
-void output::splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user, bool ordered)
+void output::splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user)
 {
 	if (rows.any_cuts) throw std::runtime_error("rows that switch copies need the whole path matrix on their GPU");
 	std::vector<gpu_context *> gpus{&m_gpu};
@@ -234,7 +226,7 @@ void output::splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user, 
 				v2m_row_batch batch{};
 				batch.n_rows = local_copy[k].size();
 				batch.copy_index = local_copy[k].data();
-				turn_state st{&gate, &global_row[k], sink, user, ordered};
+				turn_state st{&gate, &global_row[k], sink, user};
 				gpus[k]->check(v2m_splice_rows(gpus[k]->get(), &batch, m_should_output_unaligned ? V2M_SPLICE_UNALIGNED : 0u, turn_sink, &st));
 			} catch (...) {
 				errors[k] = std::current_exception();
@@ -254,9 +246,9 @@ void output::splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user, 
 }
 
 
-void output::splice(row_set const &rows, v2m_sink_fn sink, void *user, bool ordered)
+void output::splice(row_set const &rows, v2m_sink_fn sink, void *user)
 {
-	if (m_interleaved && !m_more_gpus.empty()) { splice_in_turns(rows, sink, user, ordered); return; }
+	if (m_interleaved && !m_more_gpus.empty()) { splice_in_turns(rows, sink, user); return; }
 	v2m_row_batch batch{};
 	batch.n_rows = rows.copy_index.size();
 	batch.copy_index = rows.copy_index.data();
@@ -342,6 +334,159 @@ namespace {
 }
 
 
+namespace {
+	// Writer threads behind a v2m_hold_sink_fn (v2m_splice_rows_held): the sink queues a row and returns, a writer writes the row's file from the
+	// library's pinned slot and only then gives the row back.  One writer on one file moves 6-11 GB/s through the page cache, the link delivers
+	// 56: a file per sequence scales with writers (profiles/r04/e2e_config2_file_destinations.txt), and with rows that may be kept ONE GPU
+	// context is enough to feed them all.
+	class row_writer_pool {
+	public:
+		typedef bool (*write_fn)(void *user, std::uint64_t row, char const *bytes, std::uint64_t length);
+
+		row_writer_pool(unsigned n_threads, write_fn write, void *user) : m_write(write), m_user(user)
+		{
+			for (unsigned i(0); i < std::max(1u, n_threads); ++i) m_threads.emplace_back([this] { work(); });
+		}
+
+		~row_writer_pool() { finish(); }
+
+		// the v2m_hold_sink_fn: `user` is the pool
+		static int sink(void *user, uint64_t row, char const *bytes, uint64_t length, v2m_row_hold *hold)
+		{
+			auto &self(*static_cast<row_writer_pool *>(user));
+			{
+				std::lock_guard<std::mutex> const lock(self.m_mutex);
+				if (self.m_failed) return 1;                                    // not accepted: the library ends the call
+				self.m_jobs.push_back({row, bytes, length, hold});
+			}
+			self.m_wake.notify_one();
+			return 0;
+		}
+
+		// every queued row written (or dropped after a failure) and released; false if a write failed
+		bool finish()
+		{
+			{
+				std::lock_guard<std::mutex> const lock(m_mutex);
+				m_stopping = true;
+			}
+			m_wake.notify_all();
+			for (auto &t : m_threads) t.join();
+			m_threads.clear();
+			return !m_failed;
+		}
+
+	private:
+		struct job { std::uint64_t row; char const *bytes; std::uint64_t length; v2m_row_hold *hold; };
+
+		void work()
+		{
+			for (;;) {
+				job j;
+				bool write;
+				{
+					std::unique_lock<std::mutex> lock(m_mutex);
+					m_wake.wait(lock, [&] { return m_stopping || !m_jobs.empty(); });
+					if (m_jobs.empty()) return;
+					j = m_jobs.front();
+					m_jobs.pop_front();
+					write = !m_failed;
+				}
+				bool const ok(!write || m_write(m_user, j.row, j.bytes, j.length));
+				v2m_row_release(j.hold);                                            // whatever happened to the file: the slot is the library's
+				if (!ok) { std::lock_guard<std::mutex> const lock(m_mutex); m_failed = true; }
+			}
+		}
+
+		write_fn m_write;
+		void *m_user;
+		std::mutex m_mutex;
+		std::condition_variable m_wake;
+		std::deque<job> m_jobs;
+		std::vector<std::thread> m_threads;
+		bool m_stopping{}, m_failed{};
+	};
+
+	unsigned env_count(char const *name, unsigned fallback, unsigned lo, unsigned hi)
+	{
+		char const *const e(std::getenv(name));
+		long const v((e && *e) ? std::strtol(e, nullptr, 10) : 0);
+		return unsigned(std::min<long>(hi, std::max<long>(lo, v > 0 ? v : long(fallback))));
+	}
+
+	struct held_turn_state { std::vector<std::uint64_t> const *global_row; v2m_hold_sink_fn sink; void *user; };
+
+	int held_turn_sink(void *user, uint64_t row, char const *bytes, uint64_t length, v2m_row_hold *hold)
+	{
+		auto const &st(*static_cast<held_turn_state *>(user));
+		return st.sink(st.user, (*st.global_row)[row], bytes, length, hold);
+	}
+}
+
+
+// splice() for rows that need no order among themselves and a sink that keeps them for a while (v2m_splice_rows_held): one call per context,
+// each on its own thread when there are several; the sink sees the batch's row indices.
+void output::splice_held(row_set const &rows, v2m_hold_sink_fn sink, void *user)
+{
+	unsigned const n_slots(env_count("V2M_HELD_SLOTS", 4, 2, 64));
+	std::uint32_t const flags(m_should_output_unaligned ? V2M_SPLICE_UNALIGNED : 0u);
+	if (!(m_interleaved && !m_more_gpus.empty())) {
+		v2m_row_batch batch{};
+		batch.n_rows = rows.copy_index.size();
+		batch.copy_index = rows.copy_index.data();
+		std::vector<std::uint32_t> rebased;
+		if (!m_copy_shards.empty() && 0 != m_copy_shards.front().first) {
+			rebased = rebased_copies(rows, 0, rows.copy_index.size(), m_copy_shards.front());
+			batch.copy_index = rebased.data();
+		}
+		if (rows.any_cuts) {
+			batch.cut_offsets = rows.cut_offsets.data();
+			batch.cut_nodes = rows.cut_nodes.data();
+			batch.cut_copies = rows.cut_copies.data();
+		}
+		m_gpu.check(v2m_splice_rows_held(m_gpu.get(), &batch, flags, n_slots, sink, user));
+		return;
+	}
+	if (rows.any_cuts) throw std::runtime_error("rows that switch copies need the whole path matrix on their GPU");
+	std::vector<gpu_context *> gpus{&m_gpu};
+	gpus.insert(gpus.end(), m_more_gpus.begin(), m_more_gpus.end());
+	std::size_t const g(gpus.size());
+	if (m_copy_interleave.world != g) throw std::runtime_error("the copy interleave was made for another number of GPU contexts");
+	std::vector<std::vector<std::uint32_t>> local_copy(g);
+	std::vector<std::vector<std::uint64_t>> global_row(g);
+	for (std::uint64_t i(0); i < rows.copy_index.size(); ++i) {
+		std::uint32_t const c(rows.copy_index[i]);
+		bool const is_ref(V2M_PLOIDY_MAX == c);
+		std::size_t const k(is_ref ? 0 : m_copy_interleave.owner(c));
+		local_copy[k].push_back(is_ref ? c : std::uint32_t(m_copy_interleave.local(c)));
+		global_row[k].push_back(i);
+	}
+	std::vector<std::exception_ptr> errors(g);
+	std::vector<std::thread> threads;
+	for (std::size_t k(0); k < g; ++k) {
+		threads.emplace_back([&, k] {
+			try {
+				if (local_copy[k].empty()) return;
+				v2m_row_batch batch{};
+				batch.n_rows = local_copy[k].size();
+				batch.copy_index = local_copy[k].data();
+				held_turn_state st{&global_row[k], sink, user};
+				gpus[k]->check(v2m_splice_rows_held(gpus[k]->get(), &batch, flags, n_slots, held_turn_sink, &st));
+			} catch (...) {
+				errors[k] = std::current_exception();
+			}
+		});
+	}
+	for (auto &t : threads) t.join();
+	for (auto const &e : errors) {                                                      // the first error that is not just "my sink was told to stop"
+		if (!e) continue;
+		try { std::rethrow_exception(e); }
+		catch (gpu_error const &ge) { if (V2M_ERR_SINK != ge.code) throw; }
+	}
+	for (auto const &e : errors) if (e) std::rethrow_exception(e);
+}
+
+
 void output::write_a2m(row_set const &rows, std::ostream &stream)
 {
 	a2m_state st{&stream, &rows.ids, m_delegate};
@@ -352,10 +497,24 @@ void output::write_a2m(row_set const &rows, std::ostream &stream)
 void output::write_separate(row_set const &rows)
 {
 	separate_state st{&rows.ids, m_pipe_cmd, nullptr};
+	if (!m_pipe_cmd) {
+		// Files of their own need no order among themselves and no single writer: the rows stay in the library's pinned slots while a pool
+		// of threads writes them out (V2M_WRITER_THREADS, default 8 in all), so that ONE context's link is fed by as many writers as it takes.
+		// With several GPU contexts each one's thread delivers into the same pool.
+		struct file_writer {
+			static bool write(void *user, std::uint64_t row, char const *bytes, std::uint64_t length) { return 0 == separate_sink(user, row, bytes, length); }
+		};
+		row_writer_pool pool(env_count("V2M_WRITER_THREADS", 8, 1, 64), &file_writer::write, &st);
+		std::exception_ptr error;
+		try { splice_held(rows, &row_writer_pool::sink, &pool); } catch (...) { error = std::current_exception(); }
+		bool const written(pool.finish());
+		if (!written) throw std::runtime_error("error while writing a sequence file");      // the telling error, not "sink failed"
+		if (error) std::rethrow_exception(error);
+		return;
+	}
 	try {
-		// Files of their own need no order among themselves: with several GPU contexts each one's thread writes its sequences as they
-		// arrive.  Subprocesses (--pipe) are still started one after the other, as the reference starts them (output.cc:26-38).
-		splice(rows, separate_sink, &st, nullptr != m_pipe_cmd);
+		// Subprocesses (--pipe) are started one after the other, as the reference starts them (output.cc:26-38).
+		splice(rows, separate_sink, &st);
 	} catch (...) {
 		if (st.error) std::rethrow_exception(st.error);                     // what went wrong with the subprocess, not "sink failed"
 		throw;

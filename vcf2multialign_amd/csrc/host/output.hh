@@ -67,9 +67,10 @@ protected:
 		std::vector<std::uint32_t> cut_copies;
 		bool any_cuts{};
 	};
-	// ordered = false: the sink takes any row at any time and from several threads (one per GPU context)
-	void splice(row_set const &rows, v2m_sink_fn sink, void *user, bool ordered = true);
-	void splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user, bool ordered);
+	void splice(row_set const &rows, v2m_sink_fn sink, void *user);             // the sink sees the rows in batch order, one at a time
+	void splice_in_turns(row_set const &rows, v2m_sink_fn sink, void *user);
+	// rows that need no order and a sink that keeps them until it calls v2m_row_release (a pool of writers): v2m_splice_rows_held per context
+	void splice_held(row_set const &rows, v2m_hold_sink_fn sink, void *user);
 	static std::vector<std::uint32_t> rebased_copies(row_set const &rows, std::uint64_t first, std::uint64_t last, copy_shard shard);
 	void write_a2m(row_set const &rows, std::ostream &stream);
 	void write_a2m_sharded(row_set const &rows, char const *dst_name);

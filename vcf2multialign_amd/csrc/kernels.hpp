@@ -1639,35 +1639,68 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 		slot_end += (u32) __builtin_amdgcn_update_dpp(0, (int) slot_end, 0x118, 0xf, 0xf, false);   // row_shr:8
 
 		char *const dst = out + (u64) row * row_pitch + tile_offsets[(u64) row * n_tiles + tile];
+
+		// Stream-out.  A chunk without padding goes out as it is: one 16-B store at its byte-granular destination (the wave's 64 of them
+		// cover one contiguous KiB at whatever byte phase the row is in).  A chunk that holds padding has to be packed first, and that
+		// costs ~100 VALU instructions which a wave pays whether one lane needs them or all 64 -- on a dense graph (config 5: a gap
+		// every 500 bases) nearly every 1-KiB slot holds ONE or TWO such chunks, and packing "where they are" made this kernel run at
+		// 100 % VALU issue, 512 instructions per wave and row tile against the aligned kernel's 114 (profiles/r05/unaligned_pmc_*).
+		// So the short chunks of the wave's four slots are first GATHERED: their descriptors (chunk | bytes << 10 | destination << 14)
+		// move to the low lanes of one register, one v_readlane + v_writelane pair per chunk under scalar control, and ONE pass packs
+		// them all, a lane per chunk, reading the chunks back from the row tile (still whole: only this wave rewrites its own slots, in
+		// program order).  A slot with more than kGatherMax short chunks (tiles inside long insertions) is packed where it is, by the
+		// same code: stage 2 below is one loop over "the gathered ones" and "dense slot k", so the pack code exists once.
+		constexpr u32 kGatherMax = 16;                                           // 4 slots x 16 = 64 lanes: the gather register never overflows
+		u32 offs[kChunksPerThread];
+		u32 pending = 0;                                                         // lane j: descriptor of the j-th gathered chunk
+		u32 queued = 0, dense = 0;                                               // wave-uniform
 #pragma unroll
 		for (int k = 0; k < kChunksPerThread; ++k) {
 			int const slot = k * (kSpliceThreads / 64) + wave;                       // wave-uniform
 			u32 const slot_begin = slot ? (u32) __builtin_amdgcn_readlane((int) slot_end, slot - 1) : 0u;
-			u32 const off = slot_begin + incl[k] - cnt[k];
-			auto const store16 = [&](vec4u const &x) {
-				if (kNonTemporal) __builtin_nontemporal_store(x, (vec4u_unaligned *) (dst + off));
-				else *(vec4u_unaligned *) (dst + off) = x;
-			};
-			if (!__any(16 != cnt[k])) {
-				// no padding in any of the wave's 64 chunks: one 16-B store each, covering one contiguous KiB at whatever
-				// byte phase the row is in (rounding the addresses down to 16 B -- wrong output, timing only -- changes
-				// nothing; the misalignment is not what this kernel is bound by)
-				store16(v[k]);
-				continue;
+			u32 const c = cnt[k];
+			u32 const off = slot_begin + incl[k] - c;
+			offs[k] = off;
+			if (16 == c) {
+				if (kNonTemporal) __builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));
+				else *(vec4u_unaligned *) (dst + off) = v[k];
 			}
-			// Some chunk of the wave holds padding (64 % of the time at config 3, always at config 5).  What bounds this
-			// kernel is the number of small store requests such chunks cause (profiles/r02/unaligned_what_bounds_it.txt), so:
-			//  1. every lane packs its chunk's surviving bytes to the low end of a 16-B value in registers (v_perm_b32 per
-			//     dword with the selector table, then the four pieces shifted together; a full chunk packs to itself);
-			//  2. a lane whose chunk is short fills its value up with the FIRST bytes of the next lane's packed chunk (DPP
-			//     wave shift) and stores 16 B like everybody else: the bytes it writes beyond its own are exactly the ones
-			//     the next lane writes there too, so the overlap is harmless whichever store lands last;
-			//  3. only a lane that cannot do that -- lane 63, or a next chunk too short to fill up from -- stores its bytes
-			//     exactly, as at most one store each of 8, 4, 2 and 1 bytes.
+			bool const partial = c - 1u < 15u;                                       // 1 ... 15 surviving bytes (an all-padding chunk writes nothing)
+			u64 const mask = __ballot(partial);
+			if (0 == mask) continue;                                                  // (wave-uniform) nothing to pack in this slot
+			if ((u32) __builtin_popcountll(mask) > kGatherMax) { dense |= 1u << k; continue; }
+			u32 const entry = (u32) (t + kSpliceThreads * k) | c << 10 | off << 14;
+			for (u64 m = mask; m; m &= m - 1) {                                       // scalar loop: one short chunk per turn
+				u32 const e = (u32) __builtin_amdgcn_readlane((int) entry, __builtin_ctzll(m));
+				// (clang has no writelane builtin.  A gfx9 VALU instruction reads one SGPR at most, so the lane select goes through M0, which does
+				// not count; it is written by the scalar unit, so none of the VALU-writes-SGPR-then-lane-select hazards applies, and `e`,
+				// which v_readlane wrote, is the data operand.  The s_nop covers M0's one wait state after a scalar write.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"   // ("m0 is a reserved register": nothing else in this kernel uses it -- tests/test_kernel_isa.py checks)
+				asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pending) : "s"(e), "s"(queued) : "m0");
+#pragma clang diagnostic pop
+				++queued;
+			}
+		}
+		for (u32 todo = dense | (queued ? 1u << kChunksPerThread : 0u); todo; todo &= todo - 1) {   // wave-uniform
+			u32 const j = (u32) __builtin_ctz(todo);
+			u32 e = pending;
+			bool active = (u32) lane < queued;
+			if (j < (u32) kChunksPerThread) {                                         // (uniform) dense slot j, every lane its own chunk
+				u32 const c = 0 == j ? cnt[0] : 1 == j ? cnt[1] : 2 == j ? cnt[2] : cnt[3];
+				u32 const o = 0 == j ? offs[0] : 1 == j ? offs[1] : 2 == j ? offs[2] : offs[3];
+				e = ((u32) t + (u32) kSpliceThreads * j) | c << 10 | o << 14;
+				active = c - 1u < 15u;
+			}
+			if (!active) continue;
+			u32 const c = (e >> 10) & 15u;
+			vec4u const x = lds[e & 1023u];
+			// the chunk's surviving bytes packed to the low end of a 16-B value: v_perm_b32 per dword with the selector table, then the four
+			// pieces shifted together
 			u32 piece[4], len[4];
 #pragma unroll
 			for (int d = 0; d < 4; ++d) {
-				u32 const keep = ~zero_bytes_mask(v[k][d]) & 0x80808080u;          // 0x80 per surviving byte (bits 7, 15, 23, 31)
+				u32 const keep = ~zero_bytes_mask(x[d]) & 0x80808080u;             // 0x80 per surviving byte (bits 7, 15, 23, 31)
 				// ... gathered into the top nibble: neighbours side by side at bits 14|15, 22|23, 30|31, then all four at 28..31.
 				// (inline assembly because the compiler recognises x | x << 7 | ... as a multiplication by a constant and
 				// emits v_mul_lo_u32, which issues at a quarter of the rate of these two)
@@ -1675,39 +1708,21 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 				asm("v_lshl_or_b32 %0, %1, 7, %1" : "=v"(pairs) : "v"(keep));
 				asm("v_lshl_or_b32 %0, %1, 14, %1" : "=v"(quad) : "v"(pairs));
 				u32 const m = quad >> 28;
-				piece[d] = __builtin_amdgcn_perm(0u, v[k][d], compact_sel[m]);
+				piece[d] = __builtin_amdgcn_perm(0u, x[d], compact_sel[m]);
 				len[d] = (u32) __builtin_popcount(m);
 			}
 			u64 const lo = (u64) piece[0] | ((u64) piece[1] << (8 * len[0]));
 			u64 const hi = (u64) piece[2] | ((u64) piece[3] << (8 * len[2]));
-			u32 const s = 8 * (len[0] + len[1]);                                   // 0 ... 64
-			u64 const packed_lo = lo | (s < 64 ? hi << s : 0);
-			u64 const packed_hi = 0 == s ? 0 : (64 == s ? hi : hi >> (64 - s));
-
-			u64 const next_lo = wave_shift_left_u64(packed_lo), next_hi = wave_shift_left_u64(packed_hi);   // lane 63: 0
-			u32 const next_cnt = (u32) __builtin_amdgcn_update_dpp(0, (int) cnt[k], 0x130, 0xf, 0xf, true);
-			u32 const c = cnt[k];
-			if (c && c + next_cnt >= 16) {          // (a full chunk qualifies by itself; lane 63 only if full)
-				u32 const sh = 8 * c;                // next << sh, 128 bits wide; sh = 128 for a full chunk
-				u64 fill_lo = 0, fill_hi = 0;
-				if (sh < 64) {
-					fill_lo = next_lo << sh;
-					fill_hi = (next_hi << sh) | (sh ? next_lo >> (64 - sh) : 0);
-				} else if (sh < 128) {
-					fill_hi = next_lo << (sh - 64);
-				}
-				u64 const out_lo = packed_lo | fill_lo, out_hi = packed_hi | fill_hi;
-				vec4u x;
-				x[0] = (u32) out_lo; x[1] = (u32) (out_lo >> 32); x[2] = (u32) out_hi; x[3] = (u32) (out_hi >> 32);
-				store16(x);
-			} else if (c) {
-				char *p = dst + off;
-				u64 rest = packed_lo;
-				if (c & 8) { *(u64_unaligned *) p = packed_lo; p += 8; rest = packed_hi; }
-				if (c & 4) { *(u32_unaligned *) p = (u32) rest; p += 4; rest >>= 32; }
-				if (c & 2) { *(u16_unaligned *) p = (u16) rest; p += 2; rest >>= 16; }
-				if (c & 1) *p = (char) rest;
-			}
+			u32 const sh = 8 * (len[0] + len[1]);                                  // 0 ... 64
+			u64 const packed_lo = lo | (sh < 64 ? hi << sh : 0);
+			u64 const packed_hi = 0 == sh ? 0 : (64 == sh ? hi : hi >> (64 - sh));
+			// ... and stored exactly: at most one store each of 8, 4, 2 and 1 bytes (the bytes around them belong to other chunks' stores)
+			char *p = dst + (e >> 14);
+			u64 rest = packed_lo;
+			if (c & 8) { *(u64_unaligned *) p = packed_lo; p += 8; rest = packed_hi; }
+			if (c & 4) { *(u32_unaligned *) p = (u32) rest; p += 4; rest >>= 32; }
+			if (c & 2) { *(u16_unaligned *) p = (u16) rest; p += 2; rest >>= 16; }
+			if (c & 1) *p = (char) rest;
 		}
 		// wave_sums is rewritten only after the next row's barriers
 	}

@@ -10,10 +10,13 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <utility>
@@ -74,6 +77,21 @@ struct event_pair { hipEvent_t begin{}, end{}; };
 } // namespace
 
 
+// One pinned slot of v2m_splice_rows_held: the rows of one slice, and how many of them the sink still holds.  A row's hold IS its
+// slot (include/v2m_hip.h: v2m_row_hold), so that a release is one decrement under the ring's mutex from whatever thread.
+struct held_ring_state {
+	std::mutex mutex;
+	std::condition_variable released;
+};
+
+struct v2m_row_hold {
+	pinned_buf host;
+	hipEvent_t copied{};                // the slice's D2H copy has landed in `host`
+	uint64_t outstanding{};             // delivered rows not yet released (under ring->mutex)
+	held_ring_state *ring{};
+};
+
+
 struct v2m_ctx {
 	int device{};
 	hipStream_t stream{};
@@ -128,6 +146,9 @@ struct v2m_ctx {
 	dev_buf d_eff, d_row_bits, d_seg_offsets, d_seg_edge_begin, d_seg_copy, d_sums, d_lengths, d_needs_serial, d_tile_counts, d_row_lengths;
 	dev_buf ring[2];
 	pinned_buf host_ring[2];
+	// v2m_splice_rows_held: more pinned slots than the two above, each kept until the sink has released its rows
+	held_ring_state held_state;
+	std::vector<std::unique_ptr<v2m_row_hold>> held_ring;
 	pinned_buf trials_stage[2];   // v2m_pbwt_cut_trials_streamed: the pairs' way back to the host
 	hipEvent_t ev_compute[2]{}, ev_copy[2]{};
 };
@@ -964,6 +985,7 @@ void v2m_ctx_destroy(v2m_ctx *ctx)
 		if (ctx->ev_copy[i]) (void) hipEventDestroy(ctx->ev_copy[i]);
 		if (ctx->ev_row_stage[i]) (void) hipEventDestroy(ctx->ev_row_stage[i]);
 	}
+	for (auto &slot : ctx->held_ring) if (slot && slot->copied) (void) hipEventDestroy(slot->copied);
 	(void) hipStreamDestroy(ctx->stream);
 	(void) hipStreamDestroy(ctx->copy_stream);
 	delete ctx;
@@ -1703,6 +1725,125 @@ int v2m_splice_rows(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, v2m
 	if (timing) std::fprintf(stderr, "[v2m_splice_rows] %llu rows in %llu slices: %.3f s in all, %.3f s preparing and launching, %.3f s waiting for copies and in the sink\n",
 		(unsigned long long) rows->n_rows, (unsigned long long) n_slices, since(t_call), t_issue, t_drain);
 	return rc;
+}
+
+
+// ---- rows the sink may keep (ABI 5) -------------------------------------------------------------------------------------------
+//
+// v2m_splice_rows hands a row over for the duration of the sink call, so whatever the sink does with it -- a write() into a file --
+// happens on the calling thread, one row at a time, and the next slice cannot be launched meanwhile: one context, one writer.
+// Here a row stays where it is (a pinned slot of a ring of n_slots) until the sink says it is done with it, from any thread:
+// the sink queues the row for a pool of writers and returns, the call goes on launching slices and copies, and only a slot whose
+// rows are all released is copied into again.
+int v2m_splice_rows_held(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, uint32_t n_slots, v2m_hold_sink_fn sink, void *user)
+{
+	if (int const rc = check_batch(ctx, rows, flags)) return rc;
+	if (!sink) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "sink is NULL");
+	if (n_slots < 2 || n_slots > 64) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "n_slots must be between 2 and 64 (got %u)", n_slots);
+	if (0 == rows->n_rows) return V2M_OK;
+	V2M_HIP_TRY(ctx, hipSetDevice(ctx->device));
+	bool const unaligned(flags & V2M_SPLICE_UNALIGNED);
+	u64 const L(ctx->aligned_len);
+
+	auto &state(ctx->held_state);
+	auto const wait_released([&](v2m_row_hold &slot) {
+		std::unique_lock<std::mutex> lock(state.mutex);
+		state.released.wait(lock, [&] { return 0 == slot.outstanding; });
+	});
+	// hands rows [r0, r1) of a slot to the sink; returns V2M_ERR_SINK when the sink refuses one (that row and the rows after it count
+	// as never delivered)
+	auto const deliver([&](v2m_row_hold &slot, u64 r0, u64 r1, u64 pitch, u64 slot_bytes) -> int {
+		char const *const base(slot.host.as<char>());
+		u64 const *const lengths(reinterpret_cast<u64 const *>(base + slot_bytes));
+		{ std::lock_guard<std::mutex> const lock(state.mutex); slot.outstanding = r1 - r0; }
+		for (u64 r(r0); r < r1; ++r) {
+			if (0 == sink(user, r, L ? base + (r - r0) * pitch : "", (unaligned && L) ? lengths[r - r0] : L, &slot)) continue;
+			{ std::lock_guard<std::mutex> const lock(state.mutex); slot.outstanding -= r1 - r; }
+			state.released.notify_all();
+			return fail(ctx, V2M_ERR_SINK, "sink aborted at row %llu", (unsigned long long) r);
+		}
+		return V2M_OK;
+	});
+
+	while (ctx->held_ring.size() < n_slots) {
+		std::unique_ptr<v2m_row_hold> slot(new v2m_row_hold);
+		slot->ring = &state;
+		V2M_HIP_TRY(ctx, hipEventCreateWithFlags(&slot->copied, hipEventDisableTiming));
+		ctx->held_ring.push_back(std::move(slot));
+	}
+
+	if (0 == L) {   // rows without a byte: nothing to copy, nothing to hold on to
+		auto &slot(*ctx->held_ring[0]);
+		int const rc(deliver(slot, 0, rows->n_rows, 0, 0));
+		wait_released(slot);
+		return rc;
+	}
+
+	u64 const pitch(unaligned ? ((v2m_max_unaligned_length(ctx) + 255) & ~u64(255)) : v2m_min_row_pitch(ctx));
+	char const *const slot_env(std::getenv("V2M_RING_SLOT_BYTES"));   // test knob: force small slices
+	u64 const slot_default(rows->n_rows * pitch < (u64(8) << 30) ? (u64(128) << 20) : (u64(512) << 20));
+	u64 const slot_target((slot_env && *slot_env) ? std::strtoull(slot_env, nullptr, 10) : slot_default);
+	u64 const rows_per_slice(std::max<u64>(1, std::min<u64>(rows->n_rows, slot_target / pitch)));
+	u64 const n_slices((rows->n_rows + rows_per_slice - 1) / rows_per_slice);
+	u64 const slot_bytes(rows_per_slice * pitch);
+	u64 const lengths_bytes(rows_per_slice * sizeof(u64));
+	int rc(V2M_OK);
+	auto const hip_step([&](hipError_t st, char const *what) {
+		if (hipSuccess != st && V2M_OK == rc) rc = fail(ctx, hipErrorOutOfMemory == st ? V2M_ERR_OUT_OF_MEMORY : V2M_ERR_HIP, "%s: %s", what, hipGetErrorString(st));
+		return hipSuccess == st;
+	});
+	for (int i(0); i < (n_slices > 1 ? 2 : 1) && V2M_OK == rc; ++i) hip_step(ctx->ring[i].ensure(slot_bytes), "device slot");
+	u64 const slots_used(std::min<u64>(n_slots, n_slices));
+
+	u64 launched(0), delivered(0);
+	for (u64 s(0); s < n_slices && V2M_OK == rc; ++s) {
+		auto &slot(*ctx->held_ring[s % n_slots]);
+		int const d(int(s & 1));
+		u64 const r0(s * rows_per_slice), r1(std::min(rows->n_rows, r0 + rows_per_slice));
+		wait_released(slot);                                              // the slice that was here n_slots slices ago
+		if (!hip_step(slot.host.ensure(slot_bytes + lengths_bytes), "pinned slot")) break;
+		// the device slot is written again only when the copy that reads it (slice s - 2) is over
+		if (s >= 2 && !hip_step(hipStreamWaitEvent(ctx->stream, ctx->held_ring[(s - 2) % n_slots]->copied, 0), "device slot reuse")) break;
+		rc = unaligned
+			? splice_unaligned_slice(ctx, rows, r0, r1, ctx->ring[d].as<char>(), pitch)
+			: splice_aligned_slice(ctx, rows, r0, r1, ctx->ring[d].as<char>(), pitch);
+		if (V2M_OK != rc) break;
+		bool ok(true);
+		if (unaligned) ok = hip_step(hipMemcpyAsync(slot.host.as<char>() + slot_bytes, ctx->d_row_lengths.p, (r1 - r0) * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream), "row lengths");
+		ok = ok && hip_step(hipEventRecord(ctx->ev_compute[d], ctx->stream), "event");
+		ok = ok && hip_step(hipStreamWaitEvent(ctx->copy_stream, ctx->ev_compute[d], 0), "event");
+		ok = ok && hip_step(hipMemcpyAsync(slot.host.p, ctx->ring[d].p, (r1 - r0) * pitch, hipMemcpyDeviceToHost, ctx->copy_stream), "D2H copy");
+		ok = ok && hip_step(hipEventRecord(slot.copied, ctx->copy_stream), "event");
+		if (!ok) break;
+		launched = s + 1;
+		if (s >= 1) {                                                     // the slice before this one: its copy ran under this one's kernels
+			auto &prev(*ctx->held_ring[(s - 1) % n_slots]);
+			if (!hip_step(hipEventSynchronize(prev.copied), "D2H copy")) break;
+			rc = deliver(prev, r0 - rows_per_slice, r0, pitch, slot_bytes);
+			delivered = s;
+		}
+	}
+	if (V2M_OK == rc && launched > delivered) {
+		auto &last(*ctx->held_ring[(launched - 1) % n_slots]);
+		if (hip_step(hipEventSynchronize(last.copied), "D2H copy"))
+			rc = deliver(last, (launched - 1) * rows_per_slice, std::min(rows->n_rows, launched * rows_per_slice), pitch, slot_bytes);
+	}
+	// whatever happened: both streams idle, and no row still in a writer's hands when the call returns (the slots are the library's)
+	(void) hipStreamSynchronize(ctx->stream);
+	(void) hipStreamSynchronize(ctx->copy_stream);
+	for (u64 i(0); i < std::max<u64>(slots_used, 1); ++i) wait_released(*ctx->held_ring[i]);
+	return rc;
+}
+
+void v2m_row_release(v2m_row_hold *hold)
+{
+	if (!hold) return;
+	bool last(false);
+	{
+		std::lock_guard<std::mutex> const lock(hold->ring->mutex);
+		if (hold->outstanding) last = 0 == --hold->outstanding;
+	}
+	if (last) hold->ring->released.notify_all();
 }
 
 
