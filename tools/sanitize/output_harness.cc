@@ -92,9 +92,9 @@ struct v2m_row_hold {
 extern "C" {
 void v2m_row_release(v2m_row_hold *hold)
 {
-	bool last;
-	{ std::lock_guard<std::mutex> const lock(*hold->mutex); last = 0 == --hold->outstanding; }
-	if (last) hold->released->notify_all();
+	// (notified under the lock: the waiter may free the slot ring the moment it sees zero, so nothing of it is touched after the unlock)
+	std::lock_guard<std::mutex> const lock(*hold->mutex);
+	if (0 == --hold->outstanding) hold->released->notify_all();
 }
 
 int v2m_splice_rows_held(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags, uint32_t n_slots, v2m_hold_sink_fn sink, void *user)

@@ -1574,9 +1574,11 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 	__shared__ patch_cache pc;
 	__shared__ u32 wave_sums[kChunksPerThread * (kSpliceThreads / 64)];   // per 1-KiB slot, in stream order: [k][wave]
 	__shared__ u32 compact_sel[16];
+	constexpr u32 kPackQueue = 24;
+	__shared__ u32 pack_queue[kSpliceThreads / 64][kPackQueue];    // per wave: the short chunks of the row tile waiting to be packed (see the stream-out below)
 
 	int const t = threadIdx.x;
-	int const lane = t & 63, wave = t >> 6;
+	int const lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);   // (scalar: slot numbers and LDS bases derived from it stay in SGPRs)
 	if (t < 16) compact_sel[t] = compaction_selector((u32) t);   // first read follows the row loop's barriers
 	u32 tile, group;
 	map_block(blockIdx.x, n_groups, n_tiles, tile_run, tile, group);
@@ -1645,14 +1647,13 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 		// costs ~100 VALU instructions which a wave pays whether one lane needs them or all 64 -- on a dense graph (config 5: a gap
 		// every 500 bases) nearly every 1-KiB slot holds ONE or TWO such chunks, and packing "where they are" made this kernel run at
 		// 100 % VALU issue, 512 instructions per wave and row tile against the aligned kernel's 114 (profiles/r05/unaligned_pmc_*).
-		// So the short chunks of the wave's four slots are first GATHERED: their descriptors (chunk | bytes << 10 | destination << 14)
-		// move to the low lanes of one register, one v_readlane + v_writelane pair per chunk under scalar control, and ONE pass packs
-		// them all, a lane per chunk, reading the chunks back from the row tile (still whole: only this wave rewrites its own slots, in
-		// program order).  A slot with more than kGatherMax short chunks (tiles inside long insertions) is packed where it is, by the
-		// same code: stage 2 below is one loop over "the gathered ones" and "dense slot k", so the pack code exists once.
-		constexpr u32 kGatherMax = 16;                                           // 4 slots x 16 = 64 lanes: the gather register never overflows
+		// So the short chunks of the wave's four slots are first QUEUED -- descriptor = chunk | bytes << 10 | destination << 14, one
+		// LDS word each, written under the slot's mask at mbcnt positions: no loop, no branch -- and ONE pass packs them all, a lane
+		// per chunk, reading the chunks back from the row tile (still whole: only this wave rewrites its own slots, in program order).
+		// A slot whose short chunks do not fit the queue any more (kPackQueue entries per wave: what fits beside the tile without
+		// costing the seventh workgroup per CU; tiles inside long insertions) is packed where it is, by the same code: stage 2 below
+		// is one loop over "the queued ones" and "dense slot k", so the pack code exists once.
 		u32 offs[kChunksPerThread];
-		u32 pending = 0;                                                         // lane j: descriptor of the j-th gathered chunk
 		u32 queued = 0, dense = 0;                                               // wave-uniform
 #pragma unroll
 		for (int k = 0; k < kChunksPerThread; ++k) {
@@ -1667,21 +1668,14 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			}
 			bool const partial = c - 1u < 15u;                                       // 1 ... 15 surviving bytes (an all-padding chunk writes nothing)
 			u64 const mask = __ballot(partial);
-			if (0 == mask) continue;                                                  // (wave-uniform) nothing to pack in this slot
-			if ((u32) __builtin_popcountll(mask) > kGatherMax) { dense |= 1u << k; continue; }
-			u32 const entry = (u32) (t + kSpliceThreads * k) | c << 10 | off << 14;
-			for (u64 m = mask; m; m &= m - 1) {                                       // scalar loop: one short chunk per turn
-				u32 const e = (u32) __builtin_amdgcn_readlane((int) entry, __builtin_ctzll(m));
-				// (clang has no writelane builtin.  A gfx9 VALU instruction reads one SGPR at most, so the lane select goes through M0, which does
-				// not count; it is written by the scalar unit, so none of the VALU-writes-SGPR-then-lane-select hazards applies, and `e`,
-				// which v_readlane wrote, is the data operand.  The s_nop covers M0's one wait state after a scalar write.)
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Winline-asm"   // ("m0 is a reserved register": nothing else in this kernel uses it -- tests/test_kernel_isa.py checks)
-				asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(pending) : "s"(e), "s"(queued) : "m0");
-#pragma clang diagnostic pop
-				++queued;
-			}
+			u32 const n = (u32) __builtin_popcountll(mask);                           // (scalar)
+			bool const fits = queued + n <= kPackQueue;                               // (scalar)
+			u32 const pos = __builtin_amdgcn_mbcnt_hi((u32) (mask >> 32), __builtin_amdgcn_mbcnt_lo((u32) mask, queued));
+			if (partial && pos < kPackQueue) pack_queue[wave][pos] = (u32) (t + kSpliceThreads * k) | c << 10 | off << 14;   // (entries of a slot that does not fit are overwritten or ignored)
+			dense |= (n && !fits) ? 1u << k : 0u;
+			queued = fits ? queued + n : queued;
 		}
+		u32 const pending = pack_queue[wave][lane < (int) kPackQueue ? lane : 0];   // (same wave wrote them: LDS operations of a wave execute in order)
 		for (u32 todo = dense | (queued ? 1u << kChunksPerThread : 0u); todo; todo &= todo - 1) {   // wave-uniform
 			u32 const j = (u32) __builtin_ctz(todo);
 			u32 e = pending;

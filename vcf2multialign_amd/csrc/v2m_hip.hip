@@ -1758,8 +1758,7 @@ int v2m_splice_rows_held(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags
 		{ std::lock_guard<std::mutex> const lock(state.mutex); slot.outstanding = r1 - r0; }
 		for (u64 r(r0); r < r1; ++r) {
 			if (0 == sink(user, r, L ? base + (r - r0) * pitch : "", (unaligned && L) ? lengths[r - r0] : L, &slot)) continue;
-			{ std::lock_guard<std::mutex> const lock(state.mutex); slot.outstanding -= r1 - r; }
-			state.released.notify_all();
+			{ std::lock_guard<std::mutex> const lock(state.mutex); slot.outstanding -= r1 - r; }   // (the only waiter is this thread)
 			return fail(ctx, V2M_ERR_SINK, "sink aborted at row %llu", (unsigned long long) r);
 		}
 		return V2M_OK;
@@ -1838,13 +1837,12 @@ int v2m_splice_rows_held(v2m_ctx *ctx, const v2m_row_batch *rows, uint32_t flags
 void v2m_row_release(v2m_row_hold *hold)
 {
 	if (!hold) return;
-	bool last(false);
-	{
-		std::lock_guard<std::mutex> const lock(hold->ring->mutex);
-		if (hold->outstanding) last = 0 == --hold->outstanding;
-	}
-	if (last) hold->ring->released.notify_all();
+	// Notified under the lock: the thread inside v2m_splice_rows_held returns once it sees the last slot at zero, and its caller may destroy
+	// the ctx right after -- nothing of the ring is touched once the mutex is let go.
+	std::lock_guard<std::mutex> const lock(hold->ring->mutex);
+	if (hold->outstanding && 0 == --hold->outstanding) hold->ring->released.notify_all();
 }
+
 
 
 // ---- output buffers ------------------------------------------------------------------------------
