@@ -273,7 +273,9 @@ uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx);
  *
  * The ctx must hold the uploaded graph WITH its path matrix (v2m_upload_graph with paths_by_chrom_copy_and_edge): the first
  * v2m_pbwt_* call after a matrix is bound transposes it back to edge-major bits on the device, and that copy (as large as the
- * matrix) is kept for the following calls until the matrix is bound anew or the ctx is destroyed -- one founder run makes two.
+ * matrix) is kept for the following v2m_pbwt_* calls -- one founder run makes two -- until the matrix is bound anew, a v2m_splice_rows*
+ * call starts (the output that follows the searches gets the memory back) or the ctx is destroyed.  The copy is made from the matrix as it
+ * is at that first call: a caller that changes a v2m_set_paths_device() matrix in place must bind it again before the next search.
  * n_copies <= 8192 and a bound matrix of at most 8192 copy columns (V2M_ERR_UNSUPPORTED beyond: a workgroup keeps the pBWT state
  * and one edge column in LDS).  V2M_ERR_INVALID_ARGUMENT for candidate edges that decrease or lie outside the graph, aligned
  * positions that decrease (find_cut_positions.cc:129,151) and start_order entries >= n_copies -- checked on the host before any

@@ -943,6 +943,12 @@ bool find_matchings_walked(
 	std::vector<u32> rec_distinct(n_cuts, 0), rec_first_class(n_cuts, 0), rec_first_is_ref(n_cuts, 0), status(n_chunks, 1);
 	walker.records(copies, cut_edge, chunk_first_cut, walker.state_edge, walker.state_order.get(), walker.state_divergence.get(),
 		pool_capacity, pool_lhs.get(), pool_rhs.get(), pool_size.get(), rec_pool_end.data(), rec_distinct.data(), rec_first_class.data(), rec_first_is_ref.data(), status.data());
+	// The states are good for ONE matching after the search that left them: they are keyed by the graph's shape and the address of its
+	// matrix, which a matrix rewritten in place (or a new one allocated where the old one was) would still match.  Used once, then dropped.
+	walker.state_edge.clear();
+	walker.state_order.reset();
+	walker.state_divergence.reset();
+	walker.state_matrix = nullptr;
 	timer.mark("matching: chunk walks (walker)");
 	if (walker.on_last_walk) walker.on_last_walk();
 

@@ -898,6 +898,8 @@ int check_batch(v2m_ctx *ctx, v2m_row_batch const *rows, u32 flags)
 	if (rows->cut_offsets && rows->cut_offsets[rows->n_rows] && (!rows->cut_nodes || !rows->cut_copies))
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "cut arrays are NULL");
 	if (rows->n_rows >= 0xFFFFFFFFull) return fail(ctx, V2M_ERR_UNSUPPORTED, "too many rows in one batch");
+	// the founder searches' edge-major copy of the path matrix (as large as the matrix) is not kept through the output that follows them
+	if (ctx->d_by_edge.p) { ctx->d_by_edge.reset(); ctx->by_edge_valid = false; }
 	if ((flags & V2M_SPLICE_UNALIGNED) && ctx->has_nul_byte)
 		return fail(ctx, V2M_ERR_UNSUPPORTED, "the reference sequence or an ALT label holds a NUL byte, which the unaligned kernels use as their padding marker; aligned mode keeps such bytes");
 	return V2M_OK;
