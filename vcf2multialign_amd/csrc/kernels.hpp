@@ -1642,26 +1642,18 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 
 		char *const dst = out + (u64) row * row_pitch + tile_offsets[(u64) row * n_tiles + tile];
 
-		// Stream-out.  Every lane stores its chunk's surviving bytes at their byte-granular destination; a 1-KiB slot whose 64 chunks are all
-		// full is one 16-B store per lane.  A chunk that holds padding has to be packed first (~100 VALU instructions, which a wave pays
-		// whether one lane needs them or all 64), and on a dense graph (config 5: a gap every 500 bases) nearly every slot holds ONE or
-		// TWO such chunks: packing "where they are" made this kernel run at 100 % VALU issue, 512 instructions per wave and row tile
-		// against the aligned kernel's 114 (profiles/r05/unaligned_pmc_config5_before.txt).  So, in three steps:
-		//  1. per slot: destinations, and the short chunks QUEUED -- descriptor = chunk | bytes << 10 | destination << 14 | fillable << 28, one
-		//     LDS word each, written under the slot's mask at mbcnt positions: no loop, no branch;
-		//  2. ONE pass packs all queued chunks of the wave's four slots, a lane per chunk, reading them back from the row tile (still whole:
-		//     only this wave rewrites its own chunks, in program order).  A chunk whose successor is full ("fillable") is filled up to 16
-		//     bytes with the successor's first bytes -- exactly what the successor writes there itself -- and written BACK into the tile;
-		//     the others (successor short, empty or another wave's) store their bytes exactly, as at most one store each of 8, 4, 2, 1 bytes;
-		//  3. per slot: the short lanes take their 16 bytes back from the tile and ONE store instruction writes the whole slot -- full
-		//     chunks and filled-up ones side by side, so that every line of the row arrives at the L2 complete.  (Stored separately,
-		//     a slot's stragglers cost 12 % of the kernel: late partial writes of lines that have left the L2,
-		//     profiles/r05/unaligned_store_pattern_experiments.txt.)
+		// Stream-out.  A chunk without padding goes out as it is: one 16-B store at its byte-granular destination (the wave's 64 of them
+		// cover one contiguous KiB at whatever byte phase the row is in).  A chunk that holds padding has to be packed first, and that
+		// costs ~100 VALU instructions which a wave pays whether one lane needs them or all 64 -- on a dense graph (config 5: a gap
+		// every 500 bases) nearly every 1-KiB slot holds ONE or TWO such chunks, and packing "where they are" made this kernel run at
+		// 100 % VALU issue, 512 instructions per wave and row tile against the aligned kernel's 114 (profiles/r05/unaligned_pmc_*).
+		// So the short chunks of the wave's four slots are first QUEUED -- descriptor = chunk | bytes << 10 | destination << 14, one
+		// LDS word each, written under the slot's mask at mbcnt positions: no loop, no branch -- and ONE pass packs them all, a lane
+		// per chunk, reading the chunks back from the row tile (still whole: only this wave rewrites its own slots, in program order).
 		// A slot whose short chunks do not fit the queue any more (kPackQueue entries per wave: what fits beside the tile without
-		// costing the seventh workgroup per CU; tiles inside long insertions) is packed where it is, by the same code: step 2 is one
-		// loop over "the queued ones" and "dense slot k", so the pack code exists once.
+		// costing the seventh workgroup per CU; tiles inside long insertions) is packed where it is, by the same code: stage 2 below
+		// is one loop over "the queued ones" and "dense slot k", so the pack code exists once.
 		u32 offs[kChunksPerThread];
-		u32 fill_bits = 0;                                                       // bit k: my chunk of slot k is short and can be filled up from its successor
 		u32 queued = 0, dense = 0;                                               // wave-uniform
 #pragma unroll
 		for (int k = 0; k < kChunksPerThread; ++k) {
@@ -1670,15 +1662,16 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			u32 const c = cnt[k];
 			u32 const off = slot_begin + incl[k] - c;
 			offs[k] = off;
-			u32 const next_cnt = (u32) __builtin_amdgcn_update_dpp(0, (int) c, 0x130, 0xf, 0xf, true);   // wave_shl:1; lane 63: 0
+			if (16 == c) {
+				if (kNonTemporal) __builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));
+				else *(vec4u_unaligned *) (dst + off) = v[k];
+			}
 			bool const partial = c - 1u < 15u;                                       // 1 ... 15 surviving bytes (an all-padding chunk writes nothing)
-			u32 const fillable = (partial && 16u == next_cnt) ? 1u : 0u;
-			fill_bits |= fillable << k;
 			u64 const mask = __ballot(partial);
 			u32 const n = (u32) __builtin_popcountll(mask);                           // (scalar)
 			bool const fits = queued + n <= kPackQueue;                               // (scalar)
 			u32 const pos = __builtin_amdgcn_mbcnt_hi((u32) (mask >> 32), __builtin_amdgcn_mbcnt_lo((u32) mask, queued));
-			if (partial && pos < kPackQueue) pack_queue[wave][pos] = (u32) (t + kSpliceThreads * k) | c << 10 | off << 14 | fillable << 28;   // (entries of a slot that does not fit are overwritten or ignored)
+			if (partial && pos < kPackQueue) pack_queue[wave][pos] = (u32) (t + kSpliceThreads * k) | c << 10 | off << 14;   // (entries of a slot that does not fit are overwritten or ignored)
 			dense |= (n && !fits) ? 1u << k : 0u;
 			queued = fits ? queued + n : queued;
 		}
@@ -1690,14 +1683,12 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			if (j < (u32) kChunksPerThread) {                                         // (uniform) dense slot j, every lane its own chunk
 				u32 const c = 0 == j ? cnt[0] : 1 == j ? cnt[1] : 2 == j ? cnt[2] : cnt[3];
 				u32 const o = 0 == j ? offs[0] : 1 == j ? offs[1] : 2 == j ? offs[2] : offs[3];
-				e = ((u32) t + (u32) kSpliceThreads * j) | c << 10 | o << 14 | ((fill_bits >> j) & 1u) << 28;
+				e = ((u32) t + (u32) kSpliceThreads * j) | c << 10 | o << 14;
 				active = c - 1u < 15u;
 			}
 			if (!active) continue;
-			u32 const c = (e >> 10) & 15u, idx = e & 1023u;
-			bool const fill = 0u != (e >> 28);
-			vec4u const x = lds[idx];
-			vec4u const nx = lds[fill ? idx + 1u : idx];                           // (the successor: the next lane's chunk of the same slot, full)
+			u32 const c = (e >> 10) & 15u;
+			vec4u const x = lds[e & 1023u];
 			// the chunk's surviving bytes packed to the low end of a 16-B value: v_perm_b32 per dword with the selector table, then the four
 			// pieces shifted together
 			u32 piece[4], len[4];
@@ -1716,43 +1707,16 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			}
 			u64 const lo = (u64) piece[0] | ((u64) piece[1] << (8 * len[0]));
 			u64 const hi = (u64) piece[2] | ((u64) piece[3] << (8 * len[2]));
-			u32 const s8 = 8 * (len[0] + len[1]);                                  // 0 ... 64
-			u64 const packed_lo = lo | (s8 < 64 ? hi << s8 : 0);
-			u64 const packed_hi = 0 == s8 ? 0 : (64 == s8 ? hi : hi >> (64 - s8));
-			if (fill) {
-				// packed | successor << 8 c (128 bits wide, c = 1 ... 15), back into the tile: step 3 stores it with the rest of the slot
-				u64 const next_lo = (u64) nx[0] | (u64) nx[1] << 32, next_hi = (u64) nx[2] | (u64) nx[3] << 32;
-				u32 const sh = 8 * c;                                                // 8 ... 120
-				u64 fill_lo = 0, fill_hi;
-				if (sh < 64) {
-					fill_lo = next_lo << sh;
-					fill_hi = (next_hi << sh) | (next_lo >> (64 - sh));
-				} else {
-					fill_hi = next_lo << (sh - 64);
-				}
-				u64 const out_lo = packed_lo | fill_lo, out_hi = packed_hi | fill_hi;
-				vec4u y;
-				y[0] = (u32) out_lo; y[1] = (u32) (out_lo >> 32); y[2] = (u32) out_hi; y[3] = (u32) (out_hi >> 32);
-				lds[idx] = y;
-			} else {
-				// stored exactly (the bytes around them belong to other chunks' stores)
-				char *p = dst + ((e >> 14) & 0x3FFFu);
-				u64 rest = packed_lo;
-				if (c & 8) { *(u64_unaligned *) p = packed_lo; p += 8; rest = packed_hi; }
-				if (c & 4) { *(u32_unaligned *) p = (u32) rest; p += 4; rest >>= 32; }
-				if (c & 2) { *(u16_unaligned *) p = (u16) rest; p += 2; rest >>= 16; }
-				if (c & 1) *p = (char) rest;
-			}
-		}
-#pragma unroll
-		for (int k = 0; k < kChunksPerThread; ++k) {
-			bool const filled = 0u != ((fill_bits >> k) & 1u);
-			vec4u out16 = v[k];
-			if (filled) out16 = lds[t + kSpliceThreads * k];                         // (written by this wave in step 2)
-			if (filled || 16u == cnt[k]) {
-				if (kNonTemporal) __builtin_nontemporal_store(out16, (vec4u_unaligned *) (dst + offs[k]));
-				else *(vec4u_unaligned *) (dst + offs[k]) = out16;
-			}
+			u32 const sh = 8 * (len[0] + len[1]);                                  // 0 ... 64
+			u64 const packed_lo = lo | (sh < 64 ? hi << sh : 0);
+			u64 const packed_hi = 0 == sh ? 0 : (64 == sh ? hi : hi >> (64 - sh));
+			// ... and stored exactly: at most one store each of 8, 4, 2 and 1 bytes (the bytes around them belong to other chunks' stores)
+			char *p = dst + (e >> 14);
+			u64 rest = packed_lo;
+			if (c & 8) { *(u64_unaligned *) p = packed_lo; p += 8; rest = packed_hi; }
+			if (c & 4) { *(u32_unaligned *) p = (u32) rest; p += 4; rest >>= 32; }
+			if (c & 2) { *(u16_unaligned *) p = (u16) rest; p += 2; rest >>= 16; }
+			if (c & 1) *p = (char) rest;
 		}
 		// wave_sums is rewritten only after the next row's barriers
 	}
