@@ -409,6 +409,16 @@ def test_lines_transpose_indexing_model():
 	assert b"cases ok" in r.stdout and b"with merged column ends" in r.stdout
 
 
+def test_rot_transpose_indexing_model():
+	"""tools/rot_transpose_model.py: the rotating-line transpose kernel's register file, line ends, span bounds and guarded first / last lines,
+	replayed on the CPU: every destination word written exactly once, from the right register, whole lines line-aligned."""
+	import subprocess
+	import sys
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rot_transpose_model.py")], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+	assert r.returncode == 0, r.stderr.decode()[-2000:]
+	assert b"every destination word written once" in r.stdout
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
 	import subprocess
 	import sys

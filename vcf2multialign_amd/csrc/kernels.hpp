@@ -22,6 +22,7 @@ typedef uint64_t u64;
 
 constexpr int kWave = 64;
 typedef u32 vec4u __attribute__((ext_vector_type(4)));   // native 16-B vector (nontemporal builtins need it)
+typedef vec4u vec4u_unaligned8 __attribute__((aligned(8)));   // a 16-B access at an 8-byte aligned address (legal on gfx950: unaligned access mode)
 
 // ---------------------------------------------------------------------------------------------
 // Geometry of the aligned splice.
@@ -699,6 +700,185 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_lines_kernel(
 		for (int a = 0; a < kA; ++a)
 #pragma unroll
 			for (int c = 0; c < 16; ++c) y_prev[a][c] = y_cur[a][c];
+	}
+}
+
+
+// Rotating-line streaming transpose ("rot" kernel, round 5).
+//
+// The whole-line kernel above pays for its whole lines with 64 registers of carried words (y_prev + y_cur) on top of everything else:
+// 146-158 VGPRs, ONE workgroup of 8 waves per CU, 16 KB of loads in flight per CU.  But a destination column needs no carried block: lane l
+// of a tile keeps the words of its destination column in a file of 16 registers indexed by the step (y[c] = the word of column group
+// cg = 16 b + c, overwritten 16 steps later), and column r's line ends at the steps with (base + r * pitch + cg) % 16 == 15 -- one fixed c per
+// lane, done_at.  At that step the 16 registers ARE the line, rotated: word j of the line is y[(c + 1 + j) % 16], a compile-time index in
+// the unrolled step.  So every step the (four, for an odd pitch) lanes whose lines have just ended store them, each lane its own 128 bytes as
+// 16-byte pieces straight from its registers (eight global_store_dwordx4 with immediate offsets; a line that starts at an odd register takes
+// seven of them and two 8-byte ones, so that every piece is a naturally aligned register pair): no slab, no LDS on the way out, the stores
+// spread evenly over the stream, and the L2 receives each line's pieces back to back from one wave.  32 registers of state per tile.
+// A span's first 15 steps and the up to 15 lines still open at its end hold words of the neighbouring spans: those lines go out through a
+// small per-wave LDS slab, word by word under the span's bounds (the neighbours write the rest), as do steps past the matrix.
+// CPU replay of the indexing: tools/rot_transpose_model.py (also a -m "not gpu" test).
+template <int kWaves, int kDepth, int kTsR>
+__global__ __launch_bounds__(64 * kWaves) void transpose_bits_rot_kernel(
+	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,
+	u32 n_panels, u32 n_spans, u32 span_blocks, u32 items_per_xcd, u32 panel_fastest)
+{
+	constexpr int kThreads = 64 * kWaves, kA = kTsR / kWaves, kPer = (64 * kTsR) / kThreads;
+	static_assert(kTsR % kWaves == 0 && 16 % kDepth == 0 && (64 * kTsR) % kThreads == 0, "geometry");
+	__shared__ u64 in[2][64][kTsR + 1];
+	__shared__ u64 slab[kWaves][4][17];          // the guarded flavour: four lines at a time, [line][register of the file]
+	__shared__ u32 slab_lane[kWaves][4];
+
+	u64 item64;
+	if (!xcd_chunked_item(blockIdx.x, (u64) n_panels * n_spans, items_per_xcd, item64)) return;   // whole workgroup
+	u32 const item = (u32) item64;
+	u32 const panel = panel_fastest ? item % n_panels : item / n_spans;
+	u32 const span = panel_fastest ? item / n_panels : item % n_spans;
+
+	int const t = threadIdx.x, lane = t & 63;
+	int const wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	u64 const rw0 = (u64) panel * kTsR;
+	u32 const n_blocks = ((u32) DW + 15) / 16;
+	u32 const b_lo = span * span_blocks, b_hi = (b_lo + span_blocks < n_blocks) ? b_lo + span_blocks : n_blocks;
+	u32 const span_lo = 16 * b_lo, span_hi = (16 * b_hi < (u32) DW) ? 16 * b_hi : (u32) DW;
+	u32 const n_span_blocks = b_hi - b_lo;
+
+	// source: as in the lines kernel (every load unconditional from an address clamped into the matrix)
+	u32 src_off[kPer];
+#pragma unroll
+	for (int k = 0; k < kPer; ++k) {
+		int const idx = t + kThreads * k;
+		u64 const w = rw0 + idx % kTsR;
+		src_off[k] = (u32) (((u64) (idx / kTsR) * src_pitch + (w < SW ? w : SW - 1)) * 8);
+	}
+	u32 const cg_max = (u32) DW - 1;
+	auto const fetch = [&](u64 (&st)[kPer], u32 cg) {
+		char const *const base = reinterpret_cast<char const *>(src + (u64) (cg < cg_max ? cg : cg_max) * 64 * src_pitch);   // uniform
+#pragma unroll
+		for (int k = 0; k < kPer; ++k) st[k] = *reinterpret_cast<u64 const *>(base + src_off[k]);
+	};
+	auto const stash = [&](int buf, u64 const (&st)[kPer]) {
+#pragma unroll
+		for (int k = 0; k < kPer; ++k) {
+			int const idx = t + kThreads * k;
+			in[buf][idx / kTsR][idx % kTsR] = st[k];
+		}
+	};
+
+	// destination: per tile, the lane's column, the step (mod 16) at which its lines end, and the word address of the line that ends at
+	// the current step (advanced by one word per step)
+	u32 done_at[kA];
+	u64 *line_ptr[kA];
+	bool col_ok[kA];
+#pragma unroll
+	for (int a = 0; a < kA; ++a) {
+		u64 const rw = rw0 + (u64) (kA * wave + a);
+		col_ok[a] = rw < SW;                                           // (wave-uniform)
+		u64 *const col = dst + (rw * 64 + (u64) lane) * dst_pitch;
+		done_at[a] = (15u - (u32) ((reinterpret_cast<uintptr_t>(col) >> 3) & 15u)) & 15u;
+		line_ptr[a] = col + span_lo - 15;                              // (never dereferenced outside [span_lo, span_hi))
+	}
+
+	u64 y[kA][16];
+#pragma unroll
+	for (int a = 0; a < kA; ++a)
+#pragma unroll
+		for (int c = 0; c < 16; ++c) y[a][c] = 0;
+
+	// the guarded flavour: the lines that end at step c (cg = the step's column group), four at a time through the slab, every word under
+	// the span's bounds.  `c` may be a run-time value: the whole register file goes into the slab, the reader knows which register is which word.
+	auto const emit_guarded = [&](int a, u32 c, u32 cg) {
+		bool const done = done_at[a] == c;
+		u64 const mask = __ballot(done);
+		u32 const n = (u32) __builtin_popcountll(mask);                  // (uniform)
+		u32 const rank = __builtin_amdgcn_mbcnt_hi((u32) (mask >> 32), __builtin_amdgcn_mbcnt_lo((u32) mask, 0u));
+		u64 const tile_col0 = (rw0 + (u64) (kA * wave + a)) * 64;
+		for (u32 base = 0; base < n; base += 4) {
+			if (done && rank - base < 4u) {
+#pragma unroll
+				for (int w = 0; w < 16; ++w) slab[wave][rank - base][w] = y[a][w];
+				slab_lane[wave][rank - base] = (u32) lane;
+			}
+			__builtin_amdgcn_wave_barrier();                            // (LDS operations of one wave execute in order)
+			u32 const rk = (u32) lane >> 4, w = (u32) lane & 15u;
+			if (base + rk < n) {
+				u32 const j = (w - c - 1u) & 15u;                        // register w holds word j of the line
+				long long const k = (long long) cg - 15 + (long long) j; // column-relative word
+				if (k >= (long long) span_lo && k < (long long) span_hi) {
+					u64 const r = tile_col0 + slab_lane[wave][rk];
+					dst[r * dst_pitch + (u64) k] = slab[wave][rk][w];
+				}
+			}
+			__builtin_amdgcn_wave_barrier();
+		}
+	};
+
+	lean_butterfly const butterfly(lane);
+	u64 stage[kDepth][kPer];
+	auto const group_of = [&](u32 st) -> u32 { u32 const cg = span_lo + st; return cg < cg_max ? cg : cg_max; };
+#pragma unroll
+	for (int j = 0; j < kDepth; ++j) fetch(stage[j], group_of(j));
+	stash(0, stage[0]);
+	for (u32 i = 0; i < n_span_blocks; ++i) {
+#pragma unroll
+		for (int c = 0; c < 16; ++c) {
+			u32 const cg = span_lo + 16 * i + c;
+			asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // (see the ring kernel: the wait __syncthreads() implies can get lost on a loop's back edge)
+			__syncthreads();                                           // in[c & 1] is complete; everyone is done with in[(c + 1) & 1]
+			fetch(stage[c % kDepth], group_of(16 * i + c + kDepth));
+			bool const real = cg < span_hi;                            // (uniform; false only past the matrix's last column group)
+			if (real) {
+#pragma unroll
+				for (int a = 0; a < kA; ++a) y[a][c] = butterfly(in[c & 1][lane][kA * wave + a]);
+			}
+			stash((c + 1) & 1, stage[(c + 1) % kDepth]);
+#pragma unroll
+			for (int a = 0; a < kA; ++a) {
+				// From the span's second block on, a line that ends at a real step lies inside the span: the fast flavour.  (The first block's
+				// lines, the steps past the matrix and the lines still open at the end go through emit_guarded below.)
+				if (real && i >= 1 && col_ok[a] && done_at[a] == (u32) c) {
+					// the line, from the rotated register file: word j = y[(c + 1 + j) % 16]; every piece a naturally aligned register pair
+					u64 *const p = line_ptr[a];
+					if (c & 1) {
+#pragma unroll
+						for (int m = 0; m < 8; ++m) {
+							u64 const lo = y[a][(c + 1 + 2 * m) & 15], hi = y[a][(c + 2 + 2 * m) & 15];
+							vec4u v;
+							v[0] = (u32) lo; v[1] = (u32) (lo >> 32); v[2] = (u32) hi; v[3] = (u32) (hi >> 32);
+							*reinterpret_cast<vec4u *>(p + 2 * m) = v;
+						}
+					} else {
+						p[0] = y[a][(c + 1) & 15];
+#pragma unroll
+						for (int m = 0; m < 7; ++m) {
+							u64 const lo = y[a][(c + 2 + 2 * m) & 15], hi = y[a][(c + 3 + 2 * m) & 15];
+							vec4u v;
+							v[0] = (u32) lo; v[1] = (u32) (lo >> 32); v[2] = (u32) hi; v[3] = (u32) (hi >> 32);
+							*reinterpret_cast<vec4u_unaligned8 *>(p + 1 + 2 * m) = v;
+						}
+						p[15] = y[a][c & 15];
+					}
+				}
+				line_ptr[a] += 1;
+			}
+			__builtin_amdgcn_sched_barrier(0);                         // (the steps stay apart in the schedule, as in the streaming kernels)
+		}
+		if (0 == i) {
+			// The first block's lines, all at once behind its steps: the words of a line that ended at step c which belong to this span are
+			// y[0 .. c], still where they were put (the registers of the block before the span hold nothing of ours: the span before writes them).
+			for (u32 c = 0; c < 16 && span_lo + c < span_hi; ++c) {
+#pragma unroll
+				for (int a = 0; a < kA; ++a)
+					if (col_ok[a]) emit_guarded(a, c, span_lo + c);
+			}
+		}
+	}
+	// the lines still open at the span's end (and the steps past the matrix's last column group): their words before span_hi
+	for (u32 e = 0; e < 15; ++e) {
+		u32 const cg = span_hi + e;
+#pragma unroll
+		for (int a = 0; a < kA; ++a)
+			if (col_ok[a]) emit_guarded(a, cg & 15u, cg);
 	}
 }
 
