@@ -704,7 +704,10 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_lines_kernel(
 }
 
 
-// Rotating-line streaming transpose ("rot" kernel, round 5).
+#ifdef V2M_TUNING_BUILD
+// Rotating-line streaming transpose ("rot" kernel, round 5): an experiment that LOST and lives in the tuning build only
+// (profiles/r05/transpose_rot8_experiment.txt: 0.51 / 0.75 ms on the dense config-3 matrix against lines8's 0.30 / 0.32 -- a line stored as eight
+// 16-byte pieces by ONE lane is eight requests to the L2 where a coalesced store is one).
 //
 // The whole-line kernel above pays for its whole lines with 64 registers of carried words (y_prev + y_cur) on top of everything else:
 // 146-158 VGPRs, ONE workgroup of 8 waves per CU, 16 KB of loads in flight per CU.  But a destination column needs no carried block: lane l
@@ -881,6 +884,7 @@ __global__ __launch_bounds__(64 * kWaves) void transpose_bits_rot_kernel(
 			if (col_ok[a]) emit_guarded(a, cg & 15u, cg);
 	}
 }
+#endif   // V2M_TUNING_BUILD
 
 
 // ---------------------------------------------------------------------------------------------

@@ -345,7 +345,8 @@ int launch_transpose_lines(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 S
 	return V2M_OK;
 }
 
-// The rotating-line kernel: kTsR row-words per workgroup on kWaves waves, spans of `span_blocks` blocks of 16 column groups (0: chosen here:
+#ifdef V2M_TUNING_BUILD
+// The rotating-line kernel (tuning build only: it lost): kTsR row-words per workgroup on kWaves waves, spans of `span_blocks` blocks of 16 column groups (0: chosen here:
 // the longest of 32 / 16 / 8 / 4 blocks that still leaves 2048 workgroups -- with ~80 VGPRs three workgroups of 8 waves share a CU).
 template <int kWaves, int kDepth, int kTsR>
 int launch_transpose_rot(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, u64 span_blocks, bool xcd, int order)
@@ -368,6 +369,7 @@ int launch_transpose_rot(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP,
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	return V2M_OK;
 }
+#endif   // V2M_TUNING_BUILD
 
 // Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "lines8[:K]" (spans of K blocks), "ring:R,W,S,D[,K[,slow|nt]]" (tuning build; slow = ds_bpermute
 // butterfly, nt = nontemporal loads and stores); trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks, "/pf" / "/sf" make the row
@@ -413,19 +415,19 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (the product build has 8x8, stream16 and lines8; the rest needs -DV2M_TUNING_BUILD)");
 	}
 	if (shape == "stream16") return launch_transpose_stream<4, 64>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
+#ifdef V2M_TUNING_BUILD
 	if (0 == shape.compare(0, 4, "rot8")) {
-		// "rot8[:K[,V]]": spans of K blocks (0 / absent = chosen per shape); V = geometry variant (tuning build)
+		// "rot8[:K[,V]]": spans of K blocks (0 / absent = chosen per shape); V = geometry variant
 		int K(0), V(8);
 		if (shape.size() > 4 && (':' != shape[4] || std::sscanf(shape.c_str() + 5, "%d,%d", &K, &V) < 1 || K < 0)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
 		if (8 == V) return launch_transpose_rot<8, 4, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
-#ifdef V2M_TUNING_BUILD
 		if (88 == V) return launch_transpose_rot<8, 8, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);            // 8 steps of prefetch
 		if (4 == V) return launch_transpose_rot<4, 4, 8>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);             // 4 waves, two tiles each
 		if (16 == V) return launch_transpose_rot<8, 4, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);           // 16 row-words (128-B source runs), two tiles per wave
 		if (1616 == V) return launch_transpose_rot<16, 4, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);        // 16 row-words on 16 waves
-#endif
-		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (needs -DV2M_TUNING_BUILD)");
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
 	}
+#endif
 	if (0 == shape.compare(0, 6, "lines8")) {
 		// "lines8[:K]": spans of K blocks (0 / absent = chosen per shape); the tuning build also has "lines8:K,V" with V = another geometry
 		int K(0), V(8);
