@@ -24,9 +24,17 @@ namespace v2m {
 
 constexpr int kPbwtThreads = 1024;                    // (512 / 256 threads with twice / four times the copies each: 40.5 + 22.0 ms / 71.7 + 39.9 ms at config 4 against 30.5 + 17.3)
 constexpr int kPbwtWaves = kPbwtThreads / 64;
-constexpr int kPbwtMaxCopies = 8192;                  // chromosome copies a workgroup can walk (LDS-resident state)
-constexpr int kPbwtPerThread = kPbwtMaxCopies / kPbwtThreads;
-constexpr int kPbwtHashSlots = 4096;                  // distinct candidate bins per candidate node: far fewer in practice
+// Chromosome copies a workgroup can walk: its pBWT state lives in LDS -- order (u16) and divergence (u32), ONE array each (a step reads all
+// of its copies into registers, passes a barrier and writes them back to their new places, so no second buffer is needed: round 5; with two
+// the state of 8192 copies was all that fit).  The kernels are instantiated per copies-per-thread count and size their arrays for it:
+// the cut search's kernel (state + the candidates' hash and bins) reaches 20 480 copies -- BASELINE config 5's 20 000 -- and the matching's
+// kernel (state + two class arrays + the joined classes' starts) 12 288.
+constexpr int kPbwtMaxCopies = 20480;
+constexpr int kPbwtMaxCopiesRecords = 12288;
+constexpr int kPbwtPerThread = kPbwtMaxCopies / kPbwtThreads;          // 20
+constexpr int kPbwtPerThreadRecords = kPbwtMaxCopiesRecords / kPbwtThreads;   // 12
+// distinct candidate bins per candidate node: about a hundred in practice, at most kPbwtMaxBins; the largest instantiations take the smaller table
+template <int kPer> constexpr int pbwt_hash_slots() { return kPer > 8 ? 2048 : 4096; }
 constexpr int kPbwtMaxBins = kPbwtThreads;            // more distinct bins than this at one candidate (a thread per bin): the chunk is left to the host
 
 // __syncthreads() with the LDS wait spelled out: on loop back edges hipcc (ROCm 7.2) has emitted the barrier without the
@@ -157,17 +165,18 @@ struct pbwt_column_stream {
 };
 
 // Before the first step: edge `edge`'s words into column[0], the next edge's on their way.  The caller's next barrier publishes them.
+template <int kColumnWords>
 __device__ __forceinline__ pbwt_column_stream pbwt_prime_columns(uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge, uint32_t edge_limit,
-	uint64_t (*column)[kPbwtMaxCopies / 64], int t)
+	uint64_t (*column)[kColumnWords], int t)
 {
 	if ((uint32_t) t < words_per_edge) column[0][t] = pbwt_fetch_column(paths_by_edge, words_per_edge, edge, edge_limit, t);
 	return pbwt_column_stream{pbwt_fetch_column(paths_by_edge, words_per_edge, edge + 1u, edge_limit, t), 0};
 }
 
-// One step of Durbin's algorithm 2 for edge `edge` (pbwt.hh:77-134) by the whole workgroup: state order[cur] / divergence[cur]
-// -> order[cur ^ 1] / divergence[cur ^ 1].  Thread t owns `my_count` <= kPer <= kPbwtPerThread consecutive copies of the order from
+// One step of Durbin's algorithm 2 for edge `edge` (pbwt.hh:77-134) by the whole workgroup, in place: every thread has its copies in registers
+// before the step's first barrier and writes them to their new places after it.  Thread t owns `my_count` <= kPer <= kPbwtPerThread consecutive copies of the order from
 // my_begin on (kPer = ceil(copies / 1024) is a template parameter of the kernels: the per-copy loops unroll without a branch or a dead slot).  Returns how many copies do NOT use the edge (workgroup-uniform).  TWO barriers; the
-// caller flips `cur`.
+// state is updated in place.
 //   pass 1  the thread's copies, their divergence values and their bits of the edge into registers; what the run does to the zero
 //           count and to the two running maxima, folded locally; an inclusive scan of that over the wave (DPP)      -- barrier --
 //   pass 2  the 16 waves' totals scanned by every wave for itself (one LDS read + a row scan), the lane's exclusive prefix from its
@@ -178,12 +187,12 @@ __device__ __forceinline__ pbwt_column_stream pbwt_prime_columns(uint64_t const 
 template <int kPer>
 __device__ __forceinline__ uint32_t pbwt_step(
 	uint64_t const *__restrict__ paths_by_edge, uint32_t words_per_edge, uint32_t edge, uint32_t edge_limit, pbwt_column_stream &cols,
-	unsigned short (*order)[kPbwtMaxCopies], uint32_t (*divergence)[kPbwtMaxCopies], uint64_t (*column)[kPbwtMaxCopies / 64], uint4 *wave_items,
-	int cur, uint32_t my_begin, uint32_t my_count, int t, int lane, int wave)
+	unsigned short *order, uint32_t *divergence, uint64_t (*column)[kPer * (kPbwtThreads / 64)], uint4 *wave_items,
+	uint32_t my_begin, uint32_t my_count, int t, int lane, int wave)
 {
 	constexpr uint32_t per = kPer;
-	unsigned short const *const ord = order[cur];
-	uint32_t const *const dv = divergence[cur];
+	unsigned short const *const ord = order;
+	uint32_t const *const dv = divergence;
 	uint64_t const *const col = column[cols.buf];
 	// A slot past the thread's last copy (only the last threads have any) counts as a copy of class 1 with divergence 0: it adds no zero,
 	// leaves p as it is, and what it does to q only reaches threads that hold no copy at all.  So nothing below selects on validity but the
@@ -193,7 +202,7 @@ __device__ __forceinline__ uint32_t pbwt_step(
 #pragma unroll
 	for (int k = 0; k < kPer; ++k) {
 		if ((uint32_t) k < per) {                                           // (uniform)
-			copy[k] = ord[my_begin + k];                                     // (my_begin + k < 1024 * per <= kPbwtMaxCopies: inside the array either way)
+			copy[k] = ord[my_begin + k];                                     // (my_begin + k < 1024 * per = the arrays' size: inside either way)
 			d[k] = dv[my_begin + k];
 		}
 	}
@@ -239,8 +248,8 @@ __device__ __forceinline__ uint32_t pbwt_step(
 	// second pass: place the copies (stable partition) with their new divergence values
 	uint32_t p = chain_apply(before.p, edge + 2u), q = chain_apply(before.q, edge + 2u);   // biased edge + 1 (pbwt.hh:93)
 	uint32_t zero_at = before.zeros, one_at = zeros_total + (my_begin - before.zeros);
-	unsigned short *const out_ord = order[cur ^ 1];
-	uint32_t *const out_dv = divergence[cur ^ 1];
+	unsigned short *const out_ord = order;                              // (everybody's reads lie before the barrier above)
+	uint32_t *const out_dv = divergence;
 #pragma unroll
 	for (int k = 0; k < kPer; ++k) {
 		if ((uint32_t) k < per) {
@@ -266,11 +275,12 @@ __device__ __forceinline__ uint32_t pbwt_step(
 }
 
 // Puts `count` copies into the bin's slot of the candidate's hash table (claiming a slot for a bin seen for the first time).
+template <int kSlots>
 __device__ __forceinline__ void pbwt_bin_add(uint32_t *hash_key, uint32_t *hash_count, uint32_t *bin_slot, uint32_t *n_bins_s, uint32_t *failed_s, uint32_t bin, uint32_t count)
 {
-	uint32_t slot = (bin * 2654435761u) >> 20 & (uint32_t) (kPbwtHashSlots - 1);
+	uint32_t slot = (bin * 2654435761u) >> 20 & (uint32_t) (kSlots - 1);
 	bool placed = false;
-	for (int probe = 0; probe < kPbwtHashSlots && !placed; ++probe) {   // (bounded: a full table ends the chunk)
+	for (int probe = 0; probe < kSlots && !placed; ++probe) {   // (bounded: a full table ends the chunk)
 		uint32_t const seen = atomicCAS(&hash_key[slot], 0u, bin + 1u);
 		if (0u == seen) {                                       // claimed a free slot
 			uint32_t const k = atomicAdd(n_bins_s, 1u);
@@ -279,7 +289,7 @@ __device__ __forceinline__ void pbwt_bin_add(uint32_t *hash_key, uint32_t *hash_
 		} else if (seen == bin + 1u) {
 			placed = true;
 		} else {
-			slot = (slot + 1u) & (uint32_t) (kPbwtHashSlots - 1);
+			slot = (slot + 1u) & (uint32_t) (kSlots - 1);
 		}
 	}
 	if (placed) atomicAdd(&hash_count[slot], count);
@@ -299,12 +309,13 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 	uint64_t *__restrict__ trial_end,                     // [n_candidates]: trials of the chunk up to and including this candidate
 	uint32_t *__restrict__ chunk_status)                  // [n_chunks]: 0 = done, 1 = left to the host (too many bins / trials)
 {
-	__shared__ unsigned short order[2][kPbwtMaxCopies];
-	__shared__ uint32_t divergence[2][kPbwtMaxCopies];
-	__shared__ uint64_t column[2][kPbwtMaxCopies / 64];
+	constexpr int kCopies = kPer * kPbwtThreads, kHashSlots = pbwt_hash_slots<kPer>();
+	__shared__ unsigned short order[kCopies];
+	__shared__ uint32_t divergence[kCopies];
+	__shared__ uint64_t column[2][kCopies / 64];
 	__shared__ uint4 wave_items[kPbwtWaves];
-	__shared__ uint32_t hash_key[kPbwtHashSlots];         // bin + 1; 0 = free
-	__shared__ uint32_t hash_count[kPbwtHashSlots];
+	__shared__ uint32_t hash_key[kHashSlots];             // bin + 1; 0 = free
+	__shared__ uint32_t hash_count[kHashSlots];
 	__shared__ uint32_t bin_slot[kPbwtMaxBins];           // hash slots in use, in claiming order
 	__shared__ __attribute__((aligned(16))) uint32_t bin_key[kPbwtMaxBins], bin_packed[kPbwtMaxBins];   // the candidate's bins, dense: key; copies | emits << 16
 	__shared__ uint32_t bin_sum[kPbwtMaxBins];            // per bin: the same two fields summed over the bins with a larger key
@@ -319,14 +330,13 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 	uint32_t const my_count = my_end - my_begin;
 
 	for (uint32_t i = t; i < n_copies; i += kPbwtThreads) {
-		order[0][i] = (unsigned short) start_order[(uint64_t) chunk * n_copies + i];
-		divergence[0][i] = start_divergence[(uint64_t) chunk * n_copies + i];
+		order[i] = (unsigned short) start_order[(uint64_t) chunk * n_copies + i];
+		divergence[i] = start_divergence[(uint64_t) chunk * n_copies + i];
 	}
-	for (uint32_t i = t; i < (uint32_t) kPbwtHashSlots; i += kPbwtThreads) { hash_key[i] = 0; hash_count[i] = 0; }
+	for (uint32_t i = t; i < (uint32_t) kHashSlots; i += kPbwtThreads) { hash_key[i] = 0; hash_count[i] = 0; }
 	if (t == 0) { n_bins_s = 0; failed_s = 0; emitted_s = 0; smallest_s = 0xFFFFFFFFu; }
-	int cur = 0;
 	uint32_t edge = cand_begin < cand_end ? cand_edge[cand_begin] : 0;
-	pbwt_column_stream cols = pbwt_prime_columns(paths_by_edge, words_per_edge, edge, n_edges, column, t);
+	pbwt_column_stream cols = pbwt_prime_columns<kCopies / 64>(paths_by_edge, words_per_edge, edge, n_edges, column, t);
 	pbwt_block_sync();
 
 	uint64_t n_trials = 0;                                 // (kept by every thread: all of them see the same counts)
@@ -337,13 +347,12 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 		// ---- the edges before this candidate's node (find_cut_positions.cc:170-176 over pbwt.hh:77-134) -----------------
 		uint32_t const upto = cand_edge[cand];
 		for (; edge < upto; ++edge) {
-			pbwt_step<kPer>(paths_by_edge, words_per_edge, edge, n_edges, cols, order, divergence, column, wave_items, cur, my_begin, my_count, t, lane, wave);
-			cur ^= 1;
+			pbwt_step<kPer>(paths_by_edge, words_per_edge, edge, n_edges, cols, order, divergence, column, wave_items, my_begin, my_count, t, lane, wave);
 		}
 
 		// ---- the candidate (find_cut_positions.cc:134-165) ---------------------------------------------------------------
 		uint32_t const next = (uint32_t) cand;
-		uint32_t const *const dv = divergence[cur];
+		uint32_t const *const dv = divergence;
 		// the largest divergence value and how many copies hold it
 		uint32_t d[kPer];
 		uint32_t my_max = 0;
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_trials_kernel(
 #pragma unroll
 		for (int k = 0; k < kPer; ++k) {
 			if ((uint32_t) k < per) {
-				if (0xFFFFFFFFu != bin[k]) pbwt_bin_add(hash_key, hash_count, bin_slot, &n_bins_s, &failed_s, bin[k], 1u);
+				if (0xFFFFFFFFu != bin[k]) pbwt_bin_add<kHashSlots>(hash_key, hash_count, bin_slot, &n_bins_s, &failed_s, bin[k], 1u);
 			}
 		}
 		my_cnt = wave_inclusive_add(my_cnt);
@@ -534,13 +543,15 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	uint32_t *__restrict__ rec_distinct, uint32_t *__restrict__ rec_first_class, uint32_t *__restrict__ rec_first_is_ref,   // [n_cuts]
 	uint32_t *__restrict__ chunk_status)
 {
-	__shared__ unsigned short order[2][kPbwtMaxCopies];
-	__shared__ uint32_t divergence[2][kPbwtMaxCopies];
-	__shared__ uint64_t column[2][kPbwtMaxCopies / 64];
+	static_assert(kPer <= kPbwtPerThreadRecords, "the matching's kernel holds two class arrays and the joined classes' starts beside the state");
+	constexpr int kCopies = kPer * kPbwtThreads;
+	__shared__ unsigned short order[kCopies];
+	__shared__ uint32_t divergence[kCopies];
+	__shared__ uint64_t column[2][kCopies / 64];
 	__shared__ uint4 wave_items[kPbwtWaves];
 	__shared__ uint4 class_items[kPbwtWaves];
-	__shared__ unsigned short copy_class[2][kPbwtMaxCopies];      // per copy: the representative of its class at the last / the previous cut
-	__shared__ unsigned short span_start_index[kPbwtMaxCopies];   // per joined class: where it starts in the order
+	__shared__ unsigned short copy_class[2][kCopies];             // per copy: the representative of its class at the last / the previous cut
+	__shared__ unsigned short span_start_index[kCopies];          // per joined class: where it starts in the order
 
 	int const t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	uint32_t const chunk = blockIdx.x;
@@ -552,21 +563,20 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	uint32_t const my_count = my_end - my_begin;
 
 	for (uint32_t i = t; i < n_copies; i += kPbwtThreads) {
-		order[0][i] = (unsigned short) start_order[(uint64_t) chunk * n_copies + i];
-		divergence[0][i] = start_divergence[(uint64_t) chunk * n_copies + i];
+		order[i] = (unsigned short) start_order[(uint64_t) chunk * n_copies + i];
+		divergence[i] = start_divergence[(uint64_t) chunk * n_copies + i];
 		copy_class[0][i] = (unsigned short) kPbwtNoClass;
 		copy_class[1][i] = (unsigned short) kPbwtNoClass;
 	}
-	int cur = 0, rhs = 0;                                  // copy_class[rhs]: the classes the last cut left behind
+	int rhs = 0;                                           // copy_class[rhs]: the classes the last cut left behind
 	uint32_t edge = start_edge[chunk];
-	pbwt_column_stream cols = pbwt_prime_columns(paths_by_edge, words_per_edge, edge, n_edge_columns, column, t);
+	pbwt_column_stream cols = pbwt_prime_columns<kCopies / 64>(paths_by_edge, words_per_edge, edge, n_edge_columns, column, t);
 	pbwt_block_sync();
 
 	// up to the cut before the chunk's first one; the classes it left behind (founder.cc:scan_cut_chunk)
 	uint64_t const start_cut = cut_begin - 1;
 	for (uint32_t const upto = cut_edge[start_cut]; edge < upto; ++edge) {
-		pbwt_step<kPer>(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, cur, my_begin, my_count, t, lane, wave);
-		cur ^= 1;
+		pbwt_step<kPer>(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, my_begin, my_count, t, lane, wave);
 	}
 
 	// The classes of a threshold: every copy's representative = the copy at the last boundary at or before it.
@@ -576,8 +586,8 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	// Two barriers.  (What a call leaves in class_items / span_start_index / copy_class is only rewritten behind the first barrier of
 	// whatever runs next -- a pBWT step or another call -- and every read of it here lies before this call's last one.)
 	auto const classes_at_cut = [&](uint32_t block_threshold, bool with_span, uint32_t span_threshold, uint32_t &distinct_out) -> bool {
-		unsigned short const *const ord = order[cur];
-		uint32_t const *const dv = divergence[cur];
+		unsigned short const *const ord = order;
+		uint32_t const *const dv = divergence;
 		uint32_t copy[kPer], d[kPer];
 		class_scan_item mine{0u, 0u, 0u};
 #pragma unroll
@@ -648,8 +658,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	bool first_is_ref = true;
 	for (uint64_t cut = cut_begin; cut < cut_end; ++cut) {
 		for (uint32_t const upto = cut_edge[cut]; edge < upto; ++edge) {
-			uint32_t const zeros = pbwt_step<kPer>(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, cur, my_begin, my_count, t, lane, wave);
-			cur ^= 1;
+			uint32_t const zeros = pbwt_step<kPer>(paths_by_edge, words_per_edge, edge, n_edge_columns, cols, order, divergence, column, wave_items, my_begin, my_count, t, lane, wave);
 			// the copy that is first in the order now uses the edge exactly when no copy does not (:454-462)
 			first_is_ref = first_is_ref && 0u != zeros;
 		}
@@ -662,7 +671,7 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 		if (t == 0) {
 			rec_pool_end[cut] = n_pool;
 			rec_distinct[cut] = distinct;
-			rec_first_class[cut] = order[cur][0];
+			rec_first_class[cut] = order[0];
 			rec_first_is_ref[cut] = first_is_ref ? 1u : 0u;
 		}
 		first_is_ref = true;

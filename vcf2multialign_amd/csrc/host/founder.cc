@@ -1053,7 +1053,7 @@ bool find_matchings(
 	if (0 == threads) threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
 	auto const &transposed(graph.paths_by_chrom_copy_and_edge);
 	bool const have_transposed(transposed.cols >= copies && transposed.rows >= graph.edge_count() && !transposed.words.empty());
-	if (!walker || cut_positions.size() <= 2 || copies > walker->max_copies() || 0 == graph.edge_count() || !have_transposed)
+	if (!walker || cut_positions.size() <= 2 || copies > walker->max_copies_records() || 0 == graph.edge_count() || !have_transposed)
 		return find_matchings(graph, cut_positions, founder_count, keep_ref_edges, assigned, threads);
 	return find_matchings_walked(graph, cut_positions, founder_count, keep_ref_edges, assigned, threads, *walker);
 }

@@ -36,6 +36,8 @@ u32 find_cut_positions(variant_graph const &graph, u64 min_distance, std::vector
 struct founder_walker {
 	virtual ~founder_walker() {}
 	virtual u64 max_copies() const = 0;
+	// ... and in records() (the matching's walks keep two class arrays beside the state: fewer copies fit)
+	virtual u64 max_copies_records() const { return max_copies(); }
 	// how many chunks it likes to walk at once (one workgroup each on the GPU: a couple per compute unit); 0 = no preference
 	virtual std::size_t preferred_chunks() const { return 0; }
 	// cand_edge / cand_aligned: all candidates; chunk_first: n_chunks + 1 candidate indices; start_*: [n_chunks][n_copies];

@@ -950,20 +950,30 @@ int check_batch(v2m_ctx *ctx, v2m_row_batch const *rows, u32 flags)
 // =============================================================================================
 namespace {
 
-// Calls launch(std::integral_constant<int, ceil(n_copies / kPbwtThreads)>): the founder kernels' instantiation for this many copies per thread.
-template <typename t_launch>
-void pbwt_dispatch_per_thread(u64 n_copies, t_launch &&launch)
+// Calls launch(std::integral_constant<int, kPer>) with the founder kernels' instantiation for `copies` chromosome copies (the larger of the copies
+// walked and the bound matrix's columns: a thread owns kPer copies of the order, and the LDS arrays -- the staged edge column among them -- hold
+// 1024 * kPer): every count up to 8, then 10, 12, 16 and 20 (kMaxPer = the kernel's largest: 20 for the cut search, 12 for the matching).
+template <int kMaxPer, typename t_launch>
+void pbwt_dispatch_per_thread(u64 copies, t_launch &&launch)
 {
-	static_assert(8 == v2m::kPbwtPerThread, "one case per copies-per-thread count");
-	switch ((n_copies + v2m::kPbwtThreads - 1) / v2m::kPbwtThreads) {
-		case 1: launch(std::integral_constant<int, 1>{}); break;
-		case 2: launch(std::integral_constant<int, 2>{}); break;
-		case 3: launch(std::integral_constant<int, 3>{}); break;
-		case 4: launch(std::integral_constant<int, 4>{}); break;
-		case 5: launch(std::integral_constant<int, 5>{}); break;
-		case 6: launch(std::integral_constant<int, 6>{}); break;
-		case 7: launch(std::integral_constant<int, 7>{}); break;
-		default: launch(std::integral_constant<int, 8>{}); break;   // (n_copies <= kPbwtMaxCopies was checked)
+	static_assert(20 == v2m::kPbwtPerThread && 12 == v2m::kPbwtPerThreadRecords && (20 == kMaxPer || 12 == kMaxPer), "one case per instantiation");
+	u64 const per((copies + v2m::kPbwtThreads - 1) / v2m::kPbwtThreads);      // (<= kMaxPer was checked)
+	switch (per) {
+		case 0: case 1: launch(std::integral_constant<int, 1>{}); return;
+		case 2: launch(std::integral_constant<int, 2>{}); return;
+		case 3: launch(std::integral_constant<int, 3>{}); return;
+		case 4: launch(std::integral_constant<int, 4>{}); return;
+		case 5: launch(std::integral_constant<int, 5>{}); return;
+		case 6: launch(std::integral_constant<int, 6>{}); return;
+		case 7: launch(std::integral_constant<int, 7>{}); return;
+		case 8: launch(std::integral_constant<int, 8>{}); return;
+		case 9: case 10: launch(std::integral_constant<int, 10>{}); return;
+		case 11: case 12: launch(std::integral_constant<int, 12>{}); return;
+		default: break;
+	}
+	if constexpr (kMaxPer > 12) {
+		if (per <= 16) launch(std::integral_constant<int, 16>{});
+		else launch(std::integral_constant<int, 20>{});
 	}
 }
 
@@ -1408,12 +1418,12 @@ uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx) { return (ctx && ctx->has_
 namespace {
 
 // What both founder entry points ask of the ctx and of their start states, and the edge-major bits they walk.
-int pbwt_check_state(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_chunks, const uint32_t *start_order)
+int pbwt_check_state(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_chunks, const uint32_t *start_order, int max_copies)
 {
-	if (0 == n_copies || n_copies > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk holds at most %d chromosome copies (got %llu)", v2m::kPbwtMaxCopies, (unsigned long long) n_copies);
+	if (0 == n_copies || n_copies > u64(max_copies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "this GPU chunk walk holds at most %d chromosome copies (got %llu)", max_copies, (unsigned long long) n_copies);
 	if (n_copies > ctx->path_cols) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "the bound path matrix has %llu copies, %llu asked for", (unsigned long long) ctx->path_cols, (unsigned long long) n_copies);
-	// (the kernels stage a whole edge column -- path_cols / 64 words -- in an LDS array sized for kPbwtMaxCopies)
-	if (ctx->path_cols > u64(v2m::kPbwtMaxCopies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk reads edge columns of at most %d copies; the bound path matrix has %llu columns", v2m::kPbwtMaxCopies, (unsigned long long) ctx->path_cols);
+	// (the kernels stage a whole edge column -- path_cols / 64 words -- in an LDS array sized with the state)
+	if (ctx->path_cols > u64(max_copies)) return fail(ctx, V2M_ERR_UNSUPPORTED, "this GPU chunk walk reads edge columns of at most %d copies; the bound path matrix has %llu columns", max_copies, (unsigned long long) ctx->path_cols);
 	// (biased divergence values are edge indices + 2, and the kernels keep bit 31 of a running maximum for "constant")
 	if (ctx->n_edges >= 0x7FFFFFF0ull) return fail(ctx, V2M_ERR_UNSUPPORTED, "the GPU chunk walk keeps edge indices in 31 bits (the graph has %llu edges)", (unsigned long long) ctx->n_edges);
 	// the start order indexes the workgroup's state arrays in LDS
@@ -1447,7 +1457,7 @@ int pbwt_cut_trials_impl(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 	if (0 == n_chunks) return V2M_OK;
 	if (!cand_edge || !cand_aligned_pos || !chunk_first || !start_order || !start_divergence || (!sink && (!trial_pred || !trial_class_count)) || !trial_end || !chunk_status)
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL array");
-	if (int const rc = pbwt_check_state(ctx, n_copies, n_chunks, start_order)) return rc;
+	if (int const rc = pbwt_check_state(ctx, n_copies, n_chunks, start_order, v2m::kPbwtMaxCopies)) return rc;
 	if (n_candidates >= 0xFFFFFFFFull || ctx->n_edges >= 0xFFFFFFFDull) return fail(ctx, V2M_ERR_UNSUPPORTED, "candidate and edge indices are kept in 32 bits");
 	if (chunk_first[0] < 1 || chunk_first[n_chunks] > n_candidates) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds outside the candidate list");
 	for (u64 k(0); k < n_chunks; ++k) if (chunk_first[k] > chunk_first[k + 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds must not decrease");
@@ -1490,7 +1500,7 @@ int pbwt_cut_trials_impl(v2m_ctx *ctx, uint64_t n_copies, uint64_t min_distance,
 			d_by_edge, u32(cols / 64), u32(n_copies), n_edges, d_first.as<u32>(), d_cand_edge.as<u32>(), d_cand_aln.as<u64>(), min_distance,
 			d_chunk_first.as<u64>(), d_order.as<u32>(), d_div.as<u32>(), trial_capacity, d_pred.as<u32>(), d_class.as<u32>(), d_end.as<u64>(), d_status.as<u32>());
 	});
-	pbwt_dispatch_per_thread(n_copies, launch_trials);
+	pbwt_dispatch_per_thread<v2m::kPbwtPerThread>(ctx->path_cols, launch_trials);
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
 	// (only the candidates of this call's chunks: a caller may be consuming an earlier call's part of the same array meanwhile)
@@ -1594,7 +1604,7 @@ int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const
 	if (!cut_edge || !chunk_first_cut || !start_edge || !start_order || !start_divergence || !pool_lhs || !pool_rhs || !pool_size
 		|| !rec_pool_end || !rec_distinct || !rec_first_class || !rec_first_is_ref || !chunk_status)
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "NULL array");
-	if (int const rc = pbwt_check_state(ctx, n_copies, n_chunks, start_order)) return rc;
+	if (int const rc = pbwt_check_state(ctx, n_copies, n_chunks, start_order, v2m::kPbwtMaxCopiesRecords)) return rc;
 	if (chunk_first_cut[0] < 1 || chunk_first_cut[n_chunks] > n_cuts) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds outside the cut list");
 	for (u64 k(0); k < n_chunks; ++k) {
 		if (chunk_first_cut[k] > chunk_first_cut[k + 1]) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "chunk bounds must not decrease");
@@ -1632,7 +1642,7 @@ int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const
 			d_by_edge, u32(cols / 64), u32(n_copies), u32(rows), d_cut_edge.as<u32>(), d_chunk_first.as<u64>(), d_start_edge.as<u32>(), d_order.as<u32>(), d_div.as<u32>(),
 			pool_capacity, d_lhs.as<u32>(), d_rhs.as<u32>(), d_size.as<u32>(), d_end.as<u64>(), d_distinct.as<u32>(), d_first.as<u32>(), d_ref.as<u32>(), d_status.as<u32>());
 	});
-	pbwt_dispatch_per_thread(n_copies, launch_records);
+	pbwt_dispatch_per_thread<v2m::kPbwtPerThreadRecords>(ctx->path_cols, launch_records);
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
 	u64 const cut_lo(chunk_first_cut[0]), cut_hi(chunk_first_cut[n_chunks]);   // only the cuts of this call's chunks
