@@ -19,7 +19,7 @@ python3 - "$OUT" <<'PY' | tee $OUT/summary.txt
 import csv, glob, collections, sys
 out = sys.argv[1]
 print(open(out + "/plain_run.txt").read().strip())
-for kernel in ("splice_unaligned_kernel", "splice_aligned_kernel", "count_unaligned_kernel"):
+for kernel in ("splice_unaligned", "splice_aligned_kernel", "count_unaligned_kernel"):
 	tot = collections.defaultdict(float); n = collections.defaultdict(int)
 	for f in glob.glob(out + "/pmc_*/**/*counter_collection.csv", recursive=True):
 		per = collections.defaultdict(float)

@@ -1611,6 +1611,23 @@ __device__ __forceinline__ u32 wave_inclusive_scan_u32(u32 v)
 	return v;
 }
 
+// Four independent scans in lockstep, round by round: a DPP instruction that reads the register the instruction before it wrote costs two
+// wait states (hipcc fills them with s_nop 1), and written one scan after the other -- as the source had them in rounds 2-5 -- the four scans
+// came out as 24 dependent adds with 28 s_nops between them; side by side each round's four adds cover one another's wait states.
+template <int kN>
+__device__ __forceinline__ void wave_inclusive_scan_u32_lockstep(u32 (&v)[kN])
+{
+#define V2M_SCAN_ROUND(CTRL, ROWS) \
+	_Pragma("unroll") for (int k = 0; k < kN; ++k) v[k] += (u32) __builtin_amdgcn_update_dpp(0, (int) v[k], CTRL, ROWS, 0xf, false);
+	V2M_SCAN_ROUND(0x111, 0xf)   // row_shr:1, zeros shifted in
+	V2M_SCAN_ROUND(0x112, 0xf)   // row_shr:2
+	V2M_SCAN_ROUND(0x114, 0xf)   // row_shr:4
+	V2M_SCAN_ROUND(0x118, 0xf)   // row_shr:8
+	V2M_SCAN_ROUND(0x142, 0xa)   // row_bcast:15 into rows 1 and 3
+	V2M_SCAN_ROUND(0x143, 0xc)   // row_bcast:31 into rows 2 and 3
+#undef V2M_SCAN_ROUND
+}
+
 // Lane i receives lane i + 1's value, lane 63 receives 0 (v_mov_b32_dpp wave_shl:1, no LDS round trip).
 __device__ __forceinline__ u64 wave_shift_left_u64(u64 v)
 {
@@ -1747,8 +1764,11 @@ typedef u32 u32_unaligned __attribute__((aligned(1)));
 typedef u64 u64_unaligned __attribute__((aligned(1)));
 typedef vec4u vec4u_unaligned __attribute__((aligned(1)));   // 16-B access at any byte address (gfx950 / HSA unaligned access mode; tools/unaligned_store_test.hip)
 
+#ifdef V2M_TUNING_BUILD
+// The stream-out of rounds 2-5, every wave packing its own short chunks: kept for the A/B (V2M_UNALIGNED_KERNEL=wave with the tuning library;
+// profiles/r05/unaligned_shared_pack.txt).
 template <bool kNonTemporal>
-__global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
+__global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_per_wave_kernel(
 	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
 	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
 	u32 const *__restrict__ tile_offsets /* [n_rows][n_tiles]: where each tile's bytes start in its row */, u32 n_tiles,
@@ -1800,8 +1820,9 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 		vec4u v[kChunksPerThread];
 		u32 cnt[kChunksPerThread], incl[kChunksPerThread];
 #pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k) v[k] = lds[t + kSpliceThreads * k];
+#pragma unroll
 		for (int k = 0; k < kChunksPerThread; ++k) {
-			v[k] = lds[t + kSpliceThreads * k];
 			// Non-padding bytes of the chunk: v_msad_u8 adds |a - b| over the bytes whose reference byte b is not 0, and
 			// |(b ^ 1) - b| = 1 for every b: two instructions per dword instead of the five of zero-byte mask + popcount.
 			// (Round 3: with the slot bases below, 78 -> 65 VGPRs, so 7 workgroups per CU instead of 6; that, more than the
@@ -1809,11 +1830,12 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			u32 bytes = 0;
 #pragma unroll
 			for (int d = 0; d < 4; ++d) bytes = __builtin_amdgcn_msad_u8(v[k][d] ^ 0x01010101u, v[k][d], bytes);
-			cnt[k] = bytes;
-			u32 const s = wave_inclusive_scan_u32(cnt[k]);
-			incl[k] = s;
-			if (lane == 63) wave_sums[k * (kSpliceThreads / 64) + wave] = s;
+			incl[k] = cnt[k] = bytes;
 		}
+		wave_inclusive_scan_u32_lockstep(incl);
+#pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k)
+			if (lane == 63) wave_sums[k * (kSpliceThreads / 64) + wave] = incl[k];
 		__syncthreads();
 
 		// Where each of the 16 slots starts: their byte counts scanned in stream order by the first 16 lanes of every wave
@@ -1902,6 +1924,184 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 			if (c & 2) { *(u16_unaligned *) p = (u16) rest; p += 2; rest >>= 16; }
 			if (c & 1) *p = (char) rest;
 		}
+		// wave_sums is rewritten only after the next row's barriers
+	}
+}
+#endif   // V2M_TUNING_BUILD
+
+// The surviving (non-zero) bytes of the 16-B chunk x, c of them, packed to the low end of a 16-B value and stored at p exactly: at most one
+// store each of 8, 4, 2 and 1 bytes (the bytes around them belong to other chunks' stores).  v_perm_b32 per dword with the 16-entry
+// selector table, then the four pieces shifted together.
+__device__ __forceinline__ void pack_chunk_and_store_exact(vec4u const x, u32 const c, char *p, u32 const *compact_sel)
+{
+	u32 piece[4], len[4];
+#pragma unroll
+	for (int d = 0; d < 4; ++d) {
+		u32 const keep = ~zero_bytes_mask(x[d]) & 0x80808080u;             // 0x80 per surviving byte (bits 7, 15, 23, 31)
+		// ... gathered into the top nibble (inline assembly: the compiler would make a v_mul_lo_u32 of it, a quarter-rate instruction)
+		u32 pairs, quad;
+		asm("v_lshl_or_b32 %0, %1, 7, %1" : "=v"(pairs) : "v"(keep));
+		asm("v_lshl_or_b32 %0, %1, 14, %1" : "=v"(quad) : "v"(pairs));
+		u32 const m = quad >> 28;
+		piece[d] = __builtin_amdgcn_perm(0u, x[d], compact_sel[m]);
+		len[d] = (u32) __builtin_popcount(m);
+	}
+	u64 const lo = (u64) piece[0] | ((u64) piece[1] << (8 * len[0]));
+	u64 const hi = (u64) piece[2] | ((u64) piece[3] << (8 * len[2]));
+	u32 const sh = 8 * (len[0] + len[1]);                                  // 0 ... 64
+	u64 const packed_lo = lo | (sh < 64 ? hi << sh : 0);
+	u64 const packed_hi = 0 == sh ? 0 : (64 == sh ? hi : hi >> (64 - sh));
+	u64 rest = packed_lo;
+	if (c & 8) { *(u64_unaligned *) p = packed_lo; p += 8; rest = packed_hi; }
+	if (c & 4) { *(u32_unaligned *) p = (u32) rest; p += 4; rest >>= 32; }
+	if (c & 2) { *(u16_unaligned *) p = (u16) rest; p += 2; rest >>= 16; }
+	if (c & 1) *p = (char) rest;
+}
+
+// The unaligned stream-out with ONE packing pass per workgroup and row tile instead of one per wave (round 5).
+//
+// Counters on config 5 (profiles/r05/unaligned_pmc_config5_*): per wave and row tile the per-wave stream-out (rounds 2-5, now in the tuning build) issues 308 VALU + 213 SALU
+// instructions against the aligned kernel's 114 + 117, and a SIMD gets 479 issue turns per row tile at the HBM-bound pace: the
+// kernel is bound by instruction issue, and ~40 % of what it issues is the packing pass (pack + exact stores), which a wave
+// pays in full whether one of its lanes has a short chunk or all 64 -- on a dense graph every wave has a few, every row tile.
+// Here the short chunks of the whole 16-KiB row tile (config 3: ~35, config 5: ~70) go into ONE queue per workgroup --
+// descriptor (bytes | destination << 4) and the chunk's 16 bytes, at positions that fall out of the byte-count scan itself (the
+// short-chunk flag rides in the high half of the scanned word: no ballot, no mbcnt) -- and are packed 64 at a time by ONE wave,
+// a row later: row r's queue is complete at the barrier that follows row r + 1's tile build, after which wave (r + pass) % 4
+// packs it while the others go on with row r + 1 (so no barrier is added, and the packing wave rotates).  Slots whose short
+// chunks no longer fit the queue (tiles inside long insertions) are packed where they are by their own wave.
+// Measured (profiles/r05/unaligned_shared_pack.txt): config 5 11.5 -> 10.95 ms per 244 rows (aligned kernel, same rows: 9.03), VALU 308 -> 256, SALU 213 -> ~156
+// per wave and row tile (the scans in lockstep took the rest); config 3 within what two boxes differ by.
+template <bool kNonTemporal, u32 kQueue = 128>
+__global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
+	vec4u const *__restrict__ tmpl0, u64 const *__restrict__ eff, u64 eff_words_per_row,
+	tile_tables tt, edge_patch const *__restrict__ patches, char const *__restrict__ labels,
+	u32 const *__restrict__ tile_offsets /* [n_rows][n_tiles]: where each tile's bytes start in its row */, u32 n_tiles,
+	char *__restrict__ out, u64 row_pitch, u32 n_rows, u32 rows_per_group, u32 n_groups, u32 tile_run)
+{
+	constexpr int kWaves = kSpliceThreads / 64, kSlots = kChunksPerThread * kWaves;
+	// kQueue: short chunks of a row tile that wait for the packing wave(s)
+	__shared__ vec4u lds[kTileChunks];
+	__shared__ patch_cache pc;
+	__shared__ __attribute__((aligned(16))) u32 wave_sums[kSlots];         // per 1-KiB slot: [wave][k]; bytes | short chunks << 16
+	__shared__ u32 compact_sel[16];
+	__shared__ vec4u queue_data[kQueue];
+	__shared__ u32 queue_desc[kQueue];
+	__shared__ u32 queue_count;
+
+	int const t = threadIdx.x;
+	int const lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+	if (t < 16) compact_sel[t] = compaction_selector((u32) t);   // first read follows the row loop's barriers
+	u32 tile, group;
+	map_block(blockIdx.x, n_groups, n_tiles, tile_run, tile, group);
+	{
+		// (as in the kernel above: within its super-block every XCD takes a run of consecutive tiles)
+		u32 const t0 = tile / tile_run * tile_run;
+		u32 const run = (n_tiles - t0 < tile_run) ? n_tiles - t0 : tile_run;
+		if (0 == run % 8) { u32 const j = tile - t0; tile = t0 + (j & 7) * (run / 8) + (j >> 3); }
+	}
+	u32 const row_begin = group * rows_per_group;
+	u32 const row_end = (row_begin + rows_per_group < n_rows) ? row_begin + rows_per_group : n_rows;
+
+	vec4u pristine[kChunksPerThread];
+#pragma unroll
+	for (int k = 0; k < kChunksPerThread; ++k)
+		pristine[k] = tmpl0[(u64) tile * kTileChunks + t + kSpliceThreads * k];
+
+	tile_job job;
+	load_patch_cache(pc, job, tt, patches, labels, eff, eff_words_per_row, tile, row_begin, row_end - row_begin, t);
+
+	char *dst_prev = out;
+	for (u32 row = row_begin; ; ++row) {                                      // (one round more than there are rows: the last one only packs the last row's queue)
+		bool const past_end = row >= row_end;                                  // (uniform)
+		u32 const tile_offset = past_end ? 0u : tile_offsets[(u64) row * n_tiles + tile];   // (needed after the third barrier: asked for here)
+		if (!past_end) {
+#pragma unroll
+			for (int k = 0; k < kChunksPerThread; ++k)
+				lds[t + kSpliceThreads * k] = pristine[k];
+		}
+		asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                  // (the previous row's queue writes precede this barrier across the loop's back edge)
+		__syncthreads();
+
+		if (row != row_begin) {
+			// the queue of the row before: packed by wave (row + pass) % 4, 64 entries a pass
+			u32 const n = (u32) __builtin_amdgcn_readfirstlane((int) queue_count);
+			for (u32 pass = 0; 64 * pass < n; ++pass) {
+				if (((row + pass) & (u32) (kWaves - 1)) != (u32) wave) continue;
+				u32 const idx = 64 * pass + (u32) lane;
+				if (idx < n) {
+					u32 const e = queue_desc[idx];
+					pack_chunk_and_store_exact(queue_data[idx], e & 15u, dst_prev + (e >> 4), compact_sel);
+				}
+			}
+		}
+		if (past_end) break;
+
+		patch_row_tile((unsigned char *) lds, pc, job, tt, patches, labels, eff + (u64) row * eff_words_per_row, row - row_begin, t, 0);
+
+		// Thread t owns the 16-B chunks t, t + 256, ...  Scanned word: surviving bytes in the low half, "short chunk" (1 ... 15 of them) in the high half.
+		vec4u v[kChunksPerThread];
+		u32 mine[kChunksPerThread], incl[kChunksPerThread];
+#pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k) v[k] = lds[t + kSpliceThreads * k];
+#pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k) {
+			u32 bytes = 0;
+#pragma unroll
+			for (int d = 0; d < 4; ++d) bytes = __builtin_amdgcn_msad_u8(v[k][d] ^ 0x01010101u, v[k][d], bytes);
+			incl[k] = mine[k] = bytes | (bytes - 1u < 15u ? 0x10000u : 0u);
+		}
+		wave_inclusive_scan_u32_lockstep(incl);
+		if (lane == 63) {                                                      // one 16-B store: the wave's four slot totals side by side
+			vec4u sums;
+#pragma unroll
+			for (int k = 0; k < kChunksPerThread; ++k) sums[k] = incl[k];
+			*(vec4u *) &wave_sums[kChunksPerThread * wave] = sums;
+		}
+		__syncthreads();
+
+		// slot k * kWaves + wave (stream order) sits at wave_sums[kChunksPerThread * wave + k]
+		u32 slot_end = lane < kSlots ? wave_sums[kChunksPerThread * (lane % kWaves) + lane / kWaves] : 0u;
+		slot_end += (u32) __builtin_amdgcn_update_dpp(0, (int) slot_end, 0x111, 0xf, 0xf, false);   // row_shr:1 (lanes 0..15 are one DPP row)
+		slot_end += (u32) __builtin_amdgcn_update_dpp(0, (int) slot_end, 0x112, 0xf, 0xf, false);   // row_shr:2
+		slot_end += (u32) __builtin_amdgcn_update_dpp(0, (int) slot_end, 0x114, 0xf, 0xf, false);   // row_shr:4
+		slot_end += (u32) __builtin_amdgcn_update_dpp(0, (int) slot_end, 0x118, 0xf, 0xf, false);   // row_shr:8
+
+		char *const dst = out + (u64) row * row_pitch + tile_offset;
+		// the slots whose short chunks fit the queue: a prefix of the slots (the counts only grow), read off a ballot
+		u32 const n_fit = (u32) __builtin_popcountll(__ballot(lane < kSlots && (slot_end >> 16) <= kQueue));            // (uniform)
+		u32 const n_queued = n_fit ? (u32) __builtin_amdgcn_readlane((int) slot_end, (int) n_fit - 1) >> 16 : 0u;   // (uniform)
+		u32 offs[kChunksPerThread];
+		u32 dense = 0;                                                         // (uniform) this wave's slots that do not fit
+#pragma unroll
+		for (int k = 0; k < kChunksPerThread; ++k) {
+			int const slot = k * kWaves + wave;                                  // wave-uniform
+			u32 const slot_begin = slot ? (u32) __builtin_amdgcn_readlane((int) slot_end, slot - 1) : 0u;
+			u32 const c = mine[k] & 0xFFFFu;
+			u32 const before = slot_begin + incl[k] - mine[k];                   // both halves at once: bytes and short chunks before this one
+			u32 const off = before & 0xFFFFu;
+			offs[k] = off;
+			if (16 == c) {
+				if (kNonTemporal) __builtin_nontemporal_store(v[k], (vec4u_unaligned *) (dst + off));
+				else *(vec4u_unaligned *) (dst + off) = v[k];
+			}
+			if ((u32) slot < n_fit) {                                             // (uniform)
+				if (mine[k] >> 16) {
+					u32 const pos = before >> 16;
+					queue_desc[pos] = c | off << 4;
+					queue_data[pos] = v[k];
+				}
+			}
+			else dense |= 1u << k;
+		}
+		for (; dense; dense &= dense - 1) {                                    // (rare: tiles inside long insertions) packed where they are, read back from the row tile
+			u32 const j = (u32) __builtin_ctz(dense);
+			u32 const c = (0 == j ? mine[0] : 1 == j ? mine[1] : 2 == j ? mine[2] : mine[3]) & 0xFFFFu;
+			u32 const o = 0 == j ? offs[0] : 1 == j ? offs[1] : 2 == j ? offs[2] : offs[3];
+			if (c - 1u < 15u) pack_chunk_and_store_exact(lds[(u32) t + (u32) kSpliceThreads * j], c, dst + o, compact_sel);
+		}
+		if (0 == t) queue_count = n_queued;
+		dst_prev = dst;
 		// wave_sums is rewritten only after the next row's barriers
 	}
 }

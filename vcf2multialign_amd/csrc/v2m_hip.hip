@@ -885,6 +885,12 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 				ctx->d_template0.as<v2m::vec4u>(), ctx->d_eff.as<u64>(), eff_words, tt, ctx->d_patches.as<v2m::edge_patch>(), ctx->d_labels.as<char>(),
 				ctx->d_tile_counts.as<u32>(), ctx->n_tiles, d_out, row_pitch, u32(n_rows), g.rows_per_group, g.n_groups, g.tile_run);
 		});
+#ifdef V2M_TUNING_BUILD
+		// V2M_UNALIGNED_KERNEL=wave | shared64: the stream-out whose every wave packs its own short chunks / the product's with a queue of 64 (tools/unaligned_ab.sh)
+		static int const flavour([] { char const *const e(std::getenv("V2M_UNALIGNED_KERNEL")); return !e ? 0 : 0 == std::strcmp(e, "wave") ? 1 : 0 == std::strcmp(e, "shared64") ? 2 : 0; }());
+		if (1 == flavour) { if (nt) go(v2m::splice_unaligned_per_wave_kernel<true>); else go(v2m::splice_unaligned_per_wave_kernel<false>); return; }
+		if (2 == flavour) { if (nt) go(v2m::splice_unaligned_kernel<true, 64>); else go(v2m::splice_unaligned_kernel<false, 64>); return; }
+#endif
 		if (nt) go(v2m::splice_unaligned_kernel<true>);
 		else go(v2m::splice_unaligned_kernel<false>);
 	});
