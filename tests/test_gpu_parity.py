@@ -572,8 +572,9 @@ def test_nul_bytes_are_kept_in_aligned_mode_and_refused_in_unaligned_mode(v2m, c
 @pytest.mark.parametrize("mode", ["", "plain"])
 def test_unaligned_rows_with_much_padding(ctx, v2m, tmp_path, monkeypatch, mode):
 	"""Graphs dense with insertions: most 16-byte chunks of a tile hold padding -- runs of chunks with a few surviving bytes
-	or none, so every way the stream-out kernel stores a chunk is taken: the plain 16-byte store, the 16-byte store filled up
-	from the next lane's chunk, and the exact 8 / 4 / 2 / 1-byte pieces where the next chunk is too short to fill up from."""
+	or none, ~1000 short chunks per 16-KiB row tile -- so every way the stream-out kernel stores a chunk is taken: the plain
+	16-byte store, the workgroup's queue of 128 short chunks packed a row later by the rotating wave (and after the last row),
+	and, for the slots that no longer fit the queue, the pack where they are; exact 8 / 4 / 2 / 1-byte pieces in both."""
 	monkeypatch.setenv("V2M_UNALIGNED_STORE", mode)
 	g = synth.build_case(tmp_path, 94, 120000, 9000, 6, mix=(0.2, 0.7, 0.1), max_indel=40)   # an insertion every ~20 bases
 	vg = v2m.VariantGraph.from_object(g)
