@@ -321,6 +321,8 @@ def test_options_outside_this_builds_scope_are_refused(tmp_path):
 	for option in ("--output-graphviz", "--output-memory-breakdown"):
 		r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", option + "=" + str(tmp_path / "x")])
 		assert r.returncode != 0 and b"not supported by this build" in r.stderr
+	r = run(["-H", "-r", fa, "-a", vcf, "-c", "1", "-v", str(tmp_path / "x")])   # --output-graphviz's short form (cmdline.ggo:38)
+	assert r.returncode != 0 and b"not supported by this build" in r.stderr and b"Usage" not in r.stderr
 
 
 def test_an_unusable_device_ends_the_run(tmp_path):

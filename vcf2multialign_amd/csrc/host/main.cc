@@ -183,7 +183,7 @@ int main(int argc, char **argv)
 		{"output-cut-positions", required_argument, nullptr, 't'}, {"keep-ref-edges", no_argument, nullptr, o_keep_ref},
 		{"help", no_argument, nullptr, 'h'}, {nullptr, 0, nullptr, 0}};
 	int c;
-	while (-1 != (c = getopt_long(argc, argv, "HF:d:p:t:r:e:a:c:s:m:x:g:f:h", longopts, nullptr))) {
+	while (-1 != (c = getopt_long(argc, argv, "HF:d:p:t:r:e:a:c:s:m:x:g:f:v:h", longopts, nullptr))) {
 		switch (c) {
 			case 'H': opt.haplotypes = true; break;
 			case 'F': opt.founder_mode = true; opt.founder_sequences = std::atol(optarg); break;
@@ -224,7 +224,8 @@ int main(int argc, char **argv)
 			case 'p': opt.input_cut_positions = optarg; break;
 			case 't': opt.output_cut_positions = optarg; break;
 			case 'h': usage(); return EXIT_SUCCESS;
-			case o_unsupported: std::cerr << "ERROR: option " << argv[optind - 1] << " is not supported by this build.\n"; return EXIT_FAILURE;
+			case 'v':   // --output-graphviz's short form (cmdline.ggo:38): the same answer
+			case o_unsupported: std::cerr << "ERROR: option " << ('v' == c ? "-v / --output-graphviz" : argv[optind - 1]) << " is not supported by this build.\n"; return EXIT_FAILURE;
 			default: usage(); return EXIT_FAILURE;
 		}
 	}
