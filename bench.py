@@ -134,6 +134,31 @@ def device_binding(dev_index):
 	return out
 
 
+def bind_to_numa_node(node):
+	"""At N > 1 every rank keeps its host side -- the pinned slots its D2H copies land in (first touch), the sink's and the checker's
+	threads -- on the socket its GPU hangs off: eight links deliver ~450 GB/s into host memory and the sinks read it all back, which is
+	the two sockets' DRAM bandwidth, not something to send across the socket interconnect as well.  The CPUs of the
+	GPU's NUMA node that this process is allowed to run on; None (and nothing changed) when the node is unknown or shares no CPU with
+	the allowed set.  Never fatal."""
+	try:
+		if node is None or node < 0:
+			return None
+		with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+			text = f.read().strip()
+		cpus = set()
+		for part in text.split(","):
+			if part:
+				lo, _, hi = part.partition("-")
+				cpus.update(range(int(lo), int(hi or lo) + 1))
+		cpus &= os.sched_getaffinity(0)
+		if not cpus:
+			return None
+		os.sched_setaffinity(0, cpus)
+		return text
+	except (OSError, ValueError, AttributeError):
+		return None
+
+
 HUB_ENV = "V2M_BENCH_HUB"   # set for the children of `python bench.py --gpus N`: the parent serves barrier / gather over their pipes
 
 
@@ -308,6 +333,7 @@ def main():
 	ap.add_argument("--e2e-gb", type=float, default=64.0, help="the end-to-end leg (every rank, last: after the main timing and rank 0's other legs, by which time the driver has finished wiping the output-buffer candidates that v2m_alloc_output freed): this many GB of the rank's rows through v2m_splice_rows -- device slots, D2H copies on the copy stream, pinned slots -- into a C sink that checksums every row on the host; 0 disables")
 	ap.add_argument("--e2e-threads", type=int, default=0, help="host threads of the end-to-end leg's checksumming sink, PER RANK; 0 = by the CPU and the job's quota: 4 where the sink has its AVX-512DQ loop (41 GB/s per thread on the boxes' Zen 5 cores, profiles/r04/cpu_quota_and_sink_rates.txt: twice what the link delivers), 12 with the scalar loop (7 GB/s per thread), and never more than this rank's share of the job's CPU quota (cgroup cpu.max / affinity mask, divided by LOCAL_WORLD_SIZE, one core left for the rank's main thread): what goes beyond the quota gets the whole job throttled")
 	ap.add_argument("--host-threads", type=int, default=0, help="threads per rank for the CPU oracle's row checks after timing; 0 = this rank's share of the job's CPU quota (sharding.host_threads_per_rank), at most 16")
+	ap.add_argument("--numa-bind", default="auto", choices=["auto", "on", "off"], help="keep this rank's threads (and with them the pinned slots they first touch) on its GPU's NUMA node: auto = at N > 1 only")
 	ap.add_argument("--hub-selftest", action="store_true", help="no GPU work: the ranks only exercise the barrier / gather plumbing of their launch form and rank 0 prints what it gathered (CPU test suite)")
 	args = ap.parse_args()
 
@@ -367,8 +393,10 @@ def main():
 	quota_cores, quota_source = cpu_quota()
 	host_threads = args.host_threads if args.host_threads > 0 else host_threads_per_rank(local_world, cap=16)
 	where = device_binding(dev_index)
-	log("[bench] rank %d/%d (local %d/%d, pid %d): HIP device %s = %s, PCI %s, NUMA node %s; CPUs allowed %s; job quota %d cores (%s) -> %d host threads for this rank"
-		% (rank, world, local_rank, local_world, os.getpid(), where["hip_device"], where["name"], where["pci_bus_id"], where["numa_node"], where["cpus_allowed"], quota_cores, quota_source, host_threads))
+	where["numa_bound_to_cpus"] = bind_to_numa_node(where["numa_node"]) if ("on" == args.numa_bind or ("auto" == args.numa_bind and world > 1)) else None
+	log("[bench] rank %d/%d (local %d/%d, pid %d): HIP device %s = %s, PCI %s, NUMA node %s; CPUs allowed %s, bound to %s; job quota %d cores (%s) -> %d host threads for this rank"
+		% (rank, world, local_rank, local_world, os.getpid(), where["hip_device"], where["name"], where["pci_bus_id"], where["numa_node"], where["cpus_allowed"],
+		where["numa_bound_to_cpus"] or "nothing narrower", quota_cores, quota_source, host_threads))
 
 	# ---- workload: generated on every rank (deterministic), resident in HBM before timing ----------
 	t0 = time.time()

@@ -1,9 +1,12 @@
 """CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/v2m_hip.h declares, fails
 loudly without a device, and the host-side logic (row batches, sharding, checksums) is right."""
 
+import json
 import os
 import re
 import socket
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -440,3 +443,22 @@ def test_bench_as_typed_starts_child_ranks_and_relays_their_failure():
 	assert b"rank 0 -> exit" in r.stderr and b"rank 1 -> exit" in r.stderr
 	with open(os.path.join(ROOT, "bench.py")) as f:
 		assert "os.exec" not in f.read().replace("Never os.exec*", "")
+
+
+def test_bench_numa_binding_is_a_subset_of_what_was_allowed_and_never_fatal():
+	"""bench.py at N > 1 keeps a rank's host side on its GPU's NUMA node.  In a child process (the change is the
+	process's own): node 0's CPUs, cut down to what the process was allowed before, or nothing at all when the node is unknown."""
+	code = ("import os, sys, json; sys.path.insert(0, %r); import bench\n"
+		"before = os.sched_getaffinity(0)\n"
+		"print(json.dumps([bench.bind_to_numa_node(None), bench.bind_to_numa_node(-1), bench.bind_to_numa_node(4096), sorted(os.sched_getaffinity(0) ^ before)]))\n"
+		"bound = bench.bind_to_numa_node(0)\n"
+		"after = os.sched_getaffinity(0)\n"
+		"print(json.dumps([bound, after <= before, len(after) > 0]))\n") % ROOT
+	r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120, env=_clean_env())
+	assert r.returncode == 0, r.stderr.decode()
+	lines = [json.loads(l) for l in r.stdout.decode().strip().splitlines()]
+	assert lines[0] == [None, None, None, []]                                      # unknown nodes change nothing
+	assert lines[1][1] is True and lines[1][2] is True                              # a subset, never empty
+	if os.path.exists("/sys/devices/system/node/node0/cpulist"):
+		with open("/sys/devices/system/node/node0/cpulist") as f:
+			assert lines[1][0] in (None, f.read().strip())
