@@ -70,6 +70,10 @@ def _check_placement(d, n_ranks, forced_device=0):
 	for p in place:
 		assert p["hip_device"] == forced_device and p["pci_bus_id"] and p["name"] and p["cpus_allowed"]
 		assert 1 <= p["host_threads"] <= max(1, host["cpu_quota_cores"] // n_ranks)
+		# at N > 1 the rank's host side stays on its GPU's NUMA node where the box says which one that is (never at N = 1: the default run is as it was)
+		assert "numa_bound_to_cpus" in p and (n_ranks > 1 or p["numa_bound_to_cpus"] is None)
+		if n_ranks > 1 and p["numa_node"] is not None and p["numa_node"] >= 0:
+			assert p["numa_bound_to_cpus"]
 	assert sum(p["host_threads"] for p in place) <= max(n_ranks, host["cpu_quota_cores"])
 
 
