@@ -393,6 +393,8 @@ def main():
 	quota_cores, quota_source = cpu_quota()
 	host_threads = args.host_threads if args.host_threads > 0 else host_threads_per_rank(local_world, cap=16)
 	where = device_binding(dev_index)
+	if where["hip_device"] is not None and where["hip_device"] != dev_index:   # (cannot happen after torch.cuda.set_device; a rank on the wrong GPU must not produce a figure)
+		sys.exit("[bench] rank %d: the HIP runtime's current device is %d, expected %d" % (rank, where["hip_device"], dev_index))
 	where["numa_bound_to_cpus"] = bind_to_numa_node(where["numa_node"]) if ("on" == args.numa_bind or ("auto" == args.numa_bind and world > 1)) else None
 	log("[bench] rank %d/%d (local %d/%d, pid %d): HIP device %s = %s, PCI %s, NUMA node %s; CPUs allowed %s, bound to %s; job quota %d cores (%s) -> %d host threads for this rank"
 		% (rank, world, local_rank, local_world, os.getpid(), where["hip_device"], where["name"], where["pci_bus_id"], where["numa_node"], where["cpus_allowed"],
