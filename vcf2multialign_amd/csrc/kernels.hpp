@@ -447,12 +447,13 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 #pragma unroll
 	for (int a = 0; a < kA; ++a) tile_base[a] = (rw0 + kA * wave + a) * 64 * dst_pitch;
 
+	lean_butterfly const butterfly(lane);
 	auto const compute = [&](u32 cg, int buf) {
 		u64 tv[kA];
 #pragma unroll
 		for (int a = 0; a < kA; ++a) tv[a] = stage[buf][lane][kA * wave + a];
 #pragma unroll
-		for (int a = 0; a < kA; ++a) tv[a] = kFastLanes ? wave_transpose_64x64_fast(tv[a], lane) : wave_transpose_64x64(tv[a], lane);
+		for (int a = 0; a < kA; ++a) tv[a] = kFastLanes ? butterfly(tv[a]) : wave_transpose_64x64(tv[a], lane);   // (round 5: the lean butterfly of the streaming kernels)
 		bool done[kA];
 #pragma unroll
 		for (int a = 0; a < kA; ++a) {

@@ -409,6 +409,7 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 			return !fast ? V2M_RING_FLAVOUR(r, w, s, d, false, false) : nt ? V2M_RING_FLAVOUR(r, w, s, d, true, true) : V2M_RING_FLAVOUR(r, w, s, d, true, false);
 		V2M_RING(16, 8, 8, 4) V2M_RING(16, 16, 8, 8) V2M_RING(16, 8, 4, 4) V2M_RING(16, 8, 16, 4)
 		V2M_RING(8, 4, 8, 4) V2M_RING(8, 4, 8, 8) V2M_RING(8, 8, 8, 4) V2M_RING(8, 8, 8, 8) V2M_RING(8, 8, 8, 16)
+		V2M_RING(16, 16, 16, 8) V2M_RING(8, 8, 16, 8)   // (round 5: whole-line sectors with the lean butterfly; profiles/r05/transpose_rot8_experiment.txt)
 #undef V2M_RING
 #endif
 #undef V2M_RING_FLAVOUR
