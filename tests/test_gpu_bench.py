@@ -60,6 +60,22 @@ def test_bench_line_has_the_contract_fields():
 	_check_end_to_end(d, n_ranks=1)
 
 
+def test_bench_unaligned_leg_on_the_dense_graph():
+	"""The dense variant mix of BASELINE config 5 (mini5: one ALT edge per ~40 bp, MNPs, multi-allelic sites), where the unaligned stream-out's
+	queue of short chunks is busiest: the leg is bit-exact against the oracle and carries its like-for-like yardstick (the aligned kernel on the
+	same rows, buffer and pitch), so the figure the documents quote for config 5 is one the driver's own suite exercises."""
+	r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "mini5", "--steps", "1", "--warmup", "0", "--output-candidates", "1", "--cpu-baseline-rows", "4",
+		"--e2e-gb", "0", "--cpu-transpose", "0", "--transpose-extras", "0"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=ROOT)
+	assert r.returncode == 0, r.stderr.decode()[-2000:]
+	d = json.loads([l for l in r.stdout.decode().splitlines() if l.strip()][-1])
+	assert d["parity"]["bit_exact"] is True and d["parity"]["all_rows"] is True
+	un = d["unaligned"]
+	assert un["parity"]["bit_exact"] is True and un["roofline"]["kernel"] == "splice_unaligned_kernel"
+	assert un["kernels_ms"]["splice_unaligned_kernel"] > 0 and un["aligned_kernel_same_rows_ms"] > 0
+	assert abs(un["time_per_base_vs_aligned_kernel_same_rows"] * un["aligned_kernel_same_rows_ms"] * un["bases"]
+		- un["kernels_ms"]["splice_unaligned_kernel"] * d["config"]["aligned_length"] * un["rows"]) <= 0.02 * un["kernels_ms"]["splice_unaligned_kernel"] * d["config"]["aligned_length"] * un["rows"]
+
+
 def _check_placement(d, n_ranks, forced_device=0):
 	"""Every rank says where it ran (the HIP device the runtime reports, its PCI bus id, the slot's NUMA node, the CPUs it may use) and how many
 	host threads it was given out of the job's quota: a mis-bound rank or an oversubscribed host is visible in the record."""
