@@ -277,7 +277,7 @@ uint64_t v2m_max_unaligned_length(const v2m_ctx *ctx);
  * call starts (the output that follows the searches gets the memory back) or the ctx is destroyed.  The copy is made from the matrix as it
  * is at that first call: a caller that changes a v2m_set_paths_device() matrix in place must bind it again before the next search.
  * n_copies <= 20480 and a bound matrix of at most 20480 copy columns (V2M_ERR_UNSUPPORTED beyond: a workgroup keeps the pBWT state
- * and one edge column in LDS; v2m_pbwt_cut_records, which keeps two class arrays beside them: 12288).  V2M_ERR_INVALID_ARGUMENT for candidate edges that decrease or lie outside the graph, aligned
+ * and one edge column in LDS; v2m_pbwt_cut_records as well: its class arrays sit beside them up to 12288 copies and in device memory above).  V2M_ERR_INVALID_ARGUMENT for candidate edges that decrease or lie outside the graph, aligned
  * positions that decrease (find_cut_positions.cc:129,151) and start_order entries >= n_copies -- checked on the host before any
  * kernel indexes with them.
  *   cand_edge[c], cand_aligned_pos[c]   of all n_candidates candidates: the index of the node's first ALT edge (ascending, one

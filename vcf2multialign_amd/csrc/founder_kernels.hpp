@@ -27,12 +27,15 @@ constexpr int kPbwtWaves = kPbwtThreads / 64;
 // Chromosome copies a workgroup can walk: its pBWT state lives in LDS -- order (u16) and divergence (u32), ONE array each (a step reads all
 // of its copies into registers, passes a barrier and writes them back to their new places, so no second buffer is needed: round 5; with two
 // the state of 8192 copies was all that fit).  The kernels are instantiated per copies-per-thread count and size their arrays for it:
-// the cut search's kernel (state + the candidates' hash and bins) reaches 20 480 copies -- BASELINE config 5's 20 000 -- and the matching's
-// kernel (state + two class arrays + the joined classes' starts) 12 288.
+// the cut search's kernel (state + the candidates' hash and bins) reaches 20 480 copies -- BASELINE config 5's 20 000 -- and so does the matching's:
+// up to 12 288 copies its two class arrays and the joined classes' starts (6 bytes per copy, touched once per CUT, not per step) sit in LDS
+// beside the state, above that in a scratch area of global memory the host provides (kPbwtClassesInLds).
 constexpr int kPbwtMaxCopies = 20480;
-constexpr int kPbwtMaxCopiesRecords = 12288;
+constexpr int kPbwtMaxCopiesRecords = kPbwtMaxCopies;
 constexpr int kPbwtPerThread = kPbwtMaxCopies / kPbwtThreads;          // 20
-constexpr int kPbwtPerThreadRecords = kPbwtMaxCopiesRecords / kPbwtThreads;   // 12
+constexpr int kPbwtPerThreadRecords = kPbwtMaxCopiesRecords / kPbwtThreads;   // 20
+template <int kPer> constexpr bool kPbwtClassesInLds = kPer <= 12;          // (12 288 copies: state + class arrays = 150 KB)
+constexpr int kPbwtClassScratchArrays = 3;                                  // per chunk, of 1024 * kPer unsigned shorts each: the two class arrays, the joined classes' starts
 // distinct candidate bins per candidate node: about a hundred in practice, at most kPbwtMaxBins; the largest instantiations take the smaller table
 template <int kPer> constexpr int pbwt_hash_slots() { return kPer > 8 ? 2048 : 4096; }
 constexpr int kPbwtMaxBins = kPbwtThreads;            // more distinct bins than this at one candidate (a thread per bin): the chunk is left to the host
@@ -541,17 +544,30 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	uint64_t pool_capacity, uint32_t *__restrict__ pool_lhs, uint32_t *__restrict__ pool_rhs, uint32_t *__restrict__ pool_size,   // [n_chunks][pool_capacity]
 	uint64_t *__restrict__ rec_pool_end,                  // [n_cuts]: joined classes of the chunk up to and including this cut
 	uint32_t *__restrict__ rec_distinct, uint32_t *__restrict__ rec_first_class, uint32_t *__restrict__ rec_first_is_ref,   // [n_cuts]
-	uint32_t *__restrict__ chunk_status)
+	uint32_t *__restrict__ chunk_status,
+	unsigned short *__restrict__ class_scratch)           // [n_chunks][kPbwtClassScratchArrays][1024 * kPer] when the instantiation keeps its class arrays in global memory, else unused
 {
-	static_assert(kPer <= kPbwtPerThreadRecords, "the matching's kernel holds two class arrays and the joined classes' starts beside the state");
+	static_assert(kPer <= kPbwtPerThreadRecords, "one instantiation per copies-per-thread count up to the cut search's");
 	constexpr int kCopies = kPer * kPbwtThreads;
+	constexpr bool kInLds = kPbwtClassesInLds<kPer>;
 	__shared__ unsigned short order[kCopies];
 	__shared__ uint32_t divergence[kCopies];
 	__shared__ uint64_t column[2][kCopies / 64];
 	__shared__ uint4 wave_items[kPbwtWaves];
 	__shared__ uint4 class_items[kPbwtWaves];
-	__shared__ unsigned short copy_class[2][kCopies];             // per copy: the representative of its class at the last / the previous cut
-	__shared__ unsigned short span_start_index[kCopies];          // per joined class: where it starts in the order
+	// per copy: the representative of its class at the last / the previous cut; per joined class: where it starts in the order.  Written and read
+	// once per cut (scattered by copy number), never inside a pBWT step: beyond 12 288 copies they live in global memory (L2-resident: 120 KB per
+	// workgroup), where the same barriers order them (a workgroup's waves share their CU's L1).
+	__shared__ unsigned short copy_class_lds[kInLds ? 2 : 1][kInLds ? kCopies : 1];
+	__shared__ unsigned short span_start_index_lds[kInLds ? kCopies : 1];
+	unsigned short *const scratch = kInLds ? nullptr : class_scratch + (uint64_t) blockIdx.x * kPbwtClassScratchArrays * kCopies;
+	auto const copy_class = [&](int which) -> unsigned short * {
+		if constexpr (kInLds) return copy_class_lds[which];
+		else return scratch + (uint64_t) which * kCopies;
+	};
+	unsigned short *span_start_index;
+	if constexpr (kInLds) span_start_index = span_start_index_lds;
+	else span_start_index = scratch + 2 * kCopies;
 
 	int const t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	uint32_t const chunk = blockIdx.x;
@@ -565,10 +581,10 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 	for (uint32_t i = t; i < n_copies; i += kPbwtThreads) {
 		order[i] = (unsigned short) start_order[(uint64_t) chunk * n_copies + i];
 		divergence[i] = start_divergence[(uint64_t) chunk * n_copies + i];
-		copy_class[0][i] = (unsigned short) kPbwtNoClass;
-		copy_class[1][i] = (unsigned short) kPbwtNoClass;
+		copy_class(0)[i] = (unsigned short) kPbwtNoClass;
+		copy_class(1)[i] = (unsigned short) kPbwtNoClass;
 	}
-	int rhs = 0;                                           // copy_class[rhs]: the classes the last cut left behind
+	int rhs = 0;                                           // copy_class(rhs): the classes the last cut left behind
 	uint32_t edge = start_edge[chunk];
 	pbwt_column_stream cols = pbwt_prime_columns<kCopies / 64>(paths_by_edge, words_per_edge, edge, n_edge_columns, column, t);
 	pbwt_block_sync();
@@ -620,8 +636,8 @@ __global__ __launch_bounds__(kPbwtThreads) void pbwt_cut_records_kernel(
 		// second pass: representatives, class arrays, joined-class heads
 		uint32_t last = before.last_block_start;                       // 1 + index, 0 = none
 		uint32_t span_at = before.span_starts;
-		unsigned short const *const lhs_class = copy_class[rhs];       // (the previous cut's classes: read)
-		unsigned short *const rhs_class = copy_class[rhs ^ 1];         // (this cut's: written; the arrays swap roles below)
+		unsigned short const *const lhs_class = copy_class(rhs);       // (the previous cut's classes: read)
+		unsigned short *const rhs_class = copy_class(rhs ^ 1);         // (this cut's: written; the arrays swap roles below)
 #pragma unroll
 		for (int k = 0; k < kPer; ++k) {
 			if ((uint32_t) k < per) {

@@ -75,7 +75,7 @@ class gpu_founder_walker final : public founder_walker {
 public:
 	explicit gpu_founder_walker(gpu_context &gpu) : m_gpu(gpu) {}
 	u64 max_copies() const override { return 20480; }          // v2m_pbwt_cut_trials: csrc/founder_kernels.hpp kPbwtMaxCopies
-	u64 max_copies_records() const override { return 12288; }  // v2m_pbwt_cut_records: kPbwtMaxCopiesRecords
+	u64 max_copies_records() const override { return 20480; }  // v2m_pbwt_cut_records: kPbwtMaxCopiesRecords (its class arrays in LDS up to 12 288 copies, in device memory above)
 	std::size_t preferred_chunks() const override { return 256; }   // one workgroup per chunk, 1024 threads each: one round over 256 CUs
 	void walk(u64 n_copies, u64 min_distance, std::vector<u32> const &cand_edge, std::vector<u64> const &cand_aligned,
 		std::vector<u64> const &chunk_first, u32 const *start_order, u32 const *start_divergence,

@@ -959,11 +959,11 @@ namespace {
 
 // Calls launch(std::integral_constant<int, kPer>) with the founder kernels' instantiation for `copies` chromosome copies (the larger of the copies
 // walked and the bound matrix's columns: a thread owns kPer copies of the order, and the LDS arrays -- the staged edge column among them -- hold
-// 1024 * kPer): every count up to 8, then 10, 12, 16 and 20 (kMaxPer = the kernel's largest: 20 for the cut search, 12 for the matching).
+// 1024 * kPer): every count up to 8, then 10, 12, 16 and 20.
 template <int kMaxPer, typename t_launch>
 void pbwt_dispatch_per_thread(u64 copies, t_launch &&launch)
 {
-	static_assert(20 == v2m::kPbwtPerThread && 12 == v2m::kPbwtPerThreadRecords && (20 == kMaxPer || 12 == kMaxPer), "one case per instantiation");
+	static_assert(20 == v2m::kPbwtPerThread && 20 == v2m::kPbwtPerThreadRecords && 20 == kMaxPer, "one case per instantiation");
 	u64 const per((copies + v2m::kPbwtThreads - 1) / v2m::kPbwtThreads);      // (<= kMaxPer was checked)
 	switch (per) {
 		case 0: case 1: launch(std::integral_constant<int, 1>{}); return;
@@ -1644,12 +1644,21 @@ int v2m_pbwt_cut_records(v2m_ctx *ctx, uint64_t n_copies, uint64_t n_cuts, const
 	V2M_HIP_TRY(ctx, d_ref.ensure(n_cuts * sizeof(u32)));
 	V2M_HIP_TRY(ctx, d_status.ensure(n_chunks * sizeof(u32)));
 	V2M_HIP_TRY(ctx, hipMemsetAsync(d_status.p, 0xFF, n_chunks * sizeof(u32), ctx->stream));
+	dev_buf d_class_scratch;                                  // the class arrays of the instantiations that do not hold them in LDS (more than 12 288 copies)
+	hipError_t scratch_error(hipSuccess);
 	auto const launch_records([&](auto per_tag) {
-		hipLaunchKernelGGL((v2m::pbwt_cut_records_kernel<decltype(per_tag)::value>), dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
+		constexpr int kPer(decltype(per_tag)::value);
+		if (!v2m::kPbwtClassesInLds<kPer>) {
+			scratch_error = d_class_scratch.ensure(size_t(n_chunks) * v2m::kPbwtClassScratchArrays * v2m::kPbwtThreads * kPer * sizeof(unsigned short));
+			if (hipSuccess != scratch_error) return;
+		}
+		hipLaunchKernelGGL((v2m::pbwt_cut_records_kernel<kPer>), dim3(unsigned(n_chunks)), dim3(v2m::kPbwtThreads), 0, ctx->stream,
 			d_by_edge, u32(cols / 64), u32(n_copies), u32(rows), d_cut_edge.as<u32>(), d_chunk_first.as<u64>(), d_start_edge.as<u32>(), d_order.as<u32>(), d_div.as<u32>(),
-			pool_capacity, d_lhs.as<u32>(), d_rhs.as<u32>(), d_size.as<u32>(), d_end.as<u64>(), d_distinct.as<u32>(), d_first.as<u32>(), d_ref.as<u32>(), d_status.as<u32>());
+			pool_capacity, d_lhs.as<u32>(), d_rhs.as<u32>(), d_size.as<u32>(), d_end.as<u64>(), d_distinct.as<u32>(), d_first.as<u32>(), d_ref.as<u32>(), d_status.as<u32>(),
+			d_class_scratch.as<unsigned short>());
 	});
 	pbwt_dispatch_per_thread<v2m::kPbwtPerThreadRecords>(ctx->path_cols, launch_records);
+	V2M_HIP_TRY(ctx, scratch_error);
 	V2M_HIP_TRY(ctx, hipGetLastError());
 	V2M_HIP_TRY(ctx, hipMemcpyAsync(chunk_status, d_status.p, n_chunks * sizeof(u32), hipMemcpyDeviceToHost, ctx->stream));
 	u64 const cut_lo(chunk_first_cut[0]), cut_hi(chunk_first_cut[n_chunks]);   // only the cuts of this call's chunks
