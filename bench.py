@@ -159,6 +159,19 @@ def bind_to_numa_node(node):
 		return None
 
 
+def build_checker_once():
+	"""The CPU oracle's library (test infrastructure: loaded and called only AFTER the timed region, by every rank) is brought up to date
+	here, once -- by the parent of `python bench.py --gpus N` or by local rank 0 before the ranks' first barrier -- so that N ranks never
+	find it stale and run make side by side.  Building the checker is not using it: nothing of it is imported or loaded here."""
+	import subprocess
+	src, lib = os.path.join(ROOT, "oracle", "v2m_oracle.cc"), os.path.join(ROOT, "oracle", "libv2m_oracle.so")
+	if os.path.exists(lib) and os.path.getmtime(lib) >= os.path.getmtime(src):
+		return
+	if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCPROFILER_")) for k in os.environ):
+		sys.exit("[bench] oracle/libv2m_oracle.so is missing or stale and this process runs under a profiler: run `make -C oracle` first, without the profiler")
+	subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "-s"], stdout=sys.stderr)
+
+
 HUB_ENV = "V2M_BENCH_HUB"   # set for the children of `python bench.py --gpus N`: the parent serves barrier / gather over their pipes
 
 
@@ -177,6 +190,7 @@ def launch_ranks(n, argv):
 		rc = subprocess.call([sys.executable, "-c", "import sys; sys.path.insert(0, %r); from vcf2multialign_amd import build; build.build_native()" % ROOT], stdout=sys.stderr)
 		if rc != 0:
 			sys.exit("[bench] building the native libraries failed (exit %d)" % rc)
+		build_checker_once()
 	procs = []
 	for r in range(n):
 		env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
@@ -383,6 +397,7 @@ def main():
 				_build.build_native()   # no-op when the in-tree libraries are newer than their sources (hipcc cross-compiles gfx950)
 			except _build.StaleUnderProfiler as e:   # never a compiler launcher under a profiler's preload: build first, then profile
 				sys.exit("[bench] " + str(e))
+			build_checker_once()
 		hub.barrier()               # nobody loads the libraries before the (possible) rebuild is over
 	import vcf2multialign_amd as v2m
 	from vcf2multialign_amd import _native as N
