@@ -868,10 +868,11 @@ int splice_unaligned_slice(v2m_ctx *ctx, v2m_row_batch const *rows, u64 row_begi
 	V2M_HIP_TRY(ctx, ctx->d_tile_counts.ensure(n_rows * ctx->n_tiles * sizeof(u32)));
 	v2m::tile_tables tt{ctx->d_tile_edge_begin.as<u32>(), ctx->d_cross_offsets.as<u32>(), ctx->d_cross_edges.as<u32>()};
 	{
-		// pass 1 builds no row, so it takes more rows per workgroup than pass 2 (the template tile and its byte count are
-		// loaded once per group): V2M_COUNT_ROWS_PER_GROUP, at most 256 (kCountRowsMax)
+		// pass 1 builds no row, so it takes more rows per workgroup than pass 2 (the template tile, its byte count and the candidates' changes
+		// are set up once per group): as many as the kernel holds (kCountRowsMax = 256; measured per 620 / 244 rows of config 3 / 5: 32 rows
+		// 0.64 / 0.84 ms, 64 rows 0.48 / 0.64, 128 rows 0.41 / 0.53, 256 rows 0.38 / 0.49).  V2M_COUNT_ROWS_PER_GROUP overrides.
 		char const *const ce(std::getenv("V2M_COUNT_ROWS_PER_GROUP"));
-		u32 const count_rows(u32(std::min<u64>(std::max<u64>(1, n_rows), (ce && *ce && std::atoi(ce) > 0) ? u64(std::min(std::atoi(ce), int(v2m::kCountRowsMax))) : u64(64))));
+		u32 const count_rows(u32(std::min<u64>(std::max<u64>(1, n_rows), (ce && *ce && std::atoi(ce) > 0) ? u64(std::min(std::atoi(ce), int(v2m::kCountRowsMax))) : u64(v2m::kCountRowsMax))));
 		u32 const count_groups(u32((n_rows + count_rows - 1) / count_rows));
 		timed_launch tl(ctx, V2M_KERNEL_UNALIGNED_COUNT);
 		hipLaunchKernelGGL(v2m::count_unaligned_kernel, dim3(unsigned(u64(ctx->n_tiles) * count_groups)), dim3(v2m::kSpliceThreads), 0, ctx->stream,
