@@ -1555,12 +1555,18 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_aligned_kernel(
 
 	for (u32 row = row_begin; row < row_end; ++row) {
 		vec4u *const buf = lds[(row - row_begin) & 1];
+		// A group may hold more rows than the cache of effective-edge words (kGroupRowsLds): the template tile and the patch cache are set up once per
+		// group, the words are reloaded every kGroupRowsLds rows.  (No barrier before the reload: every read of the previous rows' words lies before
+		// the barrier inside their patch_row_tile(), which every thread has passed; the barrier below orders the reload before this row's reads.)
+		u32 const cached_row = (row - row_begin) % (u32) kGroupRowsLds;
+		if (row != row_begin && 0 == cached_row)
+			load_eff_cache(pc, job, eff, eff_words_per_row, row, row_end - row, t);
 #pragma unroll
 		for (int k = 0; k < kChunksPerThread; ++k)
 			buf[t + kSpliceThreads * k] = pristine[k];
 		__syncthreads();
 
-		patch_row_tile((unsigned char *) buf, pc, job, tt, patches, labels, eff + (u64) row * eff_words_per_row, row - row_begin, t, gap);
+		patch_row_tile((unsigned char *) buf, pc, job, tt, patches, labels, eff + (u64) row * eff_words_per_row, cached_row, t, gap);
 
 		char *const dst = out + (u64) row * row_pitch + (u64) tile * kTileBytes;
 #pragma unroll
@@ -2017,6 +2023,8 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 		bool const past_end = row >= row_end;                                  // (uniform)
 		u32 const tile_offset = past_end ? 0u : tile_offsets[(u64) row * n_tiles + tile];   // (needed after the third barrier: asked for here)
 		if (!past_end) {
+			if (row != row_begin && 0 == (row - row_begin) % (u32) kGroupRowsLds)   // (as in the aligned kernel: the next kGroupRowsLds rows' effective-edge words)
+				load_eff_cache(pc, job, eff, eff_words_per_row, row, row_end - row, t);
 #pragma unroll
 			for (int k = 0; k < kChunksPerThread; ++k)
 				lds[t + kSpliceThreads * k] = pristine[k];
@@ -2038,7 +2046,7 @@ __global__ __launch_bounds__(kSpliceThreads) void splice_unaligned_kernel(
 		}
 		if (past_end) break;
 
-		patch_row_tile((unsigned char *) lds, pc, job, tt, patches, labels, eff + (u64) row * eff_words_per_row, row - row_begin, t, 0);
+		patch_row_tile((unsigned char *) lds, pc, job, tt, patches, labels, eff + (u64) row * eff_words_per_row, (row - row_begin) % (u32) kGroupRowsLds, t, 0);
 
 		// Thread t owns the 16-B chunks t, t + 256, ...  Scanned word: surviving bytes in the low half, "short chunk" (1 ... 15 of them) in the high half.
 		vec4u v[kChunksPerThread];

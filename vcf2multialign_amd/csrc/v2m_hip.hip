@@ -668,7 +668,11 @@ u32 rows_per_group_for(u64 n_rows)
 	char const *e = std::getenv("V2M_ROWS_PER_GROUP");
 	int const v((e && *e) ? std::atoi(e) : 0);
 	if (v > 0) return u32(std::min(v, 256));   // count_unaligned_kernel holds at most 256 rows per group
-	return u32(std::min<u64>(16, std::max<u64>(1, n_rows)));
+	// 32 rows per workgroup: the template tile and the patch cache are set up once per group (a prologue of dependent L2 / HBM round trips during which
+	// the workgroup stores nothing) and the effective-edge words are reloaded every 16 rows (kGroupRowsLds).  Measured per 620 rows of config 3 /
+	// 244 of config 5 on one box (profiles/r05/rows_per_group.txt): 16 rows 9.39-9.57 / 9.07-9.35 ms (unaligned 10.65-10.84 / 11.0-11.7), 32 rows
+	// 9.06-9.32 / 9.14-9.31 (10.16-10.30 / 10.9-11.6), 48 rows 9.31-9.51 / 9.20-9.42, 64 rows 9.12-9.33 / 9.35-9.44.
+	return u32(std::min<u64>(32, std::max<u64>(1, n_rows)));
 }
 
 
