@@ -72,7 +72,8 @@ def test_transpose_fixed(ctx, case):   # tests/transpose_matrix.cc:188-251
 
 # every kernel of the product build, with the dispatch-order switches (the other shapes and flavours exist in the tuning build
 # only: tests/test_gpu_tuning_build.py)
-TRANSPOSE_KERNELS = ["8x8", "stream16", "8x8/rr", "stream16/pf", "lines8", "lines8:1", "lines8:3/sf", "lines8:8/rr", "lines8:400"]    # (the last: whole columns, merged column ends)
+TRANSPOSE_KERNELS = ["8x8", "stream16", "8x8/rr", "stream16/pf", "lines8", "lines8:1", "lines8:3/sf", "lines8:8/rr", "lines8:400",    # (the last: whole columns, merged column ends)
+	"lines16", "lines16:1", "lines16:2/sf", "lines16:5/rr", "lines16:400"]
 
 
 @pytest.mark.parametrize("kernel", TRANSPOSE_KERNELS)
@@ -615,7 +616,7 @@ def test_path_slices_reproduce_every_row(ctx, v2m, tmp_path, world):
 	assert [got[r] for r in range(n_copies + 1)] == expected
 
 
-@pytest.mark.parametrize("kernel", ["", "8x8", "stream16", "lines8", "lines8:2/sf"])
+@pytest.mark.parametrize("kernel", ["", "8x8", "stream16", "lines8", "lines8:2/sf", "lines16", "lines16:3"])
 def test_bind_path_matrix_device(ctx, v2m, tmp_path, monkeypatch, kernel):
 	"""v2m_bind_path_matrix_device: a device-resident transpose input becomes the context's own (line-aligned) path matrix;
 	every transpose kernel with a destination pitch that differs from the word count."""

@@ -39,8 +39,8 @@ def isa(request, tmp_path_factory):
 				name = None
 	assert len(kernels) > (20 if request.param == "tuning" else 12)
 	if request.param == "product":   # the measured-only shapes are not in the product library
-		# 8x8 panel, stream16, lines8 (plain and with merged column ends)
-		assert sum("transpose_bits" in k for k in kernels) == 4 and not any("ring" in k for k in kernels), sorted(k for k in kernels if "transpose_bits" in k)
+		# 8x8 panel, stream16, lines8 and lines16 (each plain and with merged column ends)
+		assert sum("transpose_bits" in k for k in kernels) == 6 and not any("ring" in k for k in kernels), sorted(k for k in kernels if "transpose_bits" in k)
 	kernels["__text__"] = out.read_text()
 	return kernels
 

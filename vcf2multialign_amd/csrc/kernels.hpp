@@ -526,8 +526,12 @@ __global__ __launch_bounds__(64 * kW) void transpose_bits_ring_kernel(
 // the column's line is read back from word s_r of them: every store is a whole, aligned 128-byte line.  Only the first and
 // last line of a span are written in two pieces (by the neighbouring spans' workgroups), and with a line-aligned pitch
 // (the library's own path matrix) s_r is 0 and the kernel degenerates into the streaming kernel.
-// A workgroup owns 8 source row-words (64-byte source runs; the panels that share the source lines are neighbours in item
-// order and on one XCD).  kWaves = 4 (two tiles per wave and step) or 8 (one).
+// A workgroup owns kTsR source row-words (the panels that share the source lines are neighbours in item order and on one XCD).
+// Product geometries: "lines8" = 8 row-words on 8 waves (64-byte source runs, one tile per wave, 112 / 146 VGPRs) and, since round 5,
+// "lines16" = 16 row-words on 8 waves, two tiles per wave (128-byte source runs, 185 / 253 VGPRs, one workgroup per CU): the L2's request
+// counters (profiles/r05/transpose_pmc.txt) showed that the 64-byte runs of a dense source, seven in eight of which straddle a sector, cost
+// lines8 14.4 M read requests per launch of the config-3 matrix where whole lines would be 5 M and 128-byte runs are 9.6 M -- and the
+// transposes' times follow the request count.  Dense forward 0.30-0.34 -> 0.26-0.28 ms (profiles/r05/transpose_lines16.txt).
 template <int kWaves, int kDepth, int kTsR = 8, int kSlabRows = 32, bool kMerge = false>
 __global__ __launch_bounds__(64 * kWaves) void transpose_bits_lines_kernel(
 	u64 const *__restrict__ src, u64 *__restrict__ dst, u64 SW, u64 DW, u64 src_pitch, u64 dst_pitch,

@@ -94,6 +94,7 @@ struct v2m_row_hold {
 
 struct v2m_ctx {
 	int device{};
+	u32 n_cus{256};          // compute units of the device (the lines16 transpose sizes its spans by it)
 	hipStream_t stream{};
 	hipStream_t copy_stream{};
 	std::string err;
@@ -317,6 +318,21 @@ template <int kWaves, int kDepth, int kTsR = 8, int kSlabRows = 32, bool kMayMer
 int launch_transpose_lines(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP, u64 DP, u64 *d_dst, u64 span_blocks, bool xcd, int order)
 {
 	u64 const P((SW + kTsR - 1) / kTsR), NB((DW + 15) / 16);
+	if (0 == span_blocks && 16 == kTsR) {
+		// lines16 (two tiles per wave: 185-253 VGPRs, ONE workgroup per CU): the grid is cut for whole rounds over the chip.  Among the span
+		// counts that leave at least 4 blocks per span, the one with the best (share of the CUs busy in the last round) x (share of the lines a
+		// span writes whole: K / (K + 1)); fewer, longer spans on a tie.  Config 3 forward (5 panels x 977 blocks): 49 spans of 20 blocks =
+		// 245 workgroups, one round (measured: 20 blocks 0.263-0.286 ms, 10 blocks 0.276-0.302, 8 / 13 / 16 blocks -- 2.4, 1.5, 1.2 rounds --
+		// 0.32-0.38); config 5 forward (20 panels x 6093 blocks): 51 spans of 120; whole columns when there are more panels than CUs.
+		u64 const n_cus(std::max<u32>(1, ctx->n_cus));
+		u64 const max_spans(std::max<u64>(1, std::min<u64>(NB / 4, 4 * n_cus / std::max<u64>(1, P) + 1)));
+		double best(-1);
+		for (u64 ns(1); ns <= max_spans; ++ns) {
+			u64 const k((NB + ns - 1) / ns), spans((NB + k - 1) / k), wgs(P * spans);
+			double const score(double(wgs) / double((wgs + n_cus - 1) / n_cus * n_cus) * double(k) / double(k + 1));
+			if (score > best * 1.005) { best = score; span_blocks = k; }
+		}
+	}
 	if (0 == span_blocks) {
 		if (NB <= 32 && P >= 1024) span_blocks = NB;
 		else {
@@ -371,7 +387,7 @@ int launch_transpose_rot(v2m_ctx *ctx, u64 const *d_src, u64 SW, u64 DW, u64 SP,
 }
 #endif   // V2M_TUNING_BUILD
 
-// Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "lines8[:K]" (spans of K blocks), "ring:R,W,S,D[,K[,slow|nt]]" (tuning build; slow = ds_bpermute
+// Kernel names: "8x8", "4x16", ... (LDS panel kR x kC), "stream16", "lines8[:K]" / "lines16[:K]" (whole lines, 8 / 16 row-words per workgroup, spans of K blocks), "ring:R,W,S,D[,K[,slow|nt]]" (tuning build; slow = ds_bpermute
 // butterfly, nt = nontemporal loads and stores); trailing "/rr" keeps the plain round-robin dispatch order instead of XCD chunks, "/pf" / "/sf" make the row
 // panels / the column panels (spans) run fastest in item order instead of the shorter dimension.
 #ifdef V2M_TUNING_BUILD
@@ -399,7 +415,7 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		int const got(std::sscanf(shape.c_str() + 5, "%d,%d,%d,%d,%d,%15s", &R, &W, &S, &D, &K, tail));
 		if (got < 4) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
 		[[maybe_unused]] bool const fast(0 != std::strcmp(tail, "slow")), nt(0 == std::strcmp(tail, "nt"));
-		// The product build holds the kernels the library picks among (kTransposeCandidates): 8x8, stream16 and lines8.  The other
+		// The product build holds the kernels the library picks among (kTransposeCandidates): 8x8, stream16, lines8 and lines16.  The other
 		// shapes and flavours measured on the way there (tools/tune_transpose.py) are compiled with -DV2M_TUNING_BUILD
 		// only (vcf2multialign_amd/libv2m_hip_tuning.so, loaded with V2M_HIP_LIBRARY by the tuning tool and the variant tests).
 #define V2M_RING_FLAVOUR(r, w, s, d, f, n) launch_transpose_ring<r, w, s, d, f, n>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order)
@@ -413,7 +429,7 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 #undef V2M_RING
 #endif
 #undef V2M_RING_FLAVOUR
-		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (the product build has 8x8, stream16 and lines8; the rest needs -DV2M_TUNING_BUILD)");
+		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (the product build has 8x8, stream16, lines8 and lines16; the rest needs -DV2M_TUNING_BUILD)");
 	}
 	if (shape == "stream16") return launch_transpose_stream<4, 64>(ctx, d_src, SW, DW, SP, DP, d_dst, xcd, order);
 #ifdef V2M_TUNING_BUILD
@@ -429,6 +445,12 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
 	}
 #endif
+	if (0 == shape.compare(0, 7, "lines16")) {
+		// "lines16[:K]": the whole-line kernel with 16 row-words per workgroup (128-byte source runs) on 8 waves, two tiles each; spans of K blocks (0 / absent = chosen per shape)
+		int K(0);
+		if (shape.size() > 7 && (':' != shape[7] || std::sscanf(shape.c_str() + 8, "%d", &K) < 1 || K < 0)) return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "bad transpose kernel name '%s'", shape.c_str());
+		return launch_transpose_lines<8, 4, 16, 32, true>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
+	}
 	if (0 == shape.compare(0, 6, "lines8")) {
 		// "lines8[:K]": spans of K blocks (0 / absent = chosen per shape); the tuning build also has "lines8:K,V" with V = another geometry
 		int K(0), V(8);
@@ -441,6 +463,11 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 		if (16 == V) return launch_transpose_lines<16, 4, 16, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);      // 16 row-words on 16 waves
 		if (168 == V) return launch_transpose_lines<16, 8, 16, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);
 		if (1 == V) return launch_transpose_lines<8, 4>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);                // the product's geometry without the merged column ends
+		if (28 == V) return launch_transpose_lines<8, 4, 16, 32>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);       // 16 row-words (128-B source runs) on 8 waves, two tiles each (round 5, late: profiles/r05/transpose_pmc.txt)
+		if (281 == V) return launch_transpose_lines<8, 4, 16, 32, true>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);  // the same, merged column ends where they apply
+		if (288 == V) return launch_transpose_lines<8, 8, 16, 32>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);      // the same with 8 steps of prefetch
+		if (282 == V) return launch_transpose_lines<8, 2, 16, 32>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);      // the same with 2 steps of prefetch
+		if (2816 == V) return launch_transpose_lines<8, 4, 16, 16>(ctx, d_src, SW, DW, SP, DP, d_dst, u64(K), xcd, order);     // the same with a 16-column slab
 #endif
 		return fail(ctx, V2M_ERR_INVALID_ARGUMENT, "transpose kernel '%s' is not in this build%s", shape.c_str(), kTuningBuild ? "" : " (needs -DV2M_TUNING_BUILD)");
 	}
@@ -475,7 +502,7 @@ int launch_transpose_named(v2m_ctx *ctx, std::string shape, u64 const *d_src, u6
 // Several kernels implement the transpose; which is fastest depends on the matrix shape, so matrices of at least 32 MiB
 // are timed once per shape and context with each candidate (the result is the same either way) and the fastest is
 // remembered.  V2M_TRANSPOSE_PANEL forces one; V2M_TRANSPOSE_CANDIDATES (comma-free list separated by ';') replaces the list.
-char const *const kTransposeCandidates[] = {"8x8", "stream16", "lines8"};
+char const *const kTransposeCandidates[] = {"8x8", "stream16", "lines8", "lines16"};
 
 // src_pitch / dst_pitch: words from one column to the next (0 = dense: n_rows / 64 and n_cols / 64).
 int launch_transpose(v2m_ctx *ctx, u64 const *d_src, u64 n_rows, u64 n_cols, u64 *d_dst, u64 src_pitch = 0, u64 dst_pitch = 0)
@@ -1016,6 +1043,7 @@ int v2m_ctx_create(int device_id, v2m_ctx **ctx_out)
 
 	auto *ctx(new v2m_ctx);
 	ctx->device = device_id;
+	if (prop.multiProcessorCount > 0) ctx->n_cus = u32(prop.multiProcessorCount);
 	if (hipSuccess != (st = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking))
 		|| hipSuccess != (st = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking))) {
 		delete ctx;
