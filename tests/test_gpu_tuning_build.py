@@ -24,6 +24,7 @@ KERNELS = ["4x16", "16x8", "16x4", "4x8", "8x4", "8x16", "ring:16,8,8,4,16", "ri
 	"ring:16,8,4,4,64", "ring:16,8,16,4,32", "ring:16,16,8,8,64/rr", "ring:8,8,8,4,64", "ring:8,8,8,8,128,nt", "ring:8,8,8,16,24/sf", "8x8", "stream16",
 	"stream16:2,64", "stream16:4,32", "stream16:2,16", "stream16:4,32,8", "stream16:2,16,8", "stream8x32", "stream8x32:8", "stream32x8", "stream4x64", "stream16:old",
 	"ring:8,8,8,8,64", "ring:8,8,8,8,128", "lines8", "lines8:2,4", "lines8:0,88", "lines8:3,816", "lines8:0,16", "lines8:2,168/sf", "lines8:400,1",
+	"lines16", "lines16:2", "lines8:3,28", "lines8:400,281", "lines8:2,282/sf", "lines8:3,2816", "lines8:2,288/rr",
 	"rot8", "rot8:1", "rot8:2/sf", "rot8:5/rr", "rot8:400", "rot8:0,88", "rot8:3,4", "rot8:0,16", "rot8:2,1616"]
 SHAPES = [(1, 1), (1, 2), (3, 5), (9, 7), (16, 17), (79, 33), (5, 130), (17, 15), (2, 200)]
 n = 0
